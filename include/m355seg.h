@@ -1,0 +1,248 @@
+/*
+ * m355seg.h — C ABI of libm355seg.so: the MI355X (gfx950) 3D U-Net hot path.
+ *
+ * This is the drop-in boundary for the efirdc/Segmentation-Pipeline hot path
+ * (SURVEY.md §8b).  The reference has no native code: every entry point below
+ * replaces a stock torch.nn op the reference calls from Python, and the comment
+ * on each one cites the reference call site (paths relative to the reference
+ * repo root) it stands in for.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - All tensors are float32 (M355_F32), NCDHW, spatial dims dense
+ *    (stride of W == 1, H == W, D == H*W, C == D*H*W).  The batch stride is
+ *    explicit (in elements) wherever a tensor may be a channel slice of a
+ *    larger concat buffer; 0 means dense (C*D*H*W).
+ *  - Caller owns every buffer, including workspace.  The library never
+ *    allocates, frees or retains device memory.
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as
+ *    void*); no implicit synchronisation.
+ *  - Return 0 (M355_OK) or a negative status; never throws, never aborts.
+ *    m355_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef M355SEG_H
+#define M355SEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M355_ABI_VERSION 1
+
+enum {
+  M355_OK = 0,
+  M355_EINVALID_ARG = -1,
+  M355_EUNSUPPORTED = -2,
+  M355_ELAUNCH = -3,
+  M355_EWORKSPACE = -4
+};
+
+enum { M355_F32 = 0 };
+
+/* activation fused into the normalise pass (components.py:26,54-55) */
+enum { M355_ACT_NONE = 0, M355_ACT_RELU = 1, M355_ACT_LEAKY_RELU = 2 };
+
+int m355_version(void);
+const char* m355_last_error(void);
+
+/* ------------------------------------------------------------------ conv3d
+ * Replaces nn.Conv3d as used by Block3d (models/components.py:36,42,51) and the
+ * out conv (models/modular_unet.py:83,99), and the strided F.conv3d of
+ * BlurConv3d (components.py:119).  Cubic kernel k, isotropic stride / zero pad.
+ *   y[n,o,z,y,x] = bias[o] + add[n,o,z,y,x]
+ *                + sum_{c,dz,dy,dx} w[o,c,dz,dy,dx] * x[n,c,z*s+dz-p, ...]
+ * `bias` and `add` may be NULL.  `add` has y's layout (residual branch fusion,
+ * components.py:67-68).  Weight layout [Cout,Cin,k,k,k] (torch).
+ */
+typedef struct m355_conv3d_desc {
+  int32_t N, Cin, Cout;
+  int32_t D, H, W;          /* INPUT spatial size of the forward op */
+  int32_t k, stride, pad;
+  int32_t out_pad;          /* conv-transpose only */
+  int64_t x_batch_stride;   /* elements; 0 = dense */
+  int64_t y_batch_stride;   /* elements; 0 = dense */
+} m355_conv3d_desc;
+
+size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d);
+int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
+                    const float* bias, const float* add, float* y,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx = conv-transpose of dy with w (autograd of the op above w.r.t. x).
+ * desc describes the FORWARD op; dx has x's shape and x_batch_stride,
+ * dy has y's shape and y_batch_stride. */
+size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d);
+int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const float* w,
+                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw[o,c,taps] = sum_{n,voxels} dy * shifted x;  dbias[o] = sum dy (NULL to skip).
+ * Deterministic (fixed-order two-stage reduction). */
+size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d);
+int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
+                           float* dw, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------- conv-transpose3d
+ * Replaces nn.ConvTranspose3d(kernel_size=2, stride=2) reached through the
+ * upsample_class hook (models/modular_unet.py:20-21,72-81,96) and the
+ * F.conv_transpose3d of BlurConvTranspose3d (components.py:152).
+ * desc: N, Cin, Cout, D/H/W = INPUT spatial, k, stride, pad, out_pad.
+ * Weight layout [Cin,Cout,k,k,k] (torch).  Output spatial =
+ * (D-1)*stride - 2*pad + k + out_pad.
+ */
+size_t m355_conv_transpose3d_workspace(const m355_conv3d_desc* d);
+int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
+                              const float* bias, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const float* w,
+                                   float* dx, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
+                                     float* dw, float* dbias,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------- normalisation (+ act)
+ * Replaces normalization_class(out_channels) + activation_class() inside
+ * Block3d (components.py:52-55): nn.BatchNorm3d (default) or nn.GroupNorm via
+ * functools.partial.  One descriptor covers both:
+ *   groups == 0 : BatchNorm — one statistic per channel over (N, voxels)
+ *   groups  > 0 : GroupNorm — one statistic per (n, group) over (C/groups, voxels)
+ * y = act((x - mean) * rstd * gamma[c] + beta[c]) (+ add, the residual branch).
+ */
+typedef struct m355_norm_desc {
+  int32_t N, C;
+  int64_t S;                /* voxels per channel (D*H*W) */
+  int32_t groups;           /* 0 = batch norm */
+  int32_t act;              /* M355_ACT_* */
+  float eps;
+  float act_slope;          /* leaky relu negative slope */
+  int64_t x_batch_stride;   /* elements; 0 = dense */
+  int64_t y_batch_stride;
+} m355_norm_desc;
+
+/* number of statistics: C for BN, N*groups for GN */
+int64_t m355_norm_num_stats(const m355_norm_desc* d);
+size_t m355_norm_workspace(const m355_norm_desc* d);
+
+/* Pass 1: mean[s], rstd[s] (biased variance, 1/sqrt(var+eps)).  For BN in
+ * training mode running_mean/running_var (may be NULL) are updated in place
+ * with `momentum` and the UNBIASED variance, as torch does. */
+int m355_norm_stats(const m355_norm_desc* d, const float* x, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* BN eval mode: derive mean/rstd from the running statistics. */
+int m355_norm_stats_from_running(const m355_norm_desc* d, const float* running_mean,
+                                 const float* running_var, float* mean, float* rstd,
+                                 void* stream);
+/* Pass 2: normalise + affine + activation (+ add).  gamma/beta/add may be NULL. */
+int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta,
+                      const float* add, float* y, void* stream);
+/* Backward.  x is the SAVED PRE-NORM input; the activation mask and x_hat are
+ * recomputed from it.  Produces dx (x's layout), dgamma[C], dbeta[C] (either may
+ * be NULL when gamma is NULL).  `training` = 0 for BN eval mode (statistics are
+ * constants, no mean-subtraction terms). */
+int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
+                      const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, float* dx, float* dgamma, float* dbeta,
+                      int training, void* workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------- pooling
+ * nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False)
+ * (models/modular_unet.py:22,41,64,92).  Input D,H,W must be even.
+ */
+int m355_avgpool3d_2x_fwd(const float* x, float* y, int32_t N, int32_t C,
+                          int32_t D, int32_t H, int32_t W,
+                          int64_t x_batch_stride, int64_t y_batch_stride, void* stream);
+int m355_avgpool3d_2x_bwd(const float* dy, float* dx, int32_t N, int32_t C,
+                          int32_t D, int32_t H, int32_t W, /* INPUT size of fwd */
+                          int64_t dy_batch_stride, int64_t dx_batch_stride, void* stream);
+
+/* ------------------------------------------------------------- upsampling
+ * nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)
+ * (models/modular_unet.py:20,39,80,96).  D,H,W = input size; output = 2x.
+ */
+int m355_upsample_trilinear2x_fwd(const float* x, float* y, int32_t N, int32_t C,
+                                  int32_t D, int32_t H, int32_t W,
+                                  int64_t x_batch_stride, int64_t y_batch_stride, void* stream);
+int m355_upsample_trilinear2x_bwd(const float* dy, float* dx, int32_t N, int32_t C,
+                                  int32_t D, int32_t H, int32_t W,
+                                  int64_t dy_batch_stride, int64_t dx_batch_stride, void* stream);
+
+/* ---------------------------------------------------------------- softmax
+ * nn.Softmax(dim=1) (models/modular_unet.py:26,46,84,100) and the softmax of
+ * StochasticMatrix (components.py:170-185): x viewed as [N, C, inner, S] with
+ * softmax over C; inner = 1 for the plain case, C for the stochastic matrix.
+ * diag_bias is added to x[n, i, i, :] first when inner == C (0 to disable).
+ */
+int m355_softmax_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t inner,
+                     int64_t S, float diag_bias, void* stream);
+int m355_softmax_bwd(const float* y, const float* dy, float* dx, int32_t N, int32_t C,
+                     int32_t inner, int64_t S, void* stream);
+
+/* ------------------------------------------------------- hybrid dice loss
+ * HybridLogisticDiceLoss.forward (criterions/hybrid_logistic_dice_loss.py:13-43).
+ * prediction p and one-hot target t: dense [N, C, S].
+ * out[0] = loss, out[1] = dice_loss, out[2] = logistic_loss.
+ * sums (workspace kept for backward): [N*C*4] = {sum p*t, sum_p, sum_t, sum t*log p_safe}
+ * where sum_p/sum_t are of squares when square_dice != 0.
+ */
+size_t m355_hybrid_loss_workspace(int32_t N, int32_t C, int64_t S);
+int m355_hybrid_loss_fwd(const float* p, const float* t, int32_t N, int32_t C, int64_t S,
+                         float dice_weight, const float* class_weights /* [C] or NULL */,
+                         int32_t square_dice, float* out3, float* sums,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* dp = dloss * d(loss)/dp, closed form from the saved sums. */
+int m355_hybrid_loss_bwd(const float* p, const float* t, const float* sums,
+                         const float* dloss /* device scalar */, int32_t N, int32_t C, int64_t S,
+                         float dice_weight, const float* class_weights, int32_t square_dice,
+                         float* dp, void* stream);
+
+/* ------------------------------------------------------------ elementwise
+ * torch.cat([x_up, x_skip], dim=1) (models/modular_unet.py:97) when the
+ * producer could not write into the concat buffer directly: strided copy of
+ * [N, C, S] (src_batch_stride) into a channel slice (dst_batch_stride).
+ * Dropout3d (components.py:58-60,70-71): y = x * scale[n*C + c].
+ */
+int m355_copy_channels(const float* src, float* dst, int32_t N, int32_t C, int64_t S,
+                       int64_t src_batch_stride, int64_t dst_batch_stride, void* stream);
+int m355_channel_scale(const float* x, const float* scale, float* y, int32_t N, int32_t C,
+                       int64_t S, void* stream);
+/* y = a + b (dense, n elements): residual add when not fused. */
+int m355_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+/* ------------------------------------------------- sliding-window patches
+ * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio
+ * 0.18.45 GridSampler / GridAggregator(overlap_mode='average').  These entry
+ * points are the tensor-level part: gather P patches [P, C, ps0, ps1, ps2] from
+ * a volume [C, V0, V1, V2] at integer corner locations loc[P,3] (i0,j0,k0), and
+ * the aggregation out[c,v] = (sum over covering patches, in patch order) /
+ * (number of covering patches).
+ */
+int m355_patch_gather(const float* volume, const int32_t* loc, float* patches,
+                      int32_t P, int32_t C, int32_t V0, int32_t V1, int32_t V2,
+                      int32_t ps0, int32_t ps1, int32_t ps2, void* stream);
+int m355_patch_accumulate(const float* patches, const int32_t* loc, float* accum /* [C,V] */,
+                          float* count /* [V] */, int32_t P, int32_t C,
+                          int32_t V0, int32_t V1, int32_t V2,
+                          int32_t ps0, int32_t ps1, int32_t ps2, void* stream);
+int m355_patch_finalize(const float* accum, const float* count, float* out,
+                        int32_t C, int64_t V, void* stream);
+
+/* ----------------------------------------------------- evaluation counts
+ * CustomArgMax (transforms/custom_label_transforms.py:267) + the TP/FP/FN/TN
+ * sums of SegmentationEvaluator (evaluators/segmentation_evaluator.py:69-86):
+ * argmax over C of prob [N,C,S] (first max wins, as torch.argmax) against an
+ * integer label map [N,S]; counts[n, c, 4] = {TP, FP, FN, TN} as int64.
+ * argmax_out (int32 [N,S]) may be NULL.
+ */
+int m355_argmax_confusion(const float* prob, const int32_t* target, int32_t* argmax_out,
+                          int64_t* counts, int32_t N, int32_t C, int64_t S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M355SEG_H */

@@ -1,0 +1,73 @@
+// Shared helpers for libm355seg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "../../include/m355seg.h"
+
+namespace m355 {
+
+void set_error(const char* fmt, ...);
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// Checks the launch that was just enqueued.  hipGetLastError is cheap and does
+// not synchronise.
+static inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return M355_ELAUNCH;
+  }
+  return M355_OK;
+}
+
+#define M355_REQUIRE(cond, code, ...)   \
+  do {                                  \
+    if (!(cond)) {                      \
+      m355::set_error(__VA_ARGS__);     \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+// wave-wide sum (64 lanes), result valid in every lane
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); result valid in thread 0
+// (and broadcast to all when BCAST).  `scratch` must hold NT/64 elements.
+template <typename T, int NT, bool BCAST = false>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // protect scratch reuse
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  T r = T(0);
+  if (BCAST || threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+  }
+  return r;
+}
+
+// Integer tuning override from the environment (0 / unset = use the built-in heuristic).
+static inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoi(v);
+}
+
+static inline int64_t dense_or(int64_t stride, int64_t dense) { return stride ? stride : dense; }
+
+}  // namespace m355

@@ -1,0 +1,811 @@
+// conv3d for gfx950: fp32 implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32,
+// k-ordered fma chain) for the 3x3x3 / stride 1 / pad 1 convolutions that carry
+// ~97 % of the U-Net FLOPs, plus generic direct kernels for every other
+// kernel-size / stride / padding the reference reaches (BlurConv3d k=4 s=2).
+//
+// Reference ops replaced: nn.Conv3d in Block3d (models/components.py:36,42,51),
+// out conv (models/modular_unet.py:83,99), F.conv3d in BlurConv3d
+// (components.py:119); autograd of those for bwd-data / bwd-weight.
+//
+// GEMM view of the 3x3x3 forward:  Y[o, v] = sum_k Wp[k, o] * X[k, v]
+//   M = Cout (A operand = packed weights), N = voxels (B operand = input read
+//   from an LDS halo tile with compile-time tap offsets), K = 27 * Cin.
+// The MFMA's k-pair (lanes 0-31 / 32-63) is (channel c, channel c+1) at the same
+// tap, so both halves use one immediate offset.
+#include "common.hpp"
+
+namespace m355 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- weight pack
+// fwd:      wp[(c*27 + tap)*cout_pad + o]          = w[(o*Cin + c)*27 + tap]
+// bwd-data: wp[(o*27 + (26-tap))*cin_pad32 + c]    = w[(o*Cin + c)*27 + tap]
+//           (the data-gradient is a conv of dy with the flipped, transposed filter)
+// Padded rows/cols are zero-filled.
+__global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                               int Cin, int kin_pad, int mout_pad, int transpose) {
+  // logical conv being run: K-channels = kin (padded to kin_pad), M-channels = mout_pad
+  const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i % mout_pad);
+    const int64_t r = i / mout_pad;
+    const int tap = (int)(r % 27);
+    const int kc = (int)(r / 27);
+    float v = 0.f;
+    if (!transpose) {
+      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
+    } else {
+      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
+    }
+    wp[i] = v;
+  }
+}
+
+// ------------------------------------------------------------ MFMA fwd kernel
+template <int NTW, int GX>
+struct FwdTile {
+  static constexpr int GY = 32 / GX;
+  static constexpr int TZ = 4;  // one z slice per wave
+  static constexpr int TY = NTW * GY;
+  static constexpr int TX = GX;
+  static constexpr int RS = TX + 2;
+  static constexpr int PS = (TY + 2) * RS;
+  static constexpr int CS = (TZ + 2) * PS;
+  static constexpr int CC = 4;  // input channels per LDS chunk (even: MFMA k-pair)
+  static constexpr int NROWS = CC * (TZ + 2) * (TY + 2);
+};
+
+template <int NTW, int GX>
+__global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
+    int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
+    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride) {
+  using T = FwdTile<NTW, GX>;
+  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
+                CS = T::CS, CC = T::CC;
+  __shared__ float xs[CC * CS];
+  __shared__ __attribute__((aligned(16))) float ws[CC * 27 * 32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const int ly = l32 / GX, lx = l32 % GX;
+
+  int bt = blockIdx.x;
+  const int txt = bt % tx_tiles;
+  bt /= tx_tiles;
+  const int tyt = bt % ty_tiles;
+  const int tzt = bt / ty_tiles;
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+  const int o0 = blockIdx.y * 32;
+  const int n = blockIdx.z / ksplit;
+  const int ks = blockIdx.z % ksplit;
+
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  const int ch_begin = ks * cps;
+  const int ch_end = min(nchunks, ch_begin + cps);
+
+  const float* xn = x + (int64_t)n * xbs;
+  const int64_t HW = (int64_t)H * W;
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  const float* xb = xs + half * CS + wave * PS + ly * RS + lx;
+  const float* wb = ws + half * (27 * 32) + l32;
+
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int c0 = ch * CC;
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage the input halo tile (zero padded) ----
+    if constexpr (RS <= 32) {
+      // two rows per wave instruction
+      const int sub = lane >> 5, col = lane & 31;
+      for (int rp = wave * 2; rp < T::NROWS; rp += 8) {
+        const int row = rp + sub;
+        const int c = row / ((TZ + 2) * (TY + 2));
+        const int rem = row - c * ((TZ + 2) * (TY + 2));
+        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + col - 1;
+        if (row < T::NROWS && col < RS) {
+          float v = 0.f;
+          if (gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
+          xs[row * RS + col] = v;
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int row = wave; row < T::NROWS; row += 4) {
+        const int c = row / ((TZ + 2) * (TY + 2));
+        const int rem = row - c * ((TZ + 2) * (TY + 2));
+        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
+        const bool rok = (gc < Cin) && gz >= 0 && gz < D && gy >= 0 && gy < H;
+        if (lane < RS) {
+          const int gx = x0 + lane - 1;
+          float v = 0.f;
+          if (rok && gx >= 0 && gx < W) v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
+          xs[row * RS + lane] = v;
+        }
+      }
+    }
+    // ---- stage the packed weights of this chunk / o-tile: CC*27 rows of 32 floats ----
+    {
+      const float* wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
+      for (int i = tid; i < CC * 27 * 8; i += 256) {
+        const int row = i >> 3, q = i & 7;
+        const float4 v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * cout_pad + q * 4);
+        *reinterpret_cast<float4*>(ws + row * 32 + q * 4) = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over K = CC * 27 ----
+#pragma unroll
+    for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const float a = wb[(2 * cp * 27 + tap) * 32];
+#pragma unroll
+        for (int g = 0; g < NTW; ++g) {
+          const float b = xb[2 * cp * CS + dz * PS + (g * GY + dy) * RS + dx];
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const int z = z0 + wave;
+  const int xg = x0 + lx;
+  if (z >= D || xg >= W) return;
+  if (ksplit == 1) {
+    float* yn = y + (int64_t)n * ybs;
+    const float* an = add ? add + (int64_t)n * ybs : nullptr;
+#pragma unroll
+    for (int g = 0; g < NTW; ++g) {
+      const int yg = y0 + g * GY + ly;
+      if (yg >= H) continue;
+      const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) {
+          const int64_t idx = (int64_t)o * D * HW + sp;
+          float v = acc[g][r];
+          if (bias) v += bias[o];
+          if (an) v += an[idx];
+          yn[idx] = v;
+        }
+      }
+    }
+  } else {
+    float* sn = slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW;
+#pragma unroll
+    for (int g = 0; g < NTW; ++g) {
+      const int yg = y0 + g * GY + ly;
+      if (yg >= H) continue;
+      const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sn[(int64_t)o * D * HW + sp] = acc[g][r];
+      }
+    }
+  }
+}
+
+// y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                     const float* __restrict__ add, float* __restrict__ y, int N,
+                                     int Cout, int64_t S, int ksplit, int64_t slab_stride,
+                                     int64_t ybs) {
+  const int64_t total = (int64_t)N * Cout * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i % S;
+    const int64_t no = i / S;
+    const int o = (int)(no % Cout);
+    const int n = (int)(no / Cout);
+    float v = slab[i];
+    for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * slab_stride + i];
+    if (bias) v += bias[o];
+    const int64_t yi = (int64_t)n * ybs + (int64_t)o * S + s;
+    if (add) v += add[yi];
+    y[yi] = v;
+  }
+}
+
+// ------------------------------------------------------- MFMA bwd-weight kernel
+// dW[o, c, tap] = sum_v dy[o, v] * x[c, v + off(tap)]
+// MFMA view: i = o (A = dy tile [32 o][256 voxels]), j = c (B = x halo tile
+// [32 c][halo]), k = a pair of x-adjacent voxels.  Each wave owns 7 of the 27 taps
+// (112 accumulator registers); the A fragment is reused across its 7 MFMAs.
+// Channel strides are == 1 (mod 32) so the 32 lanes of a half hit 32 banks.
+template <int GX>
+struct BwTile {
+  static constexpr int TX = GX;
+  static constexpr int TY = (GX == 32) ? 4 : 8;
+  static constexpr int TZ = (GX == 8) ? 4 : 2;
+  static constexpr int NV = TZ * TY * TX;  // 256
+  static constexpr int RS = TX + 2;
+  static constexpr int PS = (TY + 2) * RS;
+  static constexpr int HV = (TZ + 2) * PS;
+  static constexpr int CSW = ((HV + 30) / 32) * 32 + 1;  // >= HV, == 1 mod 32
+  static constexpr int DSW = NV + 1;
+  static constexpr int XROWS = 32 * (TZ + 2) * (TY + 2);
+};
+
+template <int GX>
+__global__ __launch_bounds__(256) void conv3_mfma_bww_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
+    int64_t xbs, int64_t ybs) {
+  using T = BwTile<GX>;
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, CSW = T::CSW,
+                DSW = T::DSW;
+  __shared__ float xs[32 * CSW];
+  __shared__ float ds[32 * DSW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ctile = blockIdx.x, otile = blockIdx.y, split = blockIdx.z;
+  const int c0 = ctile * 32, o0 = otile * 32;
+  const int64_t HW = (int64_t)H * W;
+
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(wave * 7 + t, 26);
+    toff[t] = (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3);
+  }
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* xb = xs + l32 * CSW + half;
+  const float* db = ds + l32 * DSW + half;
+
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles;
+    const int tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    const float* xn = x + (int64_t)n * xbs;
+    const float* dn = dy + (int64_t)n * ybs;
+
+    __syncthreads();
+    // stage x halo tile [32 c][TZ+2][TY+2][TX+2]
+    if constexpr (RS <= 32) {
+      const int sub = lane >> 5, col = lane & 31;
+      for (int rp = wave * 2; rp < T::XROWS; rp += 8) {
+        const int row = rp + sub;
+        const int c = row / ((TZ + 2) * (TY + 2));
+        const int rem = row - c * ((TZ + 2) * (TY + 2));
+        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + col - 1;
+        if (row < T::XROWS && col < RS) {
+          float v = 0.f;
+          if (gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
+          xs[c * CSW + zz * PS + yy * RS + col] = v;
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int row = wave; row < T::XROWS; row += 4) {
+        const int c = row / ((TZ + 2) * (TY + 2));
+        const int rem = row - c * ((TZ + 2) * (TY + 2));
+        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
+        const bool rok = (gc < Cin) && gz >= 0 && gz < D && gy >= 0 && gy < H;
+        if (lane < RS) {
+          const int gx = x0 + lane - 1;
+          float v = 0.f;
+          if (rok && gx >= 0 && gx < W) v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
+          xs[c * CSW + zz * PS + yy * RS + lane] = v;
+        }
+      }
+    }
+    // stage dy tile [32 o][TZ*TY*TX]
+    for (int i = tid; i < 32 * T::NV; i += 256) {
+      const int o = i / T::NV;
+      const int v = i - o * T::NV;
+      const int vz = v / (TY * TX), vy = (v / TX) % TY, vx = v % TX;
+      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx, go = o0 + o;
+      float val = 0.f;
+      if (go < Cout && gz < D && gy < H && gx < W)
+        val = dn[((int64_t)go * D + gz) * HW + (int64_t)gy * W + gx];
+      ds[o * DSW + v] = val;
+    }
+    __syncthreads();
+
+    for (int vz = 0; vz < TZ; ++vz) {
+      for (int vy = 0; vy < TY; ++vy) {
+        const float* xr = xb + vz * PS + vy * RS;
+        const float* dr = db + (vz * TY + vy) * TX;
+#pragma unroll
+        for (int xp = 0; xp < TX / 2; ++xp) {
+          const float a = dr[2 * xp];
+#pragma unroll
+          for (int t = 0; t < 7; ++t) {
+            const float b = xr[2 * xp + toff[t]];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // partial dW -> slab[split][Cout][Cin][27]
+  float* sl = slab + (int64_t)split * Cout * Cin * 27;
+  const int c = c0 + l32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave * 7 + t;
+    if (tap < 27 && c < Cin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
+      }
+    }
+  }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                   int64_t total, int nsplit) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = slab[i];
+    for (int s = 1; s < nsplit; ++s) v += slab[(int64_t)s * total + i];
+    out[i] = v;
+  }
+}
+
+// dbias[o] = sum_{n,s} dy[n,o,s]; one block per o, double accumulation.
+__global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ dy,
+                                                    float* __restrict__ dbias, int N, int Cout,
+                                                    int64_t S, int64_t ybs) {
+  __shared__ double scratch[4];
+  const int o = blockIdx.x;
+  double acc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = dy + (int64_t)n * ybs + (int64_t)o * S;
+    float part = 0.f;
+    int cnt = 0;
+    for (int64_t s = threadIdx.x; s < S; s += 256) {
+      part += p[s];
+      if (++cnt == 64) { acc += part; part = 0.f; cnt = 0; }
+    }
+    acc += part;
+  }
+  const double tot = block_sum<double, 256>(acc, scratch);
+  if (threadIdx.x == 0) dbias[o] = (float)tot;
+}
+
+// ------------------------------------------------------ generic direct kernels
+// Any cubic k / stride / pad; one thread per output element.  Fallback path.
+__global__ void conv3d_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ bias,
+                                         const float* __restrict__ add, float* __restrict__ y,
+                                         int N, int Cin, int Cout, int D, int H, int W, int OD,
+                                         int OH, int OW, int k, int stride, int pad, int64_t xbs,
+                                         int64_t ybs) {
+  const int64_t OS = (int64_t)OD * OH * OW;
+  const int64_t total = (int64_t)N * Cout * OS;
+  const int k3 = k * k * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    int64_t r = i / OW;
+    const int oy = (int)(r % OH);
+    r /= OH;
+    const int oz = (int)(r % OD);
+    r /= OD;
+    const int o = (int)(r % Cout);
+    const int n = (int)(r / Cout);
+    const float* xn = x + (int64_t)n * xbs;
+    float acc = 0.f;
+    for (int c = 0; c < Cin; ++c) {
+      const float* wc = w + ((int64_t)o * Cin + c) * k3;
+      const float* xc = xn + (int64_t)c * D * H * W;
+      for (int dz = 0; dz < k; ++dz) {
+        const int iz = oz * stride + dz - pad;
+        if (iz < 0 || iz >= D) continue;
+        for (int dy = 0; dy < k; ++dy) {
+          const int iy = oy * stride + dy - pad;
+          if (iy < 0 || iy >= H) continue;
+          for (int dx = 0; dx < k; ++dx) {
+            const int ix = ox * stride + dx - pad;
+            if (ix < 0 || ix >= W) continue;
+            acc = fmaf(wc[(dz * k + dy) * k + dx], xc[((int64_t)iz * H + iy) * W + ix], acc);
+          }
+        }
+      }
+    }
+    if (bias) acc += bias[o];
+    const int64_t yi = (int64_t)n * ybs + (int64_t)o * OS + ((int64_t)oz * OH + oy) * OW + ox;
+    if (add) acc += add[yi];
+    y[yi] = acc;
+  }
+}
+
+// dx[n,c,iz,iy,ix] = sum_{o,taps: (i + pad - d) % stride == 0} w[o,c,d] * dy[n,o,(i+pad-d)/stride]
+__global__ void conv3d_direct_bwd_data_kernel(const float* __restrict__ dy,
+                                              const float* __restrict__ w, float* __restrict__ dx,
+                                              int N, int Cin, int Cout, int D, int H, int W,
+                                              int OD, int OH, int OW, int k, int stride, int pad,
+                                              int64_t xbs, int64_t ybs) {
+  const int64_t S = (int64_t)D * H * W;
+  const int64_t OS = (int64_t)OD * OH * OW;
+  const int64_t total = (int64_t)N * Cin * S;
+  const int k3 = k * k * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    int64_t r = i / W;
+    const int iy = (int)(r % H);
+    r /= H;
+    const int iz = (int)(r % D);
+    r /= D;
+    const int c = (int)(r % Cin);
+    const int n = (int)(r / Cin);
+    const float* dyn = dy + (int64_t)n * ybs;
+    float acc = 0.f;
+    for (int o = 0; o < Cout; ++o) {
+      const float* wc = w + ((int64_t)o * Cin + c) * k3;
+      const float* dyo = dyn + (int64_t)o * OS;
+      for (int dz = 0; dz < k; ++dz) {
+        const int tz = iz + pad - dz;
+        if (tz < 0 || tz % stride) continue;
+        const int oz = tz / stride;
+        if (oz >= OD) continue;
+        for (int dyy = 0; dyy < k; ++dyy) {
+          const int ty = iy + pad - dyy;
+          if (ty < 0 || ty % stride) continue;
+          const int oy = ty / stride;
+          if (oy >= OH) continue;
+          for (int dxx = 0; dxx < k; ++dxx) {
+            const int tx = ix + pad - dxx;
+            if (tx < 0 || tx % stride) continue;
+            const int ox = tx / stride;
+            if (ox >= OW) continue;
+            acc = fmaf(wc[(dz * k + dyy) * k + dxx], dyo[((int64_t)oz * OH + oy) * OW + ox], acc);
+          }
+        }
+      }
+    }
+    dx[(int64_t)n * xbs + (int64_t)c * S + ((int64_t)iz * H + iy) * W + ix] = acc;
+  }
+}
+
+// dw[o,c,d] = sum_{n,ov} dy[n,o,ov] * x[n,c,ov*stride + d - pad]; one block per (o,c,tap).
+__global__ __launch_bounds__(256) void conv3d_direct_bwd_weight_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+    int Cin, int Cout, int D, int H, int W, int OD, int OH, int OW, int k, int stride, int pad,
+    int64_t xbs, int64_t ybs) {
+  __shared__ double scratch[4];
+  const int k3 = k * k * k;
+  int b = blockIdx.x;
+  const int tap = b % k3;
+  b /= k3;
+  const int c = b % Cin;
+  const int o = b / Cin;
+  const int dz = tap / (k * k), dyy = (tap / k) % k, dxx = tap % k;
+  const int64_t OS = (int64_t)OD * OH * OW;
+  double acc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* xc = x + (int64_t)n * xbs + (int64_t)c * D * H * W;
+    const float* dyo = dy + (int64_t)n * ybs + (int64_t)o * OS;
+    float part = 0.f;
+    int cnt = 0;
+    for (int64_t s = threadIdx.x; s < OS; s += 256) {
+      const int ox = (int)(s % OW);
+      const int oy = (int)((s / OW) % OH);
+      const int oz = (int)(s / ((int64_t)OW * OH));
+      const int iz = oz * stride + dz - pad, iy = oy * stride + dyy - pad,
+                ix = ox * stride + dxx - pad;
+      if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        part = fmaf(dyo[s], xc[((int64_t)iz * H + iy) * W + ix], part);
+      if (++cnt == 64) { acc += part; part = 0.f; cnt = 0; }
+    }
+    acc += part;
+  }
+  const double tot = block_sum<double, 256>(acc, scratch);
+  if (threadIdx.x == 0) dw[((int64_t)o * Cin + c) * k3 + tap] = (float)tot;
+}
+
+// ------------------------------------------------------------------ planning
+struct FwdPlan {
+  bool mfma;
+  int gx, ntw;
+  int tz_tiles, ty_tiles, tx_tiles;
+  int otiles, kin_pad, mout_pad, nchunks, ksplit;
+  size_t wp_bytes, slab_bytes;
+};
+
+// Plan for a 3x3x3/s1/p1 conv with K-channels `kin` and M-channels `mout`.
+static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W) {
+  FwdPlan p{};
+  p.mfma = true;
+  p.gx = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+  const int gy = 32 / p.gx;
+  p.kin_pad = (int)round_up(kin, 4);
+  p.mout_pad = (int)round_up(mout, 32);
+  p.otiles = p.mout_pad / 32;
+  p.nchunks = p.kin_pad / 4;
+  p.tz_tiles = (int)ceil_div(D, 4);
+  p.tx_tiles = (int)ceil_div(W, p.gx);
+  // Prefer the largest voxel tile (most reuse of the staged weights); fill the
+  // chip with split-K over input-channel chunks when the layer is small.
+  const int64_t out_bytes = (int64_t)N * mout * D * H * W * 4;
+  const int target = env_int("M355_CONV_TARGET_WG", 512);
+  const int force_ntw = env_int("M355_CONV_NTW", 0);
+  const int force_ks = env_int("M355_CONV_KSPLIT", 0);
+  const int cands[4] = {8, 4, 2, 1};
+  int chosen = 1, chosen_ks = 1;
+  for (int i = 0; i < 4; ++i) {
+    const int ntw = cands[i];
+    if (force_ntw && ntw != force_ntw) continue;
+    const int ty = ntw * gy;
+    if (ty > H && ntw > 1 && !force_ntw) continue;  // do not overhang H by a whole factor
+    const int64_t nwg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+    int64_t ks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(target, nwg),
+                                                       std::min<int64_t>(p.nchunks, 8)));
+    while (ks > 1 && ks * out_bytes > (128ll << 20)) --ks;
+    // keep every split non-empty
+    while (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) --ks;
+    chosen = ntw;
+    chosen_ks = (int)ks;
+    if (nwg * ks * 4 >= (int64_t)target * 3) break;
+  }
+  if (force_ks) {
+    chosen_ks = std::min(force_ks, p.nchunks);
+    while (chosen_ks > 1 && (chosen_ks - 1) * (int)ceil_div(p.nchunks, chosen_ks) >= p.nchunks)
+      --chosen_ks;
+  }
+  p.ntw = chosen;
+  p.ty_tiles = (int)ceil_div(H, p.ntw * gy);
+  p.ksplit = chosen_ks;
+  const int ksplit = chosen_ks;
+  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * 4, 256);
+  p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
+  return p;
+}
+
+static bool is_k3s1p1(const m355_conv3d_desc* d) {
+  return d->k == 3 && d->stride == 1 && d->pad == 1;
+}
+
+static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+template <int NTW, int GX>
+static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const float* bias,
+                       const float* add, float* y, float* slab, int N, int kin, int mout, int D,
+                       int H, int W, int64_t xbs, int64_t ybs, hipStream_t st) {
+  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
+            (unsigned)(N * p.ksplit));
+  const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
+                     y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
+                     p.ksplit, xbs, ybs, slab_stride);
+}
+
+// Runs the MFMA implicit GEMM: out[n, m, v] = bias + add + sum_{kc,tap} wp * in[n, kc, v+tap]
+static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
+                         const float* bias, const float* add, float* out, int N, int kin,
+                         int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
+                         size_t ws_bytes, hipStream_t st) {
+  const FwdPlan p = plan_mfma(N, kin, mout, D, H, W);
+  M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
+               "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
+  M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
+  float* wp = (float*)ws;
+  float* slab = (float*)((char*)ws + p.wp_bytes);
+  {
+    const int64_t total = (int64_t)p.kin_pad * 27 * p.mout_pad;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(pack_w3_kernel, dim3(blocks), dim3(256), 0, st, w, wp, Cout_w, Cin_w,
+                       p.kin_pad, p.mout_pad, transpose ? 1 : 0);
+  }
+  const float* kb = p.ksplit == 1 ? bias : nullptr;
+  const float* ka = p.ksplit == 1 ? add : nullptr;
+#define M355_FWD_CASE(NTW, GX)                                                              \
+  if (p.ntw == NTW && p.gx == GX) {                                                         \
+    launch_fwd<NTW, GX>(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, \
+                        st);                                                                \
+  } else
+  M355_FWD_CASE(8, 32)
+  M355_FWD_CASE(4, 32)
+  M355_FWD_CASE(2, 32)
+  M355_FWD_CASE(1, 32)
+  M355_FWD_CASE(8, 16)
+  M355_FWD_CASE(4, 16)
+  M355_FWD_CASE(2, 16)
+  M355_FWD_CASE(1, 16)
+  M355_FWD_CASE(8, 8)
+  M355_FWD_CASE(4, 8)
+  M355_FWD_CASE(2, 8)
+  M355_FWD_CASE(1, 8) {
+    set_error("conv3d: no kernel for ntw=%d gx=%d", p.ntw, p.gx);
+    return M355_EUNSUPPORTED;
+  }
+#undef M355_FWD_CASE
+  if (p.ksplit > 1) {
+    const int64_t S = (int64_t)D * H * W;
+    const int64_t total = (int64_t)N * mout * S;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out,
+                       N, mout, S, p.ksplit, total, out_bs);
+  }
+  return check_launch("conv3d_mfma");
+}
+
+struct BwwPlan {
+  int gx, tz_tiles, ty_tiles, tx_tiles, otiles, ctiles, nsplit;
+  size_t slab_bytes;
+};
+
+static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
+  BwwPlan p{};
+  p.gx = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+  const int tz = p.gx == 8 ? 4 : 2, ty = p.gx == 32 ? 4 : 8;
+  p.tz_tiles = (int)ceil_div(D, tz);
+  p.ty_tiles = (int)ceil_div(H, ty);
+  p.tx_tiles = (int)ceil_div(W, p.gx);
+  p.otiles = (int)ceil_div(Cout, 32);
+  p.ctiles = (int)ceil_div(Cin, 32);
+  const int64_t ntiles = (int64_t)N * p.tz_tiles * p.ty_tiles * p.tx_tiles;
+  const int64_t pairs = (int64_t)p.otiles * p.ctiles;
+  int64_t nsplit = std::max<int64_t>(1, 256 / pairs);
+  nsplit = std::min<int64_t>(nsplit, ntiles);
+  p.nsplit = (int)nsplit;
+  p.slab_bytes = (size_t)round_up((int64_t)p.nsplit * Cout * Cin * 27 * 4, 256);
+  return p;
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+// ---------------------------------------------------------------------- ABI
+extern "C" size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d) {
+  if (!d || !is_k3s1p1(d)) return 0;
+  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+  return p.wp_bytes + p.slab_bytes;
+}
+
+static int validate_conv(const m355_conv3d_desc* d, const char* who) {
+  M355_REQUIRE(d != nullptr, M355_EINVALID_ARG, "%s: null descriptor", who);
+  M355_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->D > 0 && d->H > 0 && d->W > 0,
+               M355_EINVALID_ARG, "%s: non-positive dimension", who);
+  M355_REQUIRE(d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->pad >= 0, M355_EINVALID_ARG,
+               "%s: bad k/stride/pad (%d/%d/%d)", who, d->k, d->stride, d->pad);
+  return M355_OK;
+}
+
+extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
+                               const float* bias, const float* add, float* y, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int rc = validate_conv(d, "conv3d_fwd")) return rc;
+  M355_REQUIRE(x && w && y, M355_EINVALID_ARG, "conv3d_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
+            OW = out_dim(d->W, d->k, d->stride, d->pad);
+  M355_REQUIRE(OD > 0 && OH > 0 && OW > 0, M355_EINVALID_ARG, "conv3d_fwd: empty output");
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
+  if (is_k3s1p1(d)) {
+    return run_mfma_conv(x, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
+                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st);
+  }
+  const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
+  const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
+  hipLaunchKernelGGL(conv3d_direct_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, add, y,
+                     d->N, d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k, d->stride, d->pad,
+                     xbs, ybs);
+  return check_launch("conv3d_direct_fwd");
+}
+
+extern "C" size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d) {
+  if (!d || !is_k3s1p1(d)) return 0;
+  const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W);
+  return p.wp_bytes + p.slab_bytes;
+}
+
+extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const float* w,
+                                    float* dx, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (int rc = validate_conv(d, "conv3d_bwd_data")) return rc;
+  M355_REQUIRE(dy && w && dx, M355_EINVALID_ARG, "conv3d_bwd_data: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
+            OW = out_dim(d->W, d->k, d->stride, d->pad);
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
+  if (is_k3s1p1(d)) {
+    // dx = conv(dy, flipped/transposed w): K-channels = Cout, M-channels = Cin
+    return run_mfma_conv(dy, w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin,
+                         d->D, d->H, d->W, ybs, xbs, workspace, workspace_bytes, st);
+  }
+  const int64_t total = (int64_t)d->N * d->Cin * d->D * d->H * d->W;
+  const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
+  hipLaunchKernelGGL(conv3d_direct_bwd_data_kernel, dim3(blocks), dim3(256), 0, st, dy, w, dx,
+                     d->N, d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k, d->stride, d->pad,
+                     xbs, ybs);
+  return check_launch("conv3d_direct_bwd_data");
+}
+
+extern "C" size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d) {
+  if (!d || !is_k3s1p1(d)) return 0;
+  return plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes;
+}
+
+extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
+                                      float* dw, float* dbias, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (int rc = validate_conv(d, "conv3d_bwd_weight")) return rc;
+  M355_REQUIRE(x && dy && dw, M355_EINVALID_ARG, "conv3d_bwd_weight: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
+            OW = out_dim(d->W, d->k, d->stride, d->pad);
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
+  if (is_k3s1p1(d)) {
+    const BwwPlan p = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+    M355_REQUIRE(workspace_bytes >= p.slab_bytes, M355_EWORKSPACE,
+                 "conv3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
+                 p.slab_bytes);
+    float* slab = (float*)workspace;
+    dim3 grid((unsigned)p.ctiles, (unsigned)p.otiles, (unsigned)p.nsplit);
+    if (p.gx == 32)
+      hipLaunchKernelGGL((conv3_mfma_bww_kernel<32>), grid, dim3(256), 0, st, x, dy, slab, d->N,
+                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                         p.nsplit, xbs, ybs);
+    else if (p.gx == 16)
+      hipLaunchKernelGGL((conv3_mfma_bww_kernel<16>), grid, dim3(256), 0, st, x, dy, slab, d->N,
+                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                         p.nsplit, xbs, ybs);
+    else
+      hipLaunchKernelGGL((conv3_mfma_bww_kernel<8>), grid, dim3(256), 0, st, x, dy, slab, d->N,
+                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                         p.nsplit, xbs, ybs);
+    const int64_t total = (int64_t)d->Cout * d->Cin * 27;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, total,
+                       p.nsplit);
+  } else {
+    const int k3 = d->k * d->k * d->k;
+    const int64_t nblk = (int64_t)d->Cout * d->Cin * k3;
+    M355_REQUIRE(nblk < (1ll << 31), M355_EUNSUPPORTED, "conv3d_bwd_weight: grid too large");
+    hipLaunchKernelGGL(conv3d_direct_bwd_weight_kernel, dim3((unsigned)nblk), dim3(256), 0, st, x,
+                       dy, dw, d->N, d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k,
+                       d->stride, d->pad, xbs, ybs);
+  }
+  if (dbias) {
+    hipLaunchKernelGGL(dbias_kernel, dim3((unsigned)d->Cout), dim3(256), 0, st, dy, dbias, d->N,
+                       d->Cout, (int64_t)OD * OH * OW, ybs);
+  }
+  return check_launch("conv3d_bwd_weight");
+}

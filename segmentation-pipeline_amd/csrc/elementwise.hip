@@ -1,0 +1,417 @@
+// HBM-bound streaming kernels: AvgPool3d(2,2), trilinear x2 upsampling
+// (align_corners=True), channel softmax, channel-slice copy (concat), channel
+// scale (Dropout3d) and add.
+//
+// Reference ops replaced: nn.AvgPool3d / nn.Upsample / nn.Softmax defaults of
+// ModularUNet (models/modular_unet.py:20-26,39-46,92,96,100), torch.cat
+// (modular_unet.py:97), Dropout3d and the residual add of Block3d
+// (models/components.py:58-60,67-71), StochasticMatrix softmax (components.py:170-185).
+#include "common.hpp"
+
+namespace m355 {
+
+static inline unsigned grid_for(int64_t work, int per_block = 256, int64_t cap = 8192) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, per_block), cap));
+}
+
+// ------------------------------------------------------------------ avg pool
+// torch accumulates the window in (z, y, x) order and divides by the window size.
+template <bool VEC>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int N, int C,
+                                                           int D, int H, int W, int64_t xbs,
+                                                           int64_t ybs) {
+  const int OD = D / 2, OH = H / 2, OW = W / 2;
+  const int OWV = VEC ? OW / 2 : OW;  // VEC: two outputs per thread
+  const int64_t total = (int64_t)N * C * OD * OH * OWV;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ox = (int)(i % OWV);
+    int64_t r = i / OWV;
+    const int oy = (int)(r % OH);
+    r /= OH;
+    const int oz = (int)(r % OD);
+    r /= OD;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const float* xp = x + (int64_t)n * xbs + (int64_t)c * D * H * W;
+    float* yp = y + (int64_t)n * ybs + (int64_t)c * OD * OH * OW;
+    const int64_t r00 = ((int64_t)(2 * oz) * H + 2 * oy) * W;
+    const int64_t r01 = r00 + W, r10 = r00 + (int64_t)H * W, r11 = r10 + W;
+    if (VEC) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + r00 + 4 * ox);
+      const float4 b = *reinterpret_cast<const float4*>(xp + r01 + 4 * ox);
+      const float4 cc = *reinterpret_cast<const float4*>(xp + r10 + 4 * ox);
+      const float4 d = *reinterpret_cast<const float4*>(xp + r11 + 4 * ox);
+      float2 o;
+      o.x = (((((((a.x + a.y) + b.x) + b.y) + cc.x) + cc.y) + d.x) + d.y) * 0.125f;
+      o.y = (((((((a.z + a.w) + b.z) + b.w) + cc.z) + cc.w) + d.z) + d.w) * 0.125f;
+      *reinterpret_cast<float2*>(yp + ((int64_t)oz * OH + oy) * OW + 2 * ox) = o;
+    } else {
+      const int xi = 2 * ox;
+      const float s = ((((((xp[r00 + xi] + xp[r00 + xi + 1]) + xp[r01 + xi]) + xp[r01 + xi + 1]) +
+                         xp[r10 + xi]) + xp[r10 + xi + 1]) + xp[r11 + xi]) + xp[r11 + xi + 1];
+      yp[((int64_t)oz * OH + oy) * OW + ox] = s * 0.125f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int N, int C,
+                                                           int D, int H, int W, int64_t dybs,
+                                                           int64_t dxbs) {
+  const int OD = D / 2, OH = H / 2, OW = W / 2;
+  const int W2 = W / 2;  // one thread per x pair
+  const int64_t total = (int64_t)N * C * D * H * W2;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int xp = (int)(i % W2);
+    int64_t r = i / W2;
+    const int iy = (int)(r % H);
+    r /= H;
+    const int iz = (int)(r % D);
+    r /= D;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const float g = dy[(int64_t)n * dybs + (int64_t)c * OD * OH * OW +
+                       ((int64_t)(iz / 2) * OH + iy / 2) * OW + xp] * 0.125f;
+    float* o = dx + (int64_t)n * dxbs + (int64_t)c * D * H * W + ((int64_t)iz * H + iy) * W + 2 * xp;
+    o[0] = g;
+    o[1] = g;
+  }
+}
+
+// --------------------------------------------------------- trilinear upsample
+// aten/src/ATen/native/UpSample.h semantics for align_corners=True:
+//   ratio = (in-1)/(out-1) (float), src = ratio*o, i0 = min(floor(src), in-1),
+//   l1 = clamp(src - i0, 0, 1), l0 = 1 - l1, i1 = i0 + (i0 < in-1)
+struct Lin {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
+  Lin r;
+  if (in == out) {
+    r.i0 = r.i1 = o; r.l0 = 1.f; r.l1 = 0.f;
+    return r;
+  }
+  const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = ratio * (float)o;
+  r.i0 = min((int)floorf(src), in - 1);
+  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  r.l0 = 1.f - r.l1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void trilinear2_fwd_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ y, int N, int C,
+                                                             int D, int H, int W, int64_t xbs,
+                                                             int64_t ybs) {
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const int64_t total = (int64_t)N * C * OD * OH * OW;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ox = (int)(i % OW);
+    int64_t r = i / OW;
+    const int oy = (int)(r % OH);
+    r /= OH;
+    const int oz = (int)(r % OD);
+    r /= OD;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const Lin lz = lin_coord(oz, D, OD), ly = lin_coord(oy, H, OH), lx = lin_coord(ox, W, OW);
+    const float* xp = x + (int64_t)n * xbs + (int64_t)c * D * H * W;
+    auto row = [&](int z, int yy) {
+      const float* p = xp + ((int64_t)z * H + yy) * W;
+      return lx.l0 * p[lx.i0] + lx.l1 * p[lx.i1];
+    };
+    const float v0 = ly.l0 * row(lz.i0, ly.i0) + ly.l1 * row(lz.i0, ly.i1);
+    const float v1 = ly.l0 * row(lz.i1, ly.i0) + ly.l1 * row(lz.i1, ly.i1);
+    y[(int64_t)n * ybs + (int64_t)c * OD * OH * OW + ((int64_t)oz * OH + oy) * OW + ox] =
+        lz.l0 * v0 + lz.l1 * v1;
+  }
+}
+
+// weight with which output o (size out) reads input i (size in)
+__device__ __forceinline__ float lin_weight(int o, int i, int in, int out) {
+  if (o < 0 || o >= out) return 0.f;
+  const Lin l = lin_coord(o, in, out);
+  return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
+}
+
+// gather-form backward (deterministic): every output index that can read input i
+// lies in [2i-3, 2i+4] for out = 2*in (trilinear backward).
+__global__ __launch_bounds__(256) void trilinear2_bwd_kernel(const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int N, int C,
+                                                             int D, int H, int W, int64_t dybs,
+                                                             int64_t dxbs) {
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const int64_t total = (int64_t)N * C * D * H * W;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ix = (int)(i % W);
+    int64_t r = i / W;
+    const int iy = (int)(r % H);
+    r /= H;
+    const int iz = (int)(r % D);
+    r /= D;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const float* dp = dy + (int64_t)n * dybs + (int64_t)c * OD * OH * OW;
+    float wx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wx[k] = lin_weight(2 * ix - 3 + k, ix, W, OW);
+    float acc = 0.f;
+    for (int kz = 0; kz < 8; ++kz) {
+      const int oz = 2 * iz - 3 + kz;
+      const float wz = lin_weight(oz, iz, D, OD);
+      if (wz == 0.f) continue;
+      for (int ky = 0; ky < 8; ++ky) {
+        const int oy = 2 * iy - 3 + ky;
+        const float wy = lin_weight(oy, iy, H, OH);
+        if (wy == 0.f) continue;
+        const float* row = dp + ((int64_t)oz * OH + oy) * OW;
+        float racc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ox = 2 * ix - 3 + k;
+          if (wx[k] != 0.f) racc = fmaf(wx[k], row[ox], racc);
+        }
+        acc = fmaf(wz * wy, racc, acc);
+      }
+    }
+    dx[(int64_t)n * dxbs + (int64_t)c * D * H * W + ((int64_t)iz * H + iy) * W + ix] = acc;
+  }
+}
+
+// -------------------------------------------------------------------- softmax
+// x viewed as [N, C, inner, S]; softmax over C.  One thread per (n, inner, s).
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ y, int N, int C,
+                                                          int inner, int64_t S, float diag_bias) {
+  const int64_t total = (int64_t)N * inner * S;
+  const int64_t cstride = (int64_t)inner * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t s = i % S;
+    const int64_t r = i / S;
+    const int in = (int)(r % inner);
+    const int n = (int)(r / inner);
+    const int64_t base = ((int64_t)n * C * inner + in) * S + s;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      float v = x[base + c * cstride];
+      if (inner > 1 && c == in) v += diag_bias;
+      mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float v = x[base + c * cstride];
+      if (inner > 1 && c == in) v += diag_bias;
+      sum += expf(v - mx);
+    }
+    const float inv = 1.f / sum;
+    for (int c = 0; c < C; ++c) {
+      float v = x[base + c * cstride];
+      if (inner > 1 && c == in) v += diag_bias;
+      y[base + c * cstride] = expf(v - mx) * inv;
+    }
+  }
+}
+
+// dx_c = y_c * (dy_c - sum_j y_j dy_j)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y,
+                                                          const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int N, int C,
+                                                          int inner, int64_t S) {
+  const int64_t total = (int64_t)N * inner * S;
+  const int64_t cstride = (int64_t)inner * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t s = i % S;
+    const int64_t r = i / S;
+    const int in = (int)(r % inner);
+    const int n = (int)(r / inner);
+    const int64_t base = ((int64_t)n * C * inner + in) * S + s;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = fmaf(y[base + c * cstride], dy[base + c * cstride], dot);
+    for (int c = 0; c < C; ++c)
+      dx[base + c * cstride] = y[base + c * cstride] * (dy[base + c * cstride] - dot);
+  }
+}
+
+// ------------------------------------------------------- copy / scale / add
+template <bool VEC>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src,
+                                                            float* __restrict__ dst, int N,
+                                                            int64_t CS, int64_t sbs, int64_t dbs) {
+  // CS = C*S contiguous floats per sample
+  const int64_t per = VEC ? CS / 4 : CS;
+  const int64_t total = (int64_t)N * per;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t n = i / per, k = i - n * per;
+    if (VEC)
+      reinterpret_cast<float4*>(dst + n * dbs)[k] = reinterpret_cast<const float4*>(src + n * sbs)[k];
+    else
+      dst[n * dbs + k] = src[n * sbs + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_scale_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ scale,
+                                                            float* __restrict__ y, int64_t NC,
+                                                            int64_t S) {
+  const int64_t total = NC * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll)
+    y[i] = x[i] * scale[i / S];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
+                                                  const float* __restrict__ b,
+                                                  float* __restrict__ y, int64_t n) {
+  const int64_t total = VEC ? n / 4 : n;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    if (VEC) {
+      const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+      reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    } else {
+      y[i] = a[i] + b[i];
+    }
+  }
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+static int check_ncdhw(int N, int C, int D, int H, int W, const char* who) {
+  M355_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, M355_EINVALID_ARG,
+               "%s: non-positive dimension", who);
+  return M355_OK;
+}
+
+extern "C" int m355_avgpool3d_2x_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t D,
+                                     int32_t H, int32_t W, int64_t x_batch_stride,
+                                     int64_t y_batch_stride, void* stream) {
+  if (int rc = check_ncdhw(N, C, D, H, W, "avgpool3d_2x_fwd")) return rc;
+  M355_REQUIRE(x && y, M355_EINVALID_ARG, "avgpool3d_2x_fwd: null pointer");
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED,
+               "avgpool3d_2x_fwd: odd spatial size (%d,%d,%d)", D, H, W);
+  const int64_t xbs = dense_or(x_batch_stride, (int64_t)C * D * H * W);
+  const int64_t ybs = dense_or(y_batch_stride, (int64_t)C * (D / 2) * (H / 2) * (W / 2));
+  const bool vec = (W % 4 == 0) && (xbs % 4 == 0) && (ybs % 2 == 0) && ((uintptr_t)x & 15) == 0 &&
+                   ((uintptr_t)y & 7) == 0;
+  const int64_t total = (int64_t)N * C * (D / 2) * (H / 2) * (vec ? W / 4 : W / 2);
+  if (vec)
+    hipLaunchKernelGGL(avgpool2_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, C, D, H, W, xbs, ybs);
+  else
+    hipLaunchKernelGGL(avgpool2_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, C, D, H, W, xbs, ybs);
+  return check_launch("avgpool3d_2x_fwd");
+}
+
+extern "C" int m355_avgpool3d_2x_bwd(const float* dy, float* dx, int32_t N, int32_t C, int32_t D,
+                                     int32_t H, int32_t W, int64_t dy_batch_stride,
+                                     int64_t dx_batch_stride, void* stream) {
+  if (int rc = check_ncdhw(N, C, D, H, W, "avgpool3d_2x_bwd")) return rc;
+  M355_REQUIRE(dy && dx, M355_EINVALID_ARG, "avgpool3d_2x_bwd: null pointer");
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED,
+               "avgpool3d_2x_bwd: odd spatial size (%d,%d,%d)", D, H, W);
+  const int64_t dxbs = dense_or(dx_batch_stride, (int64_t)C * D * H * W);
+  const int64_t dybs = dense_or(dy_batch_stride, (int64_t)C * (D / 2) * (H / 2) * (W / 2));
+  const int64_t total = (int64_t)N * C * D * H * (W / 2);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     dy, dx, N, C, D, H, W, dybs, dxbs);
+  return check_launch("avgpool3d_2x_bwd");
+}
+
+extern "C" int m355_upsample_trilinear2x_fwd(const float* x, float* y, int32_t N, int32_t C,
+                                             int32_t D, int32_t H, int32_t W,
+                                             int64_t x_batch_stride, int64_t y_batch_stride,
+                                             void* stream) {
+  if (int rc = check_ncdhw(N, C, D, H, W, "upsample_trilinear2x_fwd")) return rc;
+  M355_REQUIRE(x && y, M355_EINVALID_ARG, "upsample_trilinear2x_fwd: null pointer");
+  const int64_t xbs = dense_or(x_batch_stride, (int64_t)C * D * H * W);
+  const int64_t ybs = dense_or(y_batch_stride, (int64_t)C * D * H * W * 8);
+  const int64_t total = (int64_t)N * C * D * H * W * 8;
+  hipLaunchKernelGGL(trilinear2_fwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, N, C, D, H, W, xbs, ybs);
+  return check_launch("upsample_trilinear2x_fwd");
+}
+
+extern "C" int m355_upsample_trilinear2x_bwd(const float* dy, float* dx, int32_t N, int32_t C,
+                                             int32_t D, int32_t H, int32_t W,
+                                             int64_t dy_batch_stride, int64_t dx_batch_stride,
+                                             void* stream) {
+  if (int rc = check_ncdhw(N, C, D, H, W, "upsample_trilinear2x_bwd")) return rc;
+  M355_REQUIRE(dy && dx, M355_EINVALID_ARG, "upsample_trilinear2x_bwd: null pointer");
+  const int64_t dxbs = dense_or(dx_batch_stride, (int64_t)C * D * H * W);
+  const int64_t dybs = dense_or(dy_batch_stride, (int64_t)C * D * H * W * 8);
+  const int64_t total = (int64_t)N * C * D * H * W;
+  hipLaunchKernelGGL(trilinear2_bwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, N, C, D, H, W, dybs, dxbs);
+  return check_launch("upsample_trilinear2x_bwd");
+}
+
+extern "C" int m355_softmax_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t inner,
+                                int64_t S, float diag_bias, void* stream) {
+  M355_REQUIRE(x && y, M355_EINVALID_ARG, "softmax_fwd: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && inner > 0 && S > 0, M355_EINVALID_ARG,
+               "softmax_fwd: non-positive size");
+  M355_REQUIRE(inner == 1 || inner == C, M355_EINVALID_ARG,
+               "softmax_fwd: inner must be 1 or C (stochastic matrix)");
+  const int64_t total = (int64_t)N * inner * S;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, N, C, inner, S, diag_bias);
+  return check_launch("softmax_fwd");
+}
+
+extern "C" int m355_softmax_bwd(const float* y, const float* dy, float* dx, int32_t N, int32_t C,
+                                int32_t inner, int64_t S, void* stream) {
+  M355_REQUIRE(y && dy && dx, M355_EINVALID_ARG, "softmax_bwd: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && inner > 0 && S > 0, M355_EINVALID_ARG,
+               "softmax_bwd: non-positive size");
+  const int64_t total = (int64_t)N * inner * S;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y,
+                     dy, dx, N, C, inner, S);
+  return check_launch("softmax_bwd");
+}
+
+extern "C" int m355_copy_channels(const float* src, float* dst, int32_t N, int32_t C, int64_t S,
+                                  int64_t src_batch_stride, int64_t dst_batch_stride,
+                                  void* stream) {
+  M355_REQUIRE(src && dst, M355_EINVALID_ARG, "copy_channels: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0, M355_EINVALID_ARG, "copy_channels: non-positive size");
+  const int64_t CS = (int64_t)C * S;
+  const int64_t sbs = dense_or(src_batch_stride, CS), dbs = dense_or(dst_batch_stride, CS);
+  const bool vec = (CS % 4 == 0) && (sbs % 4 == 0) && (dbs % 4 == 0) &&
+                   (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  const int64_t total = (int64_t)N * (vec ? CS / 4 : CS);
+  if (vec)
+    hipLaunchKernelGGL(copy_channels_kernel<true>, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, CS, sbs, dbs);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<false>, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, CS, sbs, dbs);
+  return check_launch("copy_channels");
+}
+
+extern "C" int m355_channel_scale(const float* x, const float* scale, float* y, int32_t N, int32_t C,
+                                  int64_t S, void* stream) {
+  M355_REQUIRE(x && scale && y, M355_EINVALID_ARG, "channel_scale: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0, M355_EINVALID_ARG, "channel_scale: non-positive size");
+  const int64_t total = (int64_t)N * C * S;
+  hipLaunchKernelGGL(channel_scale_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     x, scale, y, (int64_t)N * C, S);
+  return check_launch("channel_scale");
+}
+
+extern "C" int m355_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  M355_REQUIRE(a && b && y, M355_EINVALID_ARG, "add: null pointer");
+  M355_REQUIRE(n > 0, M355_EINVALID_ARG, "add: non-positive size");
+  const bool vec = (n % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(add_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, y, n);
+  else
+    hipLaunchKernelGGL(add_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, y, n);
+  return check_launch("add");
+}

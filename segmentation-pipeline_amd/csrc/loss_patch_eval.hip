@@ -1,0 +1,327 @@
+// Hybrid logistic + Dice loss (fwd/bwd), sliding-window patch gather /
+// aggregation, and argmax + confusion counts.  All HBM-bound single-pass kernels.
+//
+// Reference code replaced:
+//   HybridLogisticDiceLoss.forward  criterions/hybrid_logistic_dice_loss.py:13-43
+//   PatchPredict tiling/aggregation prediction.py:132-143 (torchio GridSampler /
+//     GridAggregator(overlap_mode='average'))
+//   CustomArgMax + SegmentationEvaluator counts
+//     transforms/custom_label_transforms.py:267, evaluators/segmentation_evaluator.py:69-86
+#include "common.hpp"
+
+namespace m355 {
+
+constexpr int LOSS_CHUNK = 16384;
+
+// partial[((n*C + c)*nblk + b)*4 + k], k: 0 = sum p*t, 1 = sum p(^2), 2 = sum t(^2),
+// 3 = sum t*log(p_safe)
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ p,
+                                                           const float* __restrict__ t,
+                                                           double* __restrict__ partial, int64_t S,
+                                                           int square_dice, int nblk) {
+  __shared__ double scratch[4];
+  const int b = blockIdx.x;
+  const int64_t nc = blockIdx.y;
+  const float* pp = p + nc * S;
+  const float* tp = t + nc * S;
+  const int64_t begin = (int64_t)b * LOSS_CHUNK, end = min(S, begin + LOSS_CHUNK);
+  // reference: eps = 1e-8; prediction_safe = (prediction + eps) / (1 + eps), evaluated by
+  // torch in fp32 with the python scalars rounded to fp32 (1 + 1e-8 == 1.0f)
+  const float eps = 1e-8f;
+  const float denom = (float)(1.0 + 1e-8);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+    const float pv = pp[i], tv = tp[i];
+    s0 = fmaf(pv, tv, s0);
+    if (square_dice) {
+      s1 = fmaf(pv, pv, s1);
+      s2 = fmaf(tv, tv, s2);
+    } else {
+      s1 += pv;
+      s2 += tv;
+    }
+    const float ps = (pv + eps) / denom;
+    s3 = fmaf(tv, logf(ps), s3);
+  }
+  const double t0 = block_sum<double, 256>((double)s0, scratch);
+  const double t1 = block_sum<double, 256>((double)s1, scratch);
+  const double t2 = block_sum<double, 256>((double)s2, scratch);
+  const double t3 = block_sum<double, 256>((double)s3, scratch);
+  if (threadIdx.x == 0) {
+    double* o = partial + (nc * nblk + b) * 4;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+  }
+}
+
+// single block: sums[nc*4+k], out3 = {loss, dice_loss, logistic_loss}
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ partial,
+                                                            const float* __restrict__ class_w,
+                                                            float* __restrict__ sums,
+                                                            float* __restrict__ out3, int N, int C,
+                                                            int64_t S, int nblk, float dice_weight) {
+  __shared__ double scratch[4];
+  const int NC = N * C;
+  double dice_acc = 0.0, log_acc = 0.0;
+  for (int nc = threadIdx.x; nc < NC; nc += 256) {
+    double v[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblk; ++b)
+      for (int k = 0; k < 4; ++k) v[k] += partial[((int64_t)nc * nblk + b) * 4 + k];
+    for (int k = 0; k < 4; ++k) sums[nc * 4 + k] = (float)v[k];
+    // dice_coeffs = 2*overlap / (total + eps)   (fp32 in the reference)
+    const float overlap = (float)v[0], total = (float)v[1] + (float)v[2];
+    const float dice = 2.f * overlap / (total + 1e-8f);
+    dice_acc += (double)(1.f - dice);
+    float logistic = (float)(v[3] / (double)S);  // torch.mean over spatial dims
+    if (class_w) logistic *= class_w[nc % C];
+    log_acc += (double)(-logistic);
+  }
+  const double d = block_sum<double, 256>(dice_acc, scratch);
+  const double l = block_sum<double, 256>(log_acc, scratch);
+  if (threadIdx.x == 0) {
+    const float dice_loss = (float)(d / NC), logistic_loss = (float)(l / NC);
+    out3[0] = (1.f - dice_weight) * logistic_loss + dice_weight * dice_loss;
+    out3[1] = dice_loss;
+    out3[2] = logistic_loss;
+  }
+}
+
+// dp = dloss * [ (1-w) * d(logistic_loss)/dp + w * d(dice_loss)/dp ]
+//   d logistic_loss / dp = -cw[c] * t / ((p + eps) ) / (N*C*S)          (denominator 1+eps == 1)
+//   d dice_loss / dp     = -(1/(N*C)) * (2 t / (T+eps) - 2 O * dT/dp / (T+eps)^2)
+//                          dT/dp = 2p (square_dice) or 1
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ p,
+                                                       const float* __restrict__ t,
+                                                       const float* __restrict__ sums,
+                                                       const float* __restrict__ dloss,
+                                                       const float* __restrict__ class_w,
+                                                       float* __restrict__ dp, int N, int C,
+                                                       int64_t S, float dice_weight,
+                                                       int square_dice) {
+  const int64_t nc = blockIdx.y;
+  const float g = dloss[0];
+  const float O = sums[nc * 4 + 0];
+  const float T = sums[nc * 4 + 1] + sums[nc * 4 + 2] + 1e-8f;
+  const float inv_nc = 1.f / (float)(N * C);
+  const float cw = class_w ? class_w[nc % C] : 1.f;
+  const float klog = -(1.f - dice_weight) * cw * inv_nc / (float)S * g;
+  const float kd1 = -dice_weight * inv_nc * 2.f / T * g;          // * t
+  const float kd2 = dice_weight * inv_nc * 2.f * O / (T * T) * g;  // * dT/dp
+  const float denom = (float)(1.0 + 1e-8);
+  const float* pp = p + nc * S;
+  const float* tp = t + nc * S;
+  float* op = dp + nc * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
+    const float pv = pp[i], tv = tp[i];
+    const float ps = (pv + 1e-8f) / denom;
+    float d = klog * tv / (ps * denom);
+    d = fmaf(kd1, tv, d);
+    d = fmaf(kd2, square_dice ? 2.f * pv : 1.f, d);
+    op[i] = d;
+  }
+}
+
+// ------------------------------------------------------------------ patches
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ vol,
+                                                           const int32_t* __restrict__ loc,
+                                                           float* __restrict__ patches, int P,
+                                                           int C, int V0, int V1, int V2, int ps0,
+                                                           int ps1, int ps2) {
+  const int64_t PS = (int64_t)ps0 * ps1 * ps2;
+  const int64_t total = (int64_t)P * C * PS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int k = (int)(i % ps2);
+    int64_t r = i / ps2;
+    const int j = (int)(r % ps1);
+    r /= ps1;
+    const int ii = (int)(r % ps0);
+    r /= ps0;
+    const int c = (int)(r % C);
+    const int pidx = (int)(r / C);
+    const int i0 = loc[pidx * 3], j0 = loc[pidx * 3 + 1], k0 = loc[pidx * 3 + 2];
+    patches[i] = vol[(((int64_t)c * V0 + (i0 + ii)) * V1 + (j0 + j)) * V2 + (k0 + k)];
+  }
+}
+
+// gather-form, deterministic: each output voxel sums the covering patches in patch order
+// (== torchio's sequential `output[...] += patch` over the batch) and counts them.
+__global__ __launch_bounds__(256) void patch_accumulate_kernel(const float* __restrict__ patches,
+                                                               const int32_t* __restrict__ loc,
+                                                               float* __restrict__ accum,
+                                                               float* __restrict__ count, int P,
+                                                               int C, int V0, int V1, int V2,
+                                                               int ps0, int ps1, int ps2) {
+  const int64_t V = (int64_t)V0 * V1 * V2;
+  const int64_t PS = (int64_t)ps0 * ps1 * ps2;
+  for (int64_t v = blockIdx.x * 256ll + threadIdx.x; v < V; v += gridDim.x * 256ll) {
+    const int k = (int)(v % V2);
+    const int j = (int)((v / V2) % V1);
+    const int i = (int)(v / ((int64_t)V2 * V1));
+    float cnt = count[v];
+    for (int pidx = 0; pidx < P; ++pidx) {
+      const int i0 = loc[pidx * 3], j0 = loc[pidx * 3 + 1], k0 = loc[pidx * 3 + 2];
+      const int di = i - i0, dj = j - j0, dk = k - k0;
+      if (di < 0 || di >= ps0 || dj < 0 || dj >= ps1 || dk < 0 || dk >= ps2) continue;
+      const int64_t off = ((int64_t)di * ps1 + dj) * ps2 + dk;
+      for (int c = 0; c < C; ++c)
+        accum[(int64_t)c * V + v] += patches[((int64_t)pidx * C + c) * PS + off];
+      cnt += 1.f;
+    }
+    count[v] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void patch_finalize_kernel(const float* __restrict__ accum,
+                                                             const float* __restrict__ count,
+                                                             float* __restrict__ out, int C,
+                                                             int64_t V) {
+  const int64_t total = (int64_t)C * V;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll)
+    out[i] = accum[i] / count[i % V];
+}
+
+// ------------------------------------------------------- argmax + confusion
+// counts[(n*C + c)*4 + {TP, FP, FN, TN}]; block-level reduction then one atomic per
+// (block, class, stat) -- integer adds, so the result is order-independent.
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ prob,
+                                                               const int32_t* __restrict__ target,
+                                                               int32_t* __restrict__ argmax_out,
+                                                               unsigned long long* __restrict__ counts,
+                                                               int C, int64_t S) {
+  extern __shared__ unsigned int sh[];  // C*3: TP, FP, FN per class
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < C * 3; i += 256) sh[i] = 0;
+  __syncthreads();
+  const float* pn = prob + (int64_t)n * C * S;
+  for (int64_t s = blockIdx.x * 256ll + threadIdx.x; s < S; s += gridDim.x * 256ll) {
+    int best = 0;
+    float bv = pn[s];
+    for (int c = 1; c < C; ++c) {
+      const float v = pn[(int64_t)c * S + s];
+      if (v > bv) { bv = v; best = c; }  // first maximum wins (torch.argmax)
+    }
+    if (argmax_out) argmax_out[(int64_t)n * S + s] = best;
+    const int tg = target[(int64_t)n * S + s];
+    if (best == tg) {
+      atomicAdd(&sh[best * 3 + 0], 1u);
+    } else {
+      atomicAdd(&sh[best * 3 + 1], 1u);
+      if (tg >= 0 && tg < C) atomicAdd(&sh[tg * 3 + 2], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 3; i += 256) {
+    if (sh[i]) atomicAdd(&counts[((int64_t)n * C + i / 3) * 4 + (i % 3)], (unsigned long long)sh[i]);
+  }
+}
+
+// TN = S - TP - FP - FN
+__global__ void confusion_tn_kernel(unsigned long long* __restrict__ counts, int NC, int64_t S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NC)
+    counts[i * 4 + 3] = (unsigned long long)S - counts[i * 4] - counts[i * 4 + 1] - counts[i * 4 + 2];
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" size_t m355_hybrid_loss_workspace(int32_t N, int32_t C, int64_t S) {
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  return (size_t)N * C * ceil_div(S, LOSS_CHUNK) * 4 * sizeof(double) + 256;
+}
+
+extern "C" int m355_hybrid_loss_fwd(const float* p, const float* t, int32_t N, int32_t C, int64_t S,
+                                    float dice_weight, const float* class_weights,
+                                    int32_t square_dice, float* out3, float* sums, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  M355_REQUIRE(p && t && out3 && sums && workspace, M355_EINVALID_ARG, "hybrid_loss_fwd: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0, M355_EINVALID_ARG, "hybrid_loss_fwd: non-positive size");
+  M355_REQUIRE((int64_t)N * C <= 65535, M355_EUNSUPPORTED, "hybrid_loss_fwd: N*C > 65535");
+  M355_REQUIRE(workspace_bytes >= m355_hybrid_loss_workspace(N, C, S), M355_EWORKSPACE,
+               "hybrid_loss_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)ceil_div(S, LOSS_CHUNK);
+  double* partial = (double*)workspace;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)nblk, (unsigned)(N * C)), dim3(256), 0, st,
+                     p, t, partial, S, square_dice, nblk);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, class_weights, sums,
+                     out3, N, C, S, nblk, dice_weight);
+  return check_launch("hybrid_loss_fwd");
+}
+
+extern "C" int m355_hybrid_loss_bwd(const float* p, const float* t, const float* sums,
+                                    const float* dloss, int32_t N, int32_t C, int64_t S,
+                                    float dice_weight, const float* class_weights,
+                                    int32_t square_dice, float* dp, void* stream) {
+  M355_REQUIRE(p && t && sums && dloss && dp, M355_EINVALID_ARG, "hybrid_loss_bwd: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0, M355_EINVALID_ARG, "hybrid_loss_bwd: non-positive size");
+  M355_REQUIRE((int64_t)N * C <= 65535, M355_EUNSUPPORTED, "hybrid_loss_bwd: N*C > 65535");
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 1024), 2048));
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(bx, (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream,
+                     p, t, sums, dloss, class_weights, dp, N, C, S, dice_weight, square_dice);
+  return check_launch("hybrid_loss_bwd");
+}
+
+static int check_patch_args(int32_t P, int32_t C, int32_t V0, int32_t V1, int32_t V2, int32_t ps0,
+                            int32_t ps1, int32_t ps2, const char* who) {
+  M355_REQUIRE(P > 0 && C > 0 && V0 > 0 && V1 > 0 && V2 > 0 && ps0 > 0 && ps1 > 0 && ps2 > 0,
+               M355_EINVALID_ARG, "%s: non-positive size", who);
+  M355_REQUIRE(ps0 <= V0 && ps1 <= V1 && ps2 <= V2, M355_EINVALID_ARG,
+               "%s: patch (%d,%d,%d) larger than volume (%d,%d,%d)", who, ps0, ps1, ps2, V0, V1, V2);
+  return M355_OK;
+}
+
+extern "C" int m355_patch_gather(const float* volume, const int32_t* loc, float* patches, int32_t P,
+                                 int32_t C, int32_t V0, int32_t V1, int32_t V2, int32_t ps0,
+                                 int32_t ps1, int32_t ps2, void* stream) {
+  if (int rc = check_patch_args(P, C, V0, V1, V2, ps0, ps1, ps2, "patch_gather")) return rc;
+  M355_REQUIRE(volume && loc && patches, M355_EINVALID_ARG, "patch_gather: null pointer");
+  const int64_t total = (int64_t)P * C * ps0 * ps1 * ps2;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 16384);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, volume,
+                     loc, patches, P, C, V0, V1, V2, ps0, ps1, ps2);
+  return check_launch("patch_gather");
+}
+
+extern "C" int m355_patch_accumulate(const float* patches, const int32_t* loc, float* accum,
+                                     float* count, int32_t P, int32_t C, int32_t V0, int32_t V1,
+                                     int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2,
+                                     void* stream) {
+  if (int rc = check_patch_args(P, C, V0, V1, V2, ps0, ps1, ps2, "patch_accumulate")) return rc;
+  M355_REQUIRE(patches && loc && accum && count, M355_EINVALID_ARG, "patch_accumulate: null pointer");
+  const int64_t V = (int64_t)V0 * V1 * V2;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(V, 256), 16384);
+  hipLaunchKernelGGL(patch_accumulate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     patches, loc, accum, count, P, C, V0, V1, V2, ps0, ps1, ps2);
+  return check_launch("patch_accumulate");
+}
+
+extern "C" int m355_patch_finalize(const float* accum, const float* count, float* out, int32_t C,
+                                   int64_t V, void* stream) {
+  M355_REQUIRE(accum && count && out, M355_EINVALID_ARG, "patch_finalize: null pointer");
+  M355_REQUIRE(C > 0 && V > 0, M355_EINVALID_ARG, "patch_finalize: non-positive size");
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)C * V, 256), 16384);
+  hipLaunchKernelGGL(patch_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, accum,
+                     count, out, C, V);
+  return check_launch("patch_finalize");
+}
+
+extern "C" int m355_argmax_confusion(const float* prob, const int32_t* target, int32_t* argmax_out,
+                                     int64_t* counts, int32_t N, int32_t C, int64_t S,
+                                     void* stream) {
+  M355_REQUIRE(prob && target && counts, M355_EINVALID_ARG, "argmax_confusion: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0, M355_EINVALID_ARG, "argmax_confusion: non-positive size");
+  M355_REQUIRE(N <= 65535 && C <= 4096, M355_EUNSUPPORTED, "argmax_confusion: N > 65535 or C > 4096");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)N * C * 4 * sizeof(int64_t), st);
+  M355_REQUIRE(e == hipSuccess, M355_ELAUNCH, "argmax_confusion: memset failed: %s",
+               hipGetErrorString(e));
+  // each block handles <= 2^31 voxels, so the 32-bit LDS counters cannot overflow
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 2048), 1024));
+  hipLaunchKernelGGL(argmax_confusion_kernel, dim3(bx, (unsigned)N), dim3(256),
+                     (size_t)C * 3 * sizeof(unsigned int), st, prob, target, argmax_out,
+                     (unsigned long long*)counts, C, S);
+  hipLaunchKernelGGL(confusion_tn_kernel, dim3((unsigned)ceil_div((int64_t)N * C, 64)), dim3(64), 0,
+                     st, (unsigned long long*)counts, N * C, S);
+  return check_launch("argmax_confusion");
+}

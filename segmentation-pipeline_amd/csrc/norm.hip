@@ -1,0 +1,458 @@
+// GroupNorm / BatchNorm3d + activation, forward and backward (HBM-bound).
+//
+// Reference ops replaced: normalization_class(out_channels) and
+// activation_class() inside Block3d (models/components.py:52-55): nn.BatchNorm3d
+// by default, nn.GroupNorm through functools.partial (the north-star config).
+//
+// A "statistic" s is a mean/rstd pair:
+//   BN : s = channel c,          data = N runs of S contiguous floats
+//   GN : s = n*groups + g,       data = 1 run of (C/groups)*S contiguous floats
+// Pass 1 (stats): blocks reduce chunks to (sum, sumsq) in fp32 per thread over
+// short runs, combined in double -> partial[s][blk][2]; a finalize kernel sums
+// the partials in fixed order.  Pass 2 (apply): float4 streaming, one (n,c)
+// channel chunk per block so gamma/beta/mean/rstd are block-uniform.
+#include "common.hpp"
+
+namespace m355 {
+
+constexpr int NORM_CHUNK = 16384;  // elements per block in the reduction passes
+
+struct NormGeom {
+  int64_t nstats;  // number of statistics
+  int64_t runs;    // runs per statistic
+  int64_t len;     // elements per run
+  int64_t count;   // runs * len
+  int nblk;        // blocks per statistic
+};
+
+static NormGeom geom(const m355_norm_desc* d) {
+  NormGeom g;
+  if (d->groups == 0) {
+    g.nstats = d->C;
+    g.runs = d->N;
+    g.len = d->S;
+  } else {
+    g.nstats = (int64_t)d->N * d->groups;
+    g.runs = 1;
+    g.len = (int64_t)(d->C / d->groups) * d->S;
+  }
+  g.count = g.runs * g.len;
+  g.nblk = (int)ceil_div(g.count, NORM_CHUNK);
+  return g;
+}
+
+__device__ __forceinline__ int64_t stat_base(int64_t s, int64_t run, int groups, int C, int64_t S,
+                                             int64_t xbs, int64_t len) {
+  if (groups == 0) return run * xbs + s * S;  // BN: s = channel, run = n
+  const int64_t n = s / groups, g = s % groups;
+  return n * xbs + g * len;
+}
+
+// partial[(s*nblk + b)*2 + {0,1}] = (sum, sumsq) of chunk b of statistic s
+// VEC: len % 4 == 0 and 16-byte aligned runs, so a float4 never straddles a run.
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x,
+                                                           double* __restrict__ partial,
+                                                           int groups, int C, int64_t S,
+                                                           int64_t xbs, int64_t runs, int64_t len,
+                                                           int nblk) {
+  __shared__ double scratch[4];
+  const int64_t s = blockIdx.y;
+  const int b = blockIdx.x;
+  const int64_t count = runs * len;
+  const int64_t begin = (int64_t)b * NORM_CHUNK;
+  const int64_t end = min(count, begin + NORM_CHUNK);
+  constexpr int STEP = VEC ? 4 : 1;
+  float s1 = 0.f, s2 = 0.f;
+  // one division per thread, then incremental (run, off) bookkeeping
+  int64_t i = begin + (int64_t)threadIdx.x * STEP;
+  int64_t run = i / len, off = i - run * len;
+  for (; i < end; i += 256 * STEP) {
+    const float* p = x + stat_base(s, run, groups, C, S, xbs, len) + off;
+    if (VEC) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 = fmaf(v.x, v.x, s2); s2 = fmaf(v.y, v.y, s2);
+      s2 = fmaf(v.z, v.z, s2); s2 = fmaf(v.w, v.w, s2);
+    } else {
+      const float v = *p;
+      s1 += v;
+      s2 = fmaf(v, v, s2);
+    }
+    off += 256 * STEP;
+    while (off >= len) { off -= len; ++run; }
+  }
+  const double t1 = block_sum<double, 256>((double)s1, scratch);
+  const double t2 = block_sum<double, 256>((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)s * nblk + b) * 2 + 0] = t1;
+    partial[((int64_t)s * nblk + b) * 2 + 1] = t2;
+  }
+}
+
+__global__ void norm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
+                                     float* __restrict__ rstd, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, float momentum, float eps,
+                                     int64_t nstats, int nblk, int64_t count) {
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= nstats) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    t1 += partial[(s * nblk + b) * 2 + 0];
+    t2 += partial[(s * nblk + b) * 2 + 1];
+  }
+  const double m = t1 / (double)count;
+  double var = t2 / (double)count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[s] = (float)m;
+  rstd[s] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[s] = (1.f - momentum) * running_mean[s] + momentum * (float)m;
+  if (running_var) {
+    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    running_var[s] = (1.f - momentum) * running_var[s] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void norm_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                         float eps, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  rstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+  if (act == M355_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == M355_ACT_LEAKY_RELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) {
+  if (act == M355_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+  if (act == M355_ACT_LEAKY_RELU) return pre > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// grid: (chunks over S, C, N).  y = act((x-mean)*rstd*gamma + beta) + add
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ add,
+    float* __restrict__ y, int C, int64_t S, int groups, int act, float slope, int64_t xbs,
+    int64_t ybs) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+  const float m = mean[s], r = rstd[s];
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = r * g;
+  const float sh = b - m * sc;
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c * S;
+  float* yp = y + (int64_t)n * ybs + (int64_t)c * S;
+  const float* ap = add ? add + (int64_t)n * ybs + (int64_t)c * S : nullptr;
+  if (VEC) {
+    const int64_t S4 = S >> 2;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S4; i += gridDim.x * 256ll) {
+      float4 v = reinterpret_cast<const float4*>(xp)[i];
+      v.x = act_fwd(fmaf(v.x, sc, sh), act, slope);
+      v.y = act_fwd(fmaf(v.y, sc, sh), act, slope);
+      v.z = act_fwd(fmaf(v.z, sc, sh), act, slope);
+      v.w = act_fwd(fmaf(v.w, sc, sh), act, slope);
+      if (ap) {
+        const float4 a = reinterpret_cast<const float4*>(ap)[i];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      reinterpret_cast<float4*>(yp)[i] = v;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
+      float v = act_fwd(fmaf(xp[i], sc, sh), act, slope);
+      if (ap) v += ap[i];
+      yp[i] = v;
+    }
+  }
+}
+
+// Backward pass 1: per (n,c) partial sums A = sum g, B = sum g*xhat with
+// g = dy * act'(pre).  partial[((n*C + c)*nblk + b)*2 + {0,1}]
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    double* __restrict__ partial, int C, int64_t S, int groups, int act, float slope, int64_t xbs,
+    int64_t ybs, int nblk) {
+  __shared__ double scratch[4];
+  const int b = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+  const float m = mean[s], r = rstd[s];
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c * S;
+  const float* dp = dy + (int64_t)n * ybs + (int64_t)c * S;
+  const int64_t begin = (int64_t)b * NORM_CHUNK, end = min(S, begin + NORM_CHUNK);
+  float a1 = 0.f, a2 = 0.f;
+  const float sc = r * g, sh = bt - m * sc;  // same expression as the forward pass
+  auto acc = [&](float xv, float dv) {
+    const float xh = (xv - m) * r;
+    const float pre = fmaf(xv, sc, sh);
+    const float gg = dv * act_grad(pre, act, slope);
+    a1 += gg;
+    a2 = fmaf(gg, xh, a2);
+  };
+  if (VEC) {
+    for (int64_t i = begin + threadIdx.x * 4; i < end; i += 1024) {
+      const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+      const float4 dv = *reinterpret_cast<const float4*>(dp + i);
+      acc(xv.x, dv.x); acc(xv.y, dv.y); acc(xv.z, dv.z); acc(xv.w, dv.w);
+    }
+  } else {
+    for (int64_t i = begin + threadIdx.x; i < end; i += 256) acc(xp[i], dp[i]);
+  }
+  const double t1 = block_sum<double, 256>((double)a1, scratch);
+  const double t2 = block_sum<double, 256>((double)a2, scratch);
+  if (threadIdx.x == 0) {
+    const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
+    partial[o] = t1;
+    partial[o + 1] = t2;
+  }
+}
+
+// Backward finalize: AB[n*C+c] = (A,B); dgamma[c] = sum_n B; dbeta[c] = sum_n A;
+// per-statistic means m1 = mean(dxhat), m2 = mean(dxhat*xhat) -> stat_m[s*2+{0,1}]
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ partial,
+                                         const float* __restrict__ gamma,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         float* __restrict__ stat_m, int N, int C, int groups,
+                                         int nblk, int64_t count, int training) {
+  // one thread per statistic; loops are tiny (C/groups channels or N samples)
+  const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s < nstats) {
+    double m1 = 0.0, m2 = 0.0;
+    if (groups == 0) {
+      const int c = (int)s;
+      const double g = gamma ? (double)gamma[c] : 1.0;
+      for (int n = 0; n < N; ++n)
+        for (int b = 0; b < nblk; ++b) {
+          const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
+          m1 += partial[o];
+          m2 += partial[o + 1];
+        }
+      m1 *= g;
+      m2 *= g;
+    } else {
+      const int cpg = C / groups;
+      const int n = (int)(s / groups), gi = (int)(s % groups);
+      for (int cc = 0; cc < cpg; ++cc) {
+        const int c = gi * cpg + cc;
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        double a = 0.0, bb = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+          const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
+          a += partial[o];
+          bb += partial[o + 1];
+        }
+        m1 += g * a;
+        m2 += g * bb;
+      }
+    }
+    if (!training) { m1 = 0.0; m2 = 0.0; }
+    stat_m[s * 2 + 0] = (float)(m1 / (double)count);
+    stat_m[s * 2 + 1] = (float)(m2 / (double)count);
+  }
+  // dgamma / dbeta: one thread per channel
+  if (s < C && (dgamma || dbeta)) {
+    const int c = (int)s;
+    double a = 0.0, bb = 0.0;
+    for (int n = 0; n < N; ++n)
+      for (int b = 0; b < nblk; ++b) {
+        const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
+        a += partial[o];
+        bb += partial[o + 1];
+      }
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)bb;
+  }
+}
+
+// Backward pass 2: dx = rstd * (g*gamma - m1 - xhat*m2)
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stat_m, float* __restrict__ dx, int C, int64_t S, int groups, int act,
+    float slope, int64_t xbs, int64_t ybs) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+  const float m = mean[s], r = rstd[s];
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float m1 = stat_m[s * 2], m2 = stat_m[s * 2 + 1];
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c * S;
+  const float* dp = dy + (int64_t)n * ybs + (int64_t)c * S;
+  float* op = dx + (int64_t)n * xbs + (int64_t)c * S;
+  const float sc = r * g, sh = bt - m * sc;  // same expression as the forward pass
+  auto f = [&](float xv, float dv) {
+    const float xh = (xv - m) * r;
+    const float pre = fmaf(xv, sc, sh);
+    const float gg = dv * act_grad(pre, act, slope) * g;
+    return r * (gg - m1 - xh * m2);
+  };
+  if (VEC) {
+    const int64_t S4 = S >> 2;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S4; i += gridDim.x * 256ll) {
+      const float4 xv = reinterpret_cast<const float4*>(xp)[i];
+      const float4 dv = reinterpret_cast<const float4*>(dp)[i];
+      float4 o;
+      o.x = f(xv.x, dv.x); o.y = f(xv.y, dv.y); o.z = f(xv.z, dv.z); o.w = f(xv.w, dv.w);
+      reinterpret_cast<float4*>(op)[i] = o;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll)
+      op[i] = f(xp[i], dp[i]);
+  }
+}
+
+static int validate_norm(const m355_norm_desc* d, const char* who) {
+  M355_REQUIRE(d != nullptr, M355_EINVALID_ARG, "%s: null descriptor", who);
+  M355_REQUIRE(d->N > 0 && d->C > 0 && d->S > 0, M355_EINVALID_ARG, "%s: non-positive size", who);
+  M355_REQUIRE(d->groups >= 0 && (d->groups == 0 || d->C % d->groups == 0), M355_EINVALID_ARG,
+               "%s: C=%d not divisible by groups=%d", who, d->C, d->groups);
+  M355_REQUIRE(d->act >= M355_ACT_NONE && d->act <= M355_ACT_LEAKY_RELU, M355_EINVALID_ARG,
+               "%s: bad activation %d", who, d->act);
+  M355_REQUIRE(d->N <= 65535 && d->C <= 65535, M355_EUNSUPPORTED, "%s: N or C > 65535", who);
+  return M355_OK;
+}
+
+static bool vec_ok(const m355_norm_desc* d, const void* a, const void* b, const void* c) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
+  return (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) && al(a) && al(b) && (!c || al(c));
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int64_t m355_norm_num_stats(const m355_norm_desc* d) {
+  if (!d) return 0;
+  return d->groups == 0 ? d->C : (int64_t)d->N * d->groups;
+}
+
+extern "C" size_t m355_norm_workspace(const m355_norm_desc* d) {
+  if (!d || d->N <= 0 || d->C <= 0 || d->S <= 0) return 0;
+  const NormGeom g = geom(d);
+  const size_t fwd = (size_t)g.nstats * g.nblk * 2 * sizeof(double);
+  const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
+  const size_t bwd = (size_t)d->N * d->C * nblk_c * 2 * sizeof(double) +
+                     (size_t)g.nstats * 2 * sizeof(float) + 256;
+  return std::max(fwd, bwd) + 256;
+}
+
+extern "C" int m355_norm_stats(const m355_norm_desc* d, const float* x, float* mean, float* rstd,
+                               float* running_mean, float* running_var, float momentum,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_norm(d, "norm_stats")) return rc;
+  M355_REQUIRE(x && mean && rstd && workspace, M355_EINVALID_ARG, "norm_stats: null pointer");
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE,
+               "norm_stats: workspace too small");
+  M355_REQUIRE(d->groups == 0 || (!running_mean && !running_var), M355_EINVALID_ARG,
+               "norm_stats: running statistics are only defined for batch norm");
+  hipStream_t st = (hipStream_t)stream;
+  const NormGeom g = geom(d);
+  M355_REQUIRE(g.nstats <= 65535, M355_EUNSUPPORTED, "norm_stats: too many statistics");
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  double* partial = (double*)workspace;
+  const bool vec = (g.len % 4 == 0) && (d->S % 4 == 0) && (xbs % 4 == 0) && ((uintptr_t)x & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(norm_partial_kernel<true>, dim3((unsigned)g.nblk, (unsigned)g.nstats),
+                       dim3(256), 0, st, x, partial, d->groups, d->C, d->S, xbs, g.runs, g.len,
+                       g.nblk);
+  else
+    hipLaunchKernelGGL(norm_partial_kernel<false>, dim3((unsigned)g.nblk, (unsigned)g.nstats),
+                       dim3(256), 0, st, x, partial, d->groups, d->C, d->S, xbs, g.runs, g.len,
+                       g.nblk);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)ceil_div(g.nstats, 64)), dim3(64), 0, st,
+                     partial, mean, rstd, running_mean, running_var, momentum, d->eps, g.nstats,
+                     g.nblk, g.count);
+  return check_launch("norm_stats");
+}
+
+extern "C" int m355_norm_stats_from_running(const m355_norm_desc* d, const float* running_mean,
+                                            const float* running_var, float* mean, float* rstd,
+                                            void* stream) {
+  if (int rc = validate_norm(d, "norm_stats_from_running")) return rc;
+  M355_REQUIRE(d->groups == 0, M355_EINVALID_ARG, "norm_stats_from_running: batch norm only");
+  M355_REQUIRE(running_mean && running_var && mean && rstd, M355_EINVALID_ARG,
+               "norm_stats_from_running: null pointer");
+  hipLaunchKernelGGL(norm_from_running_kernel, dim3((unsigned)ceil_div(d->C, 64)), dim3(64), 0,
+                     (hipStream_t)stream, running_mean, running_var, mean, rstd, d->eps, d->C);
+  return check_launch("norm_stats_from_running");
+}
+
+extern "C" int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta,
+                                 const float* add, float* y, void* stream) {
+  if (int rc = validate_norm(d, "norm_act_fwd")) return rc;
+  M355_REQUIRE(x && mean && rstd && y, M355_EINVALID_ARG, "norm_act_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
+  const bool vec = vec_ok(d, x, y, add);
+  const int64_t work = vec ? d->S / 4 : d->S;
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
+  dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
+  if (vec)
+    hipLaunchKernelGGL(norm_act_fwd_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma,
+                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs);
+  else
+    hipLaunchKernelGGL(norm_act_fwd_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma,
+                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs);
+  return check_launch("norm_act_fwd");
+}
+
+extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
+                                 const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, float* dx, float* dgamma, float* dbeta,
+                                 int training, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (int rc = validate_norm(d, "norm_act_bwd")) return rc;
+  M355_REQUIRE(x && dy && mean && rstd && dx && workspace, M355_EINVALID_ARG,
+               "norm_act_bwd: null pointer");
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE,
+               "norm_act_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const NormGeom g = geom(d);
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
+  const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
+  double* partial = (double*)workspace;
+  float* stat_m = (float*)((char*)workspace +
+                           round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
+  const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) &&
+                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(norm_bwd_partial_kernel<true>,
+                       dim3((unsigned)nblk_c, (unsigned)d->C, (unsigned)d->N), dim3(256), 0, st, x,
+                       dy, mean, rstd, gamma, beta, partial, d->C, d->S, d->groups, d->act,
+                       d->act_slope, xbs, ybs, nblk_c);
+  else
+    hipLaunchKernelGGL(norm_bwd_partial_kernel<false>,
+                       dim3((unsigned)nblk_c, (unsigned)d->C, (unsigned)d->N), dim3(256), 0, st, x,
+                       dy, mean, rstd, gamma, beta, partial, d->C, d->S, d->groups, d->act,
+                       d->act_slope, xbs, ybs, nblk_c);
+  const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)ceil_div(nthreads, 64)), dim3(64), 0,
+                     st, partial, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, nblk_c,
+                     g.count, training);
+  const int64_t work = vec ? d->S / 4 : d->S;
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
+  dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
+  if (vec)
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, grid, dim3(256), 0, st, x, dy, mean, rstd,
+                       gamma, beta, stat_m, dx, d->C, d->S, d->groups, d->act, d->act_slope, xbs,
+                       ybs);
+  else
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, grid, dim3(256), 0, st, x, dy, mean, rstd,
+                       gamma, beta, stat_m, dx, d->C, d->S, d->groups, d->act, d->act_slope, xbs,
+                       ybs);
+  return check_launch("norm_act_bwd");
+}
