@@ -1,0 +1,123 @@
+"""ctypes binding of libm355seg.so (include/m355seg.h).
+
+There is NO fallback: if the HIP library has not been built the import of any
+op raises, and ops called with non-GPU tensors raise.  The product path never
+touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm355seg.so")
+
+M355_OK = 0
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """m355_conv3d_desc"""
+    _fields_ = [
+        ("N", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("out_pad", C.c_int32),
+        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64),
+    ]
+
+
+class NormDesc(C.Structure):
+    """m355_norm_desc"""
+    _fields_ = [
+        ("N", C.c_int32), ("C", C.c_int32), ("S", C.c_int64),
+        ("groups", C.c_int32), ("act", C.c_int32),
+        ("eps", C.c_float), ("act_slope", C.c_float),
+        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_i32, _i64, _f32, _sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_CD, _ND = C.POINTER(ConvDesc), C.POINTER(NormDesc)
+
+# name -> (restype, argtypes); mirrors include/m355seg.h one to one
+SIGNATURES = {
+    "m355_version": (C.c_int, []),
+    "m355_last_error": (C.c_char_p, []),
+    "m355_conv3d_fwd_workspace": (_sz, [_CD]),
+    "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
+    "m355_conv3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_bwd_weight_workspace": (_sz, [_CD]),
+    "m355_conv3d_bwd_weight": (C.c_int, [_CD, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv_transpose3d_workspace": (_sz, [_CD]),
+    "m355_conv_transpose3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv_transpose3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv_transpose3d_bwd_weight": (C.c_int, [_CD, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_norm_num_stats": (_i64, [_ND]),
+    "m355_norm_workspace": (_sz, [_ND]),
+    "m355_norm_stats": (C.c_int, [_ND, _P, _P, _P, _P, _P, _f32, _P, _sz, _P]),
+    "m355_norm_stats_from_running": (C.c_int, [_ND, _P, _P, _P, _P, _P]),
+    "m355_norm_act_fwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "m355_norm_act_bwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _sz, _P]),
+    "m355_avgpool3d_2x_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_avgpool3d_2x_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_upsample_trilinear2x_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_upsample_trilinear2x_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_softmax_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i64, _f32, _P]),
+    "m355_softmax_bwd": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i64, _P]),
+    "m355_hybrid_loss_workspace": (_sz, [_i32, _i32, _i64]),
+    "m355_hybrid_loss_fwd": (C.c_int, [_P, _P, _i32, _i32, _i64, _f32, _P, _i32, _P, _P, _P, _sz, _P]),
+    "m355_hybrid_loss_bwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i64, _f32, _P, _i32, _P, _P]),
+    "m355_copy_channels": (C.c_int, [_P, _P, _i32, _i32, _i64, _i64, _i64, _P]),
+    "m355_channel_scale": (C.c_int, [_P, _P, _P, _i32, _i32, _i64, _P]),
+    "m355_add": (C.c_int, [_P, _P, _P, _i64, _P]),
+    "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
+    "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
+    "m355_patch_finalize": (C.c_int, [_P, _P, _P, _i32, _i64, _P]),
+    "m355_argmax_confusion": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i64, _P]),
+}
+
+
+class M355Error(RuntimeError):
+    pass
+
+
+def bind(lib, prefix="m355_"):
+    """Declare argtypes/restype of every ABI symbol on a loaded CDLL.
+
+    `prefix` lets the test-suite bind the CPU oracle (m355o_*) with the same
+    signatures; the product only ever binds "m355_".
+    """
+    for name, (res, args) in SIGNATURES.items():
+        sym = prefix + name[len("m355_"):]
+        fn = getattr(lib, sym, None)
+        if fn is None:
+            if prefix == "m355_":
+                raise M355Error(f"{LIB_PATH} does not export {sym}")
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    """The loaded HIP library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M355Error(
+                f"HIP extension {LIB_PATH} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, no GPU). "
+                "There is no CPU or PyTorch fallback for the hot path.")
+        _lib = bind(C.CDLL(LIB_PATH))
+        if _lib.m355_version() != 1:
+            raise M355Error(f"ABI version mismatch: library reports {_lib.m355_version()}, expected 1")
+    return _lib
+
+
+def check(rc, what):
+    if rc != M355_OK:
+        msg = lib().m355_last_error().decode("utf-8", "replace")
+        raise M355Error(f"{what} failed (status {rc}): {msg}")

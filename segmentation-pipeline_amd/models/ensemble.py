@@ -1,0 +1,83 @@
+"""Test-time ensembles (mirror of segmentation_pipeline/models/ensemble.py:9-103).
+
+The member forward passes run on the HIP kernels; the reductions over the ensemble
+axis are index / selection arithmetic on the stacked predictions.
+"""
+import itertools
+from typing import Sequence
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+_STRATEGIES = ('mean', 'majority')
+
+
+def parse_strategy(strategy: str):
+    if strategy not in _STRATEGIES:
+        raise ValueError(f"Ensembling strategy must be one of {_STRATEGIES} not {strategy}")
+    return strategy
+
+
+def apply_strategy(predictions: Sequence[torch.Tensor], strategy: str):
+    """(E, N, C, ...) stack -> 'mean' over E, or 'majority': argmax over C, mode over E,
+    one-hot back to (N, C, ...) (reference :16-35)."""
+    stacked = torch.stack(list(predictions))
+    if strategy == 'mean':
+        return stacked.mean(dim=0)
+    if strategy == 'majority':
+        num_classes = stacked.shape[2]
+        votes = stacked.argmax(dim=2)
+        winner = torch.mode(votes, dim=0).values
+        return F.one_hot(winner, num_classes=num_classes).moveaxis(-1, 1)
+    raise RuntimeError(f"Invalid prediction strategy {strategy}")
+
+
+def _flip_sets(dims):
+    out = []
+    for order in range(len(dims) + 1):
+        out += list(itertools.combinations(dims, order))
+    return out
+
+
+class EnsembleModels(nn.Module):
+    def __init__(self, models: Sequence[nn.Module], strategy: str = 'mean'):
+        super().__init__()
+        self.models = nn.ModuleList(models)
+        self.strategy = parse_strategy(strategy)
+
+    def forward(self, x):
+        return apply_strategy([m(x) for m in self.models], self.strategy)
+
+
+class EnsembleFlips(nn.Module):
+    def __init__(self, model: nn.Module, strategy: str = 'mean', spatial_dims: Sequence[int] = (2, 3, 4)):
+        super().__init__()
+        self.model = model
+        self.strategy = parse_strategy(strategy)
+        self.spatial_dims = spatial_dims
+        self.flips = _flip_sets(tuple(spatial_dims))
+
+    def forward(self, x):
+        preds = [self.model(x.flip(f).contiguous()).flip(f) for f in self.flips]
+        return apply_strategy(preds, self.strategy)
+
+
+class EnsembleOrientations(nn.Module):
+    def __init__(self, model: nn.Module, strategy: str = 'mean'):
+        super().__init__()
+        self.model = model
+        self.strategy = parse_strategy(strategy)
+        dims = (2, 3, 4)
+        self.permutations = list(itertools.permutations(dims))
+        self.flips = _flip_sets(dims)
+
+    def forward(self, x):
+        preds = []
+        for perm in self.permutations:
+            inverse = tuple((torch.argsort(torch.tensor(perm)) + 2).tolist())
+            xp = x.permute(0, 1, *perm)
+            for f in self.flips:
+                y = self.model(xp.flip(f).contiguous())
+                preds.append(y.flip(f).permute(0, 1, *inverse))
+        return apply_strategy(preds, self.strategy)

@@ -1,0 +1,156 @@
+"""ModularUNet with the reference's plug-in surface, executed by HIP kernels.
+
+Mirror of segmentation_pipeline/models/modular_unet.py:11-102 (reference): same
+constructor signature and defaults (:12-46), same sub-module names and creation
+order (:50-84) -> identical state_dict keys and seeded initialisation.  forward
+(:86-102) keeps the reference's dataflow but never materialises torch.cat: the
+encoder block and the upsampler of a level write straight into the two channel
+slices of one pre-allocated buffer, which the decoder block's first convolution
+reads whole ([x_up | x_skip], upsampled part first as in :97).
+"""
+from typing import Dict, Optional, Sequence, Union
+
+import torch
+from torch import nn
+
+from .. import ops
+from .components import Block3d, BlurConv3d, BlurConvTranspose3d, StochasticMatrix, run_conv, _uniform_int
+from .utils import filter_kwargs, is_sequence
+
+
+def _run_downsample(m, x):
+    if isinstance(m, nn.AvgPool3d):
+        k, s = _uniform_int(m.kernel_size, "kernel_size"), _uniform_int(m.stride, "stride")
+        if k != 2 or s != 2 or _uniform_int(m.padding, "padding") != 0 or m.ceil_mode:
+            raise NotImplementedError("only AvgPool3d(kernel_size=2, stride=2) has a HIP kernel")
+        return ops.avgpool3d_2x(x)
+    if isinstance(m, nn.Conv3d):  # BlurConv3d / WSConv3d / strided nn.Conv3d
+        return run_conv(m, x)
+    raise NotImplementedError(f"downsample_class {type(m).__name__} has no HIP kernel")
+
+
+def _run_upsample(m, x, out=None):
+    if isinstance(m, nn.Upsample):
+        sf = m.scale_factor
+        sf = sf if not isinstance(sf, (tuple, list)) else (sf[0] if len(set(sf)) == 1 else None)
+        if m.mode != 'trilinear' or not m.align_corners or sf is None or float(sf) != 2.0:
+            raise NotImplementedError(
+                "only Upsample(scale_factor=2, mode='trilinear', align_corners=True) has a HIP kernel")
+        return ops.upsample_trilinear2x(x, out=out)
+    if isinstance(m, BlurConvTranspose3d):
+        return m(x, out=out)
+    if isinstance(m, nn.ConvTranspose3d):
+        if m.groups != 1 or _uniform_int(m.dilation, "dilation") != 1:
+            raise NotImplementedError("grouped / dilated ConvTranspose3d has no HIP kernel")
+        return ops.conv_transpose3d(
+            x, m.weight, m.bias, stride=_uniform_int(m.stride, "stride"),
+            padding=_uniform_int(m.padding, "padding"),
+            output_padding=_uniform_int(m.output_padding, "output_padding"), out=out)
+    raise NotImplementedError(f"upsample_class {type(m).__name__} has no HIP kernel")
+
+
+def _upsample_out_channels(m, cin):
+    return m.out_channels if isinstance(m, nn.ConvTranspose3d) else cin
+
+
+def _run_hypothesis(m, x):
+    if isinstance(m, nn.Softmax):
+        if m.dim != 1:
+            raise NotImplementedError("only Softmax(dim=1) has a HIP kernel")
+        return ops.softmax_channels(x)
+    if isinstance(m, StochasticMatrix):
+        return m(x)
+    if isinstance(m, nn.Identity):
+        return x
+    raise NotImplementedError(f"hypothesis_class {type(m).__name__} has no HIP kernel")
+
+
+class ModularUNet(nn.Module):
+    def __init__(
+            self,
+            in_channels: int,
+            out_channels: int,
+            filters: Union[int, Sequence[int]],
+            depth: int,
+            block_class: nn.Module = Block3d,
+            block_params: Optional[Dict] = None,
+            upsample_class: nn.Module = nn.Upsample,
+            upsample_params: Optional[Dict] = None,
+            downsample_class: nn.Module = nn.AvgPool3d,
+            downsample_params: Optional[Dict] = None,
+            out_conv_class: nn.Module = nn.Conv3d,
+            out_conv_params: Optional[Dict] = None,
+            hypothesis_class: nn.Module = nn.Softmax,
+            hypothesis_params: Optional[Dict] = None,
+    ):
+        super().__init__()
+
+        if isinstance(filters, int):
+            filters = [filters] * depth
+        elif is_sequence(filters) and len(filters) != depth:
+            raise ValueError(f"Sequence of filters {filters} does not match depth {depth}")
+
+        block_params = {} if block_params is None else block_params
+        if upsample_params is None:
+            upsample_params = {'scale_factor': 2, 'mode': 'trilinear', 'align_corners': True}
+        if downsample_params is None:
+            downsample_params = {'kernel_size': 2, 'stride': 2, 'count_include_pad': False}
+        if out_conv_params is None:
+            out_conv_params = {'in_channels': filters[0], 'out_channels': out_channels, 'kernel_size': 3,
+                               'padding': 1}
+        if hypothesis_params is None:
+            hypothesis_params = {"dim": 1}
+
+        self.depth = depth
+        self._filters = list(filters)
+
+        # creation order matters for seeded initialisation: down blocks, downsamplers,
+        # up blocks, upsamplers, out conv (reference :50-84)
+        self.down_blocks = nn.ModuleList(
+            [block_class(in_channels if i == 0 else filters[i - 1], filters[i], **block_params)
+             for i in range(depth)])
+
+        self.downsampling = nn.ModuleList()
+        for i in range(depth - 1):
+            downsample_params.update(filter_kwargs(
+                downsample_class, in_channels=filters[i], out_channels=filters[i], channels=filters[i]))
+            self.downsampling.append(downsample_class(**downsample_params))
+
+        self.up_blocks = nn.ModuleList(
+            [block_class(filters[i] + filters[i + 1], filters[i], **block_params) for i in range(depth - 1)])
+
+        self.upsampling = nn.ModuleList()
+        for i in range(1, depth):
+            upsample_params.update(filter_kwargs(
+                upsample_class, in_channels=filters[i], out_channels=filters[i], channels=filters[i]))
+            self.upsampling.append(upsample_class(**upsample_params))
+
+        self.out_conv = out_conv_class(**out_conv_params)
+        self.hypothesis = hypothesis_class(**hypothesis_params)
+
+        for blk in list(self.down_blocks) + list(self.up_blocks):
+            if not isinstance(blk, Block3d):
+                raise NotImplementedError(
+                    f"block_class {type(blk).__name__} has no HIP execution path (use models.Block3d)")
+
+    def forward(self, x):
+        f = self._filters
+        skips = []
+        for i in range(self.depth):
+            if i != self.depth - 1:
+                # level-i concat buffer: [upsampled (f[i+1]) | skip (f[i])]
+                c_up = _upsample_out_channels(self.upsampling[i], f[i + 1])
+                buf = torch.empty((x.shape[0], c_up + f[i]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+                x = self.down_blocks[i](x, out=ops.OutSlot(buf, c_up, c_up + f[i]))
+                skips.append((x, buf, c_up))
+                x = _run_downsample(self.downsampling[i], x)
+            else:
+                x = self.down_blocks[i](x)
+
+        for i in reversed(range(self.depth - 1)):
+            x_skip, buf, c_up = skips[i]
+            x_up = _run_upsample(self.upsampling[i], x, out=ops.OutSlot(buf, 0, c_up))
+            x = self.up_blocks[i](ops.Concat(buf, [x_up, x_skip]))
+
+        x = run_conv(self.out_conv, x)
+        return _run_hypothesis(self.hypothesis, x)

@@ -1,0 +1,597 @@
+"""torch.autograd bindings of the HIP kernels (one Function per op family).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP
+stream, and the autograd graph.  Every tensor op on the hot path is a call
+through the C ABI of libm355seg.so; nothing falls back to torch or to the CPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
+
+# Optional instrumentation used by bench.py: when set to a list, every conv
+# launch appends (tag, flops, start_event, end_event) recorded on the launch stream.
+CONV_PROFILE: Optional[list] = None
+
+
+# ----------------------------------------------------------------- helpers
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require(*tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.M355Error(
+                "segmentation_pipeline_amd ops run only on the GPU through libm355seg.so "
+                f"(got a {t.device} tensor); there is no CPU fallback")
+        if t.dtype != dtype:
+            raise _lib.M355Error(f"expected {dtype}, got {t.dtype}")
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _dense_channels(t):
+    """Return (tensor, batch_stride) for a 5-D tensor whose (C, D, H, W) block is
+    dense; channel slices of a concat buffer qualify.  Anything else is compacted."""
+    N, Cc, D, H, W = t.shape
+    st = t.stride()
+    S = D * H * W
+    ok = ((W == 1 or st[4] == 1) and (H == 1 or st[3] == W) and (D == 1 or st[2] == H * W)
+          and (Cc == 1 or st[1] == S))
+    if not ok:
+        t = t.contiguous()
+        return t, Cc * S
+    return t, (st[0] if N > 1 else Cc * S)
+
+
+class OutSlot:
+    """A destination inside a pre-allocated concat buffer.
+
+    Wrapped in a plain object so autograd does not see the buffer as an input:
+    producers write straight into their channel slice (no torch.cat copy, no
+    CopySlices nodes) and return a fresh tensor aliasing the slice.
+    """
+
+    def __init__(self, buf: torch.Tensor, c0: int, c1: int):
+        self.buf, self.c0, self.c1 = buf, c0, c1
+
+    def view(self):
+        return self.buf[:, self.c0:self.c1]
+
+
+class Concat:
+    """Channel concatenation of tensors that already live in adjacent slices of
+    `buf` (models/modular_unet.py:97: torch.cat([x_up, x_skip], dim=1))."""
+
+    def __init__(self, buf: torch.Tensor, parts: Sequence[torch.Tensor]):
+        self.buf, self.parts = buf, list(parts)
+        assert sum(p.shape[1] for p in self.parts) == buf.shape[1]
+
+    @property
+    def shape(self):
+        return self.buf.shape
+
+
+def _alloc_out(out: Optional[OutSlot], shape, like):
+    if out is None:
+        return torch.empty(shape, dtype=like.dtype, device=like.device)
+    v = out.view()
+    if tuple(v.shape) != tuple(shape):
+        raise _lib.M355Error(f"output slot shape {tuple(v.shape)} != op output shape {tuple(shape)}")
+    # fresh tensor object aliasing the slice (see OutSlot)
+    return torch.as_strided(out.buf, v.shape, v.stride(), v.storage_offset())
+
+
+# ------------------------------------------------------------------ conv3d
+@dataclass
+class _ConvMeta:
+    k: int
+    stride: int
+    pad: int
+    catbuf: Optional[torch.Tensor] = None
+    out: Optional[OutSlot] = None
+    tag: str = "conv3d"
+
+
+def _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad=0):
+    return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs)
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, bias, add, meta: _ConvMeta, *parts):
+        L = _lib.lib()
+        x = meta.catbuf if meta.catbuf is not None else parts[0]
+        _require(x, weight, bias, add)
+        x, xbs = _dense_channels(x)
+        weight = weight.contiguous()
+        N, Cin, D, H, W = x.shape
+        Cout, k = weight.shape[0], meta.k
+        od = lambda n: (n + 2 * meta.pad - k) // meta.stride + 1
+        oshape = (N, Cout, od(D), od(H), od(W))
+        y = _alloc_out(meta.out, oshape, x)
+        y, ybs = _dense_channels(y)
+        if add is not None:
+            add, abs_ = _dense_channels(add)
+            if abs_ != ybs:
+                raise _lib.M355Error("conv3d: `add` must share the output's batch stride")
+        d = _conv_desc(N, Cin, Cout, D, H, W, k, meta.stride, meta.pad, xbs, ybs)
+        ws = _workspace(L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
+        prof = CONV_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(L.m355_conv3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(ws),
+                                ws.numel(), _stream()), "conv3d_fwd")
+        if prof is not None:
+            e1.record()
+            flops = 2.0 * k ** 3 * Cin * Cout * N * oshape[2] * oshape[3] * oshape[4]
+            prof.append(("conv3d_fwd", flops, e0, e1))
+        ctx.meta, ctx.desc = meta, d
+        ctx.has_bias, ctx.has_add = bias is not None, add is not None
+        ctx.part_channels = [p.shape[1] for p in parts]
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, weight = ctx.saved_tensors
+        d = ctx.desc
+        meta = ctx.meta
+        dy, dybs = _dense_channels(dy)
+        if dybs != d.y_batch_stride:
+            d = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.x_batch_stride, dybs)
+        need_w, need_b, need_add = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_x = any(ctx.needs_input_grad[4:])
+        dw = db = dadd = None
+        dparts: List[Optional[torch.Tensor]] = [None] * len(ctx.part_channels)
+        prof = CONV_PROFILE
+        if need_w or (need_b and ctx.has_bias):
+            dw = torch.empty_like(weight)
+            db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+            ws = _workspace(L.m355_conv3d_bwd_weight_workspace(C.byref(d)), x.device)
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(L.m355_conv3d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(),
+                                           _stream()), "conv3d_bwd_weight")
+            if prof is not None:
+                e1.record()
+                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1))
+        if need_x:
+            # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part
+            dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
+            dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, d.y_batch_stride)
+            ws = _workspace(L.m355_conv3d_bwd_data_workspace(C.byref(dd)), x.device)
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(L.m355_conv3d_bwd_data(C.byref(dd), _p(dy), _p(weight), _p(dx), _p(ws), ws.numel(),
+                                         _stream()), "conv3d_bwd_data")
+            if prof is not None:
+                e1.record()
+                prof.append(("conv3d_bwd_data", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1))
+            c0 = 0
+            for i, cc in enumerate(ctx.part_channels):
+                if ctx.needs_input_grad[4 + i]:
+                    dparts[i] = dx if len(ctx.part_channels) == 1 else dx[:, c0:c0 + cc]
+                c0 += cc
+        if need_add and ctx.has_add:
+            dadd = dy
+        return (dw if need_w else None, db if need_b else None, dadd, None, *dparts)
+
+
+def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[OutSlot] = None):
+    """nn.Conv3d forward (cubic kernel).  `x` is a tensor or a `Concat`; `add` is fused
+    into the epilogue (y = conv(x) + bias + add)."""
+    k = weight.shape[2]
+    if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
+        raise NotImplementedError("only cubic kernels are supported")
+    if isinstance(x, Concat):
+        meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out)
+        return _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
+    meta = _ConvMeta(k, stride, padding, out=out)
+    return _Conv3dFn.apply(weight, bias, add, meta, x)
+
+
+# -------------------------------------------------------- conv-transpose3d
+class _ConvT3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, meta):
+        L = _lib.lib()
+        _require(x, weight, bias)
+        k, stride, pad, out_pad, out = meta
+        x, xbs = _dense_channels(x)
+        weight = weight.contiguous()
+        N, Cin, D, H, W = x.shape
+        Cout = weight.shape[1]
+        od = lambda n: (n - 1) * stride - 2 * pad + k + out_pad
+        oshape = (N, Cout, od(D), od(H), od(W))
+        y = _alloc_out(out, oshape, x)
+        y, ybs = _dense_channels(y)
+        d = _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad)
+        ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(d)), x.device)
+        check(L.m355_conv_transpose3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws), ws.numel(),
+                                          _stream()), "conv_transpose3d_fwd")
+        ctx.desc, ctx.has_bias = d, bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, weight = ctx.saved_tensors
+        d = ctx.desc
+        dy, dybs = _dense_channels(dy)
+        d = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.x_batch_stride, dybs, d.out_pad)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
+            dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, dybs, d.out_pad)
+            ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(dd)), x.device)
+            check(L.m355_conv_transpose3d_bwd_data(C.byref(dd), _p(dy), _p(weight), _p(dx), _p(ws), ws.numel(),
+                                                   _stream()), "conv_transpose3d_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+            ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(d)), x.device)
+            check(L.m355_conv_transpose3d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                                     ws.numel(), _stream()), "conv_transpose3d_bwd_weight")
+        return dx, dw, db, None
+
+
+def conv_transpose3d(x, weight, bias=None, stride=2, padding=0, output_padding=0, out: Optional[OutSlot] = None):
+    """nn.ConvTranspose3d forward (cubic kernel, weight [Cin, Cout, k, k, k])."""
+    k = weight.shape[2]
+    return _ConvT3dFn.apply(x, weight, bias, (k, stride, padding, output_padding, out))
+
+
+# ----------------------------------------------------------- norm + activation
+@dataclass
+class NormCfg:
+    groups: int            # 0 = batch norm
+    eps: float
+    act: int = ACT_NONE
+    slope: float = 0.01
+    training: bool = True  # BN: use batch statistics (and update running stats)
+    momentum: float = 0.1
+    running_mean: Optional[torch.Tensor] = None
+    running_var: Optional[torch.Tensor] = None
+    out: Optional[OutSlot] = None
+
+
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, add, cfg: NormCfg):
+        L = _lib.lib()
+        _require(x, gamma, beta, add)
+        x, xbs = _dense_channels(x)
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.shape[2] * x.shape[3] * x.shape[4]
+        if xbs != Cc * S:  # keep the saved input dense so the backward writes a dense dx
+            x, xbs = x.contiguous(), Cc * S
+        y = _alloc_out(cfg.out, x.shape, x)
+        y, ybs = _dense_channels(y)
+        if add is not None:
+            add, abs_ = _dense_channels(add)
+            if abs_ != ybs:
+                raise _lib.M355Error("norm_act: `add` must share the output's batch stride")
+        d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs)
+        ns = L.m355_norm_num_stats(C.byref(d))
+        mean = torch.empty(ns, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
+        use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
+        if use_batch:
+            ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+            upd = cfg.groups == 0 and cfg.training
+            check(L.m355_norm_stats(C.byref(d), _p(x), _p(mean), _p(rstd),
+                                    _p(cfg.running_mean) if upd else None,
+                                    _p(cfg.running_var) if upd else None,
+                                    float(cfg.momentum), _p(ws), ws.numel(), _stream()), "norm_stats")
+        else:
+            check(L.m355_norm_stats_from_running(C.byref(d), _p(cfg.running_mean), _p(cfg.running_var),
+                                                 _p(mean), _p(rstd), _stream()), "norm_stats_from_running")
+        check(L.m355_norm_act_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
+                                  _stream()), "norm_act_fwd")
+        ctx.desc, ctx.batch_stats, ctx.has_add = d, use_batch, add is not None
+        ctx.has_affine = gamma is not None
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        d0 = ctx.desc
+        dy, dybs = _dense_channels(dy)
+        d = NormDesc(d0.N, d0.C, d0.S, d0.groups, d0.act, d0.eps, d0.act_slope, d0.x_batch_stride, dybs)
+        dx = torch.empty_like(x)  # x was saved dense
+        dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+        check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                  _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
+                                  _stream()), "norm_act_bwd")
+        dadd = dy if (ctx.has_add and ctx.needs_input_grad[3]) else None
+        return dx, dgamma, dbeta, dadd, None
+
+
+def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
+    """normalization_class + activation_class of Block3d (components.py:52-55), optionally
+    fused with the residual sum (components.py:67-68): act(norm(x)) + add."""
+    return _NormActFn.apply(x, gamma, beta, add, cfg)
+
+
+# ------------------------------------------------------------- pool / upsample
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out):
+        L = _lib.lib()
+        _require(x)
+        x, xbs = _dense_channels(x)
+        N, Cc, D, H, W = x.shape
+        y = _alloc_out(out, (N, Cc, D // 2, H // 2, W // 2), x)
+        y, ybs = _dense_channels(y)
+        check(L.m355_avgpool3d_2x_fwd(_p(x), _p(y), N, Cc, D, H, W, xbs, ybs, _stream()), "avgpool3d_2x_fwd")
+        ctx.shape = (N, Cc, D, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        N, Cc, D, H, W = ctx.shape
+        dy, dybs = _dense_channels(dy)
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        check(L.m355_avgpool3d_2x_bwd(_p(dy), _p(dx), N, Cc, D, H, W, dybs, 0, _stream()), "avgpool3d_2x_bwd")
+        return dx, None
+
+
+def avgpool3d_2x(x, out: Optional[OutSlot] = None):
+    """nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False)"""
+    return _AvgPoolFn.apply(x, out)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out):
+        L = _lib.lib()
+        _require(x)
+        x, xbs = _dense_channels(x)
+        N, Cc, D, H, W = x.shape
+        y = _alloc_out(out, (N, Cc, 2 * D, 2 * H, 2 * W), x)
+        y, ybs = _dense_channels(y)
+        check(L.m355_upsample_trilinear2x_fwd(_p(x), _p(y), N, Cc, D, H, W, xbs, ybs, _stream()),
+              "upsample_trilinear2x_fwd")
+        ctx.shape = (N, Cc, D, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        N, Cc, D, H, W = ctx.shape
+        dy, dybs = _dense_channels(dy)
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        check(L.m355_upsample_trilinear2x_bwd(_p(dy), _p(dx), N, Cc, D, H, W, dybs, 0, _stream()),
+              "upsample_trilinear2x_bwd")
+        return dx, None
+
+
+def upsample_trilinear2x(x, out: Optional[OutSlot] = None):
+    """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)"""
+    return _UpsampleFn.apply(x, out)
+
+
+# ------------------------------------------------------------------- softmax
+class _SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inner, diag_bias):
+        L = _lib.lib()
+        _require(x)
+        x = x.contiguous()
+        N, Ctot = x.shape[0], x.shape[1]
+        Cc = Ctot // inner
+        S = x.numel() // (N * Ctot)
+        y = torch.empty_like(x)
+        check(L.m355_softmax_fwd(_p(x), _p(y), N, Cc, inner, S, float(diag_bias), _stream()), "softmax_fwd")
+        ctx.dims = (N, Cc, inner, S)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (y,) = ctx.saved_tensors
+        N, Cc, inner, S = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(L.m355_softmax_bwd(_p(y), _p(dy), _p(dx), N, Cc, inner, S, _stream()), "softmax_bwd")
+        return dx, None, None
+
+
+def softmax_channels(x, inner=1, diag_bias=0.0):
+    """nn.Softmax(dim=1); inner=C gives StochasticMatrix's reshape+eye-bias+softmax."""
+    return _SoftmaxFn.apply(x, inner, diag_bias)
+
+
+# ----------------------------------------------------------------------- loss
+class _HybridLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t, dice_weight, class_weights, square_dice):
+        L = _lib.lib()
+        _require(p, t, class_weights)
+        if p.shape != t.shape:
+            raise _lib.M355Error(f"prediction {tuple(p.shape)} and target {tuple(t.shape)} differ in shape")
+        p, t = p.contiguous(), t.contiguous()
+        N, Cc = p.shape[0], p.shape[1]
+        S = p.numel() // (N * Cc)
+        out3 = torch.empty(3, dtype=torch.float32, device=p.device)
+        sums = torch.empty(N * Cc * 4, dtype=torch.float32, device=p.device)
+        ws = _workspace(L.m355_hybrid_loss_workspace(N, Cc, S), p.device)
+        check(L.m355_hybrid_loss_fwd(_p(p), _p(t), N, Cc, S, float(dice_weight), _p(class_weights),
+                                     1 if square_dice else 0, _p(out3), _p(sums), _p(ws), ws.numel(),
+                                     _stream()), "hybrid_loss_fwd")
+        ctx.args = (N, Cc, S, float(dice_weight), 1 if square_dice else 0)
+        ctx.save_for_backward(p, t, sums, class_weights)
+        # three independent 0-dim tensors (not views of one buffer) for autograd's sake
+        loss, dice, logistic = out3[0].clone(), out3[1].clone(), out3[2].clone()
+        ctx.mark_non_differentiable(dice, logistic)
+        return loss, dice, logistic
+
+    @staticmethod
+    def backward(ctx, dloss, _d1, _d2):
+        L = _lib.lib()
+        p, t, sums, cw = ctx.saved_tensors
+        N, Cc, S, dwt, sq = ctx.args
+        dloss = dloss.contiguous().to(torch.float32)
+        dp = torch.empty_like(p)
+        check(L.m355_hybrid_loss_bwd(_p(p), _p(t), _p(sums), _p(dloss), N, Cc, S, dwt, _p(cw), sq, _p(dp),
+                                     _stream()), "hybrid_loss_bwd")
+        return dp, None, None, None, None
+
+
+def hybrid_logistic_dice_loss(prediction, target, dice_weight=0.5, class_weights=None, square_dice=True):
+    """HybridLogisticDiceLoss.forward -> (loss, dice_loss, logistic_loss); the gradient
+    flows through `loss` (the only entry the trainer back-propagates, segmentation_trainer.py:177)."""
+    return _HybridLossFn.apply(prediction, target, dice_weight, class_weights, square_dice)
+
+
+# ---------------------------------------------------------------- elementwise
+class _ChannelScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        L = _lib.lib()
+        _require(x, scale)
+        x = x.contiguous()
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        check(L.m355_channel_scale(_p(x), _p(scale), _p(y), N, Cc, S, _stream()), "channel_scale")
+        ctx.save_for_backward(scale)
+        ctx.dims = (N, Cc, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (scale,) = ctx.saved_tensors
+        N, Cc, S = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(L.m355_channel_scale(_p(dy), _p(scale), _p(dx), N, Cc, S, _stream()), "channel_scale")
+        return dx, None
+
+
+def channel_scale(x, scale):
+    """y[n,c,...] = x[n,c,...] * scale[n,c]  (Dropout3d with a pre-drawn mask)."""
+    return _ChannelScaleFn.apply(x, scale.contiguous().view(-1))
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L = _lib.lib()
+        _require(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        check(L.m355_add(_p(a), _p(b), _p(y), a.numel(), _stream()), "add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+class _CopyIntoFn(torch.autograd.Function):
+    """Copy a tensor into a concat slot (the generic torch.cat path for producers
+    that cannot write into the buffer themselves)."""
+
+    @staticmethod
+    def forward(ctx, x, out):
+        L = _lib.lib()
+        _require(x)
+        x, xbs = _dense_channels(x)
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.shape[2] * x.shape[3] * x.shape[4]
+        y = _alloc_out(out, x.shape, x)
+        y, ybs = _dense_channels(y)
+        check(L.m355_copy_channels(_p(x), _p(y), N, Cc, S, xbs, ybs, _stream()), "copy_channels")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def copy_into(x, out: OutSlot):
+    return _CopyIntoFn.apply(x, out)
+
+
+# --------------------------------------------------- sliding window / evaluation
+def patch_gather(volume, locations, patch_size):
+    """volume [C,V0,V1,V2], locations int32 [P,3] (i0,j0,k0) -> patches [P,C,*patch_size]"""
+    L = _lib.lib()
+    _require(volume)
+    _require(locations, dtype=torch.int32)
+    volume, locations = volume.contiguous(), locations.contiguous()
+    Cc, V0, V1, V2 = volume.shape
+    P = locations.shape[0]
+    ps0, ps1, ps2 = patch_size
+    patches = torch.empty((P, Cc, ps0, ps1, ps2), dtype=volume.dtype, device=volume.device)
+    check(L.m355_patch_gather(_p(volume), _p(locations), _p(patches), P, Cc, V0, V1, V2, ps0, ps1, ps2,
+                              _stream()), "patch_gather")
+    return patches
+
+
+def patch_accumulate(patches, locations, accum, count):
+    """accum[C,V] += patches (in patch order), count[V] += 1 over each patch footprint"""
+    L = _lib.lib()
+    _require(patches, accum, count)
+    _require(locations, dtype=torch.int32)
+    patches, locations = patches.contiguous(), locations.contiguous()
+    P, Cc, ps0, ps1, ps2 = patches.shape
+    _, V0, V1, V2 = accum.shape
+    check(L.m355_patch_accumulate(_p(patches), _p(locations), _p(accum), _p(count), P, Cc, V0, V1, V2,
+                                  ps0, ps1, ps2, _stream()), "patch_accumulate")
+
+
+def patch_finalize(accum, count):
+    L = _lib.lib()
+    _require(accum, count)
+    Cc = accum.shape[0]
+    V = count.numel()
+    out = torch.empty_like(accum)
+    check(L.m355_patch_finalize(_p(accum), _p(count), _p(out), Cc, V, _stream()), "patch_finalize")
+    return out
+
+
+def argmax_confusion(prob, target):
+    """prob [N,C,...] float, target [N,...] int32 -> (argmax int32 [N,...], counts int64 [N,C,4] = TP,FP,FN,TN)"""
+    L = _lib.lib()
+    _require(prob)
+    _require(target, dtype=torch.int32)
+    prob, target = prob.contiguous(), target.contiguous()
+    N, Cc = prob.shape[0], prob.shape[1]
+    S = prob.numel() // (N * Cc)
+    am = torch.empty(target.shape, dtype=torch.int32, device=prob.device)
+    counts = torch.empty((N, Cc, 4), dtype=torch.int64, device=prob.device)
+    check(L.m355_argmax_confusion(_p(prob), _p(target), _p(am), _p(counts), N, Cc, S, _stream()),
+          "argmax_confusion")
+    return am, counts

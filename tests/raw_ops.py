@@ -1,0 +1,281 @@
+"""Thin functional wrapper over the C ABI used by the tests.
+
+`RawOps("hip")` drives libm355seg.so with CUDA tensors; `RawOps("oracle")` drives
+oracle/libm355_oracle.so (same signatures, m355o_ prefix) with CPU tensors.  The
+parity tests run the same call on both and compare.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from segmentation_pipeline_amd import _lib  # noqa: E402
+from segmentation_pipeline_amd._lib import ConvDesc, NormDesc  # noqa: E402
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libm355_oracle.so")
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "m355_oracle.c")
+    if (not os.path.exists(ORACLE_LIB)) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return ORACLE_LIB
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class RawOps:
+    def __init__(self, backend):
+        self.backend = backend
+        if backend == "hip":
+            self.lib, self.prefix, self.device = _lib.lib(), "m355_", "cuda"
+        elif backend == "oracle":
+            self.lib = _lib.bind(C.CDLL(build_oracle()), prefix="m355o_")
+            self.prefix, self.device = "m355o_", "cpu"
+        else:
+            raise ValueError(backend)
+
+    # ------------------------------------------------------------- plumbing
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.device == "cuda" else None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.m355_last_error().decode() if self.backend == "hip" else ""
+            raise RuntimeError(f"{what} -> {rc} {msg}")
+
+    def to(self, t):
+        return None if t is None else t.to(self.device).contiguous()
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _ws(self, qname, desc):
+        n = 0
+        if self.backend == "hip":
+            n = getattr(self.lib, "m355_" + qname)(C.byref(desc))
+        return torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ conv
+    @staticmethod
+    def conv_desc(x_shape, Cout, k, stride, pad, out_pad=0, xbs=0, ybs=0):
+        N, Cin, D, H, W = x_shape
+        return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs)
+
+    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1):
+        x, w, bias, add = map(self.to, (x, w, bias, add))
+        k = w.shape[2]
+        d = self.conv_desc(x.shape, w.shape[0], k, stride, pad)
+        od = lambda n: (n + 2 * pad - k) // stride + 1
+        y = self.empty(x.shape[0], w.shape[0], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
+        ws = self._ws("conv3d_fwd_workspace", d)
+        self._chk(self.fn("conv3d_fwd")(C.byref(d), _p(x), _p(w), _p(bias), _p(add), _p(y), _p(ws), ws.numel(),
+                                        self._stream()), "conv3d_fwd")
+        return y
+
+    def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1):
+        dy, w = self.to(dy), self.to(w)
+        d = self.conv_desc(x_shape, w.shape[0], w.shape[2], stride, pad)
+        dx = self.empty(*x_shape)
+        ws = self._ws("conv3d_bwd_data_workspace", d)
+        self._chk(self.fn("conv3d_bwd_data")(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel(), self._stream()),
+                  "conv3d_bwd_data")
+        return dx
+
+    def conv3d_bwd_weight(self, x, dy, k, stride=1, pad=1, with_bias=True):
+        x, dy = self.to(x), self.to(dy)
+        Cout = dy.shape[1]
+        d = self.conv_desc(x.shape, Cout, k, stride, pad)
+        dw = self.empty(Cout, x.shape[1], k, k, k)
+        db = self.empty(Cout) if with_bias else None
+        ws = self._ws("conv3d_bwd_weight_workspace", d)
+        self._chk(self.fn("conv3d_bwd_weight")(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(),
+                                               self._stream()), "conv3d_bwd_weight")
+        return dw, db
+
+    def convt_fwd(self, x, w, bias=None, stride=2, pad=0, out_pad=0):
+        x, w, bias = map(self.to, (x, w, bias))
+        k = w.shape[2]
+        d = self.conv_desc(x.shape, w.shape[1], k, stride, pad, out_pad)
+        od = lambda n: (n - 1) * stride - 2 * pad + k + out_pad
+        y = self.empty(x.shape[0], w.shape[1], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
+        ws = self._ws("conv_transpose3d_workspace", d)
+        self._chk(self.fn("conv_transpose3d_fwd")(C.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(ws), ws.numel(),
+                                                  self._stream()), "convt_fwd")
+        return y
+
+    def convt_bwd_data(self, dy, w, x_shape, stride=2, pad=0, out_pad=0):
+        dy, w = self.to(dy), self.to(w)
+        d = self.conv_desc(x_shape, w.shape[1], w.shape[2], stride, pad, out_pad)
+        dx = self.empty(*x_shape)
+        ws = self._ws("conv_transpose3d_workspace", d)
+        self._chk(self.fn("conv_transpose3d_bwd_data")(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel(),
+                                                       self._stream()), "convt_bwd_data")
+        return dx
+
+    def convt_bwd_weight(self, x, dy, k, stride=2, pad=0, out_pad=0, with_bias=True):
+        x, dy = self.to(x), self.to(dy)
+        Cout = dy.shape[1]
+        d = self.conv_desc(x.shape, Cout, k, stride, pad, out_pad)
+        dw = self.empty(x.shape[1], Cout, k, k, k)
+        db = self.empty(Cout) if with_bias else None
+        ws = self._ws("conv_transpose3d_workspace", d)
+        self._chk(self.fn("conv_transpose3d_bwd_weight")(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                                         ws.numel(), self._stream()), "convt_bwd_weight")
+        return dw, db
+
+    # ------------------------------------------------------------------ norm
+    @staticmethod
+    def norm_desc(x, groups, act=0, eps=1e-5, slope=0.01):
+        N, Cc = x.shape[:2]
+        S = x.numel() // (N * Cc)
+        return NormDesc(N, Cc, S, groups, act, eps, slope, 0, 0)
+
+    def norm_stats(self, x, groups, eps=1e-5, running=None, momentum=0.1):
+        x = self.to(x)
+        d = self.norm_desc(x, groups, eps=eps)
+        ns = self.fn("norm_num_stats")(C.byref(d))
+        mean, rstd = self.empty(ns), self.empty(ns)
+        rm = rv = None
+        if running is not None:
+            rm, rv = self.to(running[0]).clone(), self.to(running[1]).clone()
+        ws = self._ws("norm_workspace", d)
+        self._chk(self.fn("norm_stats")(C.byref(d), _p(x), _p(mean), _p(rstd), _p(rm), _p(rv), momentum, _p(ws),
+                                        ws.numel(), self._stream()), "norm_stats")
+        return mean, rstd, rm, rv
+
+    def norm_act_fwd(self, x, mean, rstd, gamma, beta, groups, act, add=None, eps=1e-5, slope=0.01):
+        x, mean, rstd, gamma, beta, add = map(self.to, (x, mean, rstd, gamma, beta, add))
+        d = self.norm_desc(x, groups, act, eps, slope)
+        y = torch.empty_like(x)
+        self._chk(self.fn("norm_act_fwd")(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add),
+                                          _p(y), self._stream()), "norm_act_fwd")
+        return y
+
+    def norm_act_bwd(self, x, dy, mean, rstd, gamma, beta, groups, act, training=1, eps=1e-5, slope=0.01):
+        x, dy, mean, rstd, gamma, beta = map(self.to, (x, dy, mean, rstd, gamma, beta))
+        d = self.norm_desc(x, groups, act, eps, slope)
+        dx = torch.empty_like(x)
+        dg = self.empty(x.shape[1]) if gamma is not None else None
+        db = self.empty(x.shape[1]) if gamma is not None else None
+        ws = self._ws("norm_workspace", d)
+        self._chk(self.fn("norm_act_bwd")(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                          _p(dx), _p(dg), _p(db), training, _p(ws), ws.numel(), self._stream()),
+                  "norm_act_bwd")
+        return dx, dg, db
+
+    # -------------------------------------------------- pool / upsample / softmax
+    def avgpool_fwd(self, x):
+        x = self.to(x)
+        N, Cc, D, H, W = x.shape
+        y = self.empty(N, Cc, D // 2, H // 2, W // 2)
+        self._chk(self.fn("avgpool3d_2x_fwd")(_p(x), _p(y), N, Cc, D, H, W, 0, 0, self._stream()), "avgpool_fwd")
+        return y
+
+    def avgpool_bwd(self, dy, x_shape):
+        dy = self.to(dy)
+        N, Cc, D, H, W = x_shape
+        dx = self.empty(*x_shape)
+        self._chk(self.fn("avgpool3d_2x_bwd")(_p(dy), _p(dx), N, Cc, D, H, W, 0, 0, self._stream()), "avgpool_bwd")
+        return dx
+
+    def upsample_fwd(self, x):
+        x = self.to(x)
+        N, Cc, D, H, W = x.shape
+        y = self.empty(N, Cc, 2 * D, 2 * H, 2 * W)
+        self._chk(self.fn("upsample_trilinear2x_fwd")(_p(x), _p(y), N, Cc, D, H, W, 0, 0, self._stream()),
+                  "upsample_fwd")
+        return y
+
+    def upsample_bwd(self, dy, x_shape):
+        dy = self.to(dy)
+        N, Cc, D, H, W = x_shape
+        dx = self.empty(*x_shape)
+        self._chk(self.fn("upsample_trilinear2x_bwd")(_p(dy), _p(dx), N, Cc, D, H, W, 0, 0, self._stream()),
+                  "upsample_bwd")
+        return dx
+
+    def softmax_fwd(self, x, inner=1, diag_bias=0.0):
+        x = self.to(x)
+        N, Ct = x.shape[:2]
+        S = x.numel() // (N * Ct)
+        y = torch.empty_like(x)
+        self._chk(self.fn("softmax_fwd")(_p(x), _p(y), N, Ct // inner, inner, S, diag_bias, self._stream()),
+                  "softmax_fwd")
+        return y
+
+    def softmax_bwd(self, y, dy, inner=1):
+        y, dy = self.to(y), self.to(dy)
+        N, Ct = y.shape[:2]
+        S = y.numel() // (N * Ct)
+        dx = torch.empty_like(y)
+        self._chk(self.fn("softmax_bwd")(_p(y), _p(dy), _p(dx), N, Ct // inner, inner, S, self._stream()),
+                  "softmax_bwd")
+        return dx
+
+    # ------------------------------------------------------------------ loss
+    def loss_fwd(self, p, t, dice_weight=0.5, cw=None, square=True):
+        p, t, cw = map(self.to, (p, t, cw))
+        N, Cc = p.shape[:2]
+        S = p.numel() // (N * Cc)
+        out3, sums = self.empty(3), self.empty(N * Cc * 4)
+        nws = self.lib.m355_hybrid_loss_workspace(N, Cc, S) if self.backend == "hip" else 16
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("hybrid_loss_fwd")(_p(p), _p(t), N, Cc, S, dice_weight, _p(cw), int(square), _p(out3),
+                                             _p(sums), _p(ws), ws.numel(), self._stream()), "loss_fwd")
+        return out3, sums
+
+    def loss_bwd(self, p, t, sums, dloss=1.0, dice_weight=0.5, cw=None, square=True):
+        p, t, sums, cw = map(self.to, (p, t, sums, cw))
+        N, Cc = p.shape[:2]
+        S = p.numel() // (N * Cc)
+        g = torch.tensor([dloss], dtype=torch.float32, device=self.device)
+        dp = torch.empty_like(p)
+        self._chk(self.fn("hybrid_loss_bwd")(_p(p), _p(t), _p(sums), _p(g), N, Cc, S, dice_weight, _p(cw),
+                                             int(square), _p(dp), self._stream()), "loss_bwd")
+        return dp
+
+    # ------------------------------------------------------ patches / evaluation
+    def patch_gather(self, vol, loc, ps):
+        vol, loc = self.to(vol), self.to(loc.to(torch.int32))
+        Cc, V0, V1, V2 = vol.shape
+        P = loc.shape[0]
+        out = self.empty(P, Cc, *ps)
+        self._chk(self.fn("patch_gather")(_p(vol), _p(loc), _p(out), P, Cc, V0, V1, V2, *ps, self._stream()),
+                  "patch_gather")
+        return out
+
+    def patch_aggregate(self, patches, loc, vshape):
+        patches, loc = self.to(patches), self.to(loc.to(torch.int32))
+        P, Cc = patches.shape[:2]
+        ps = patches.shape[2:]
+        accum = torch.zeros((Cc,) + tuple(vshape), device=self.device)
+        count = torch.zeros(tuple(vshape), device=self.device)
+        self._chk(self.fn("patch_accumulate")(_p(patches), _p(loc), _p(accum), _p(count), P, Cc, *vshape, *ps,
+                                              self._stream()), "patch_accumulate")
+        out = torch.empty_like(accum)
+        self._chk(self.fn("patch_finalize")(_p(accum), _p(count), _p(out), Cc, count.numel(), self._stream()),
+                  "patch_finalize")
+        return out, count
+
+    def argmax_confusion(self, prob, target):
+        prob, target = self.to(prob), self.to(target.to(torch.int32))
+        N, Cc = prob.shape[:2]
+        S = prob.numel() // (N * Cc)
+        am = torch.empty(target.shape, dtype=torch.int32, device=self.device)
+        counts = torch.empty((N, Cc, 4), dtype=torch.int64, device=self.device)
+        self._chk(self.fn("argmax_confusion")(_p(prob), _p(target), _p(am), _p(counts), N, Cc, S, self._stream()),
+                  "argmax_confusion")
+        return am, counts

@@ -1,0 +1,230 @@
+"""Pins the oracle (runs without a GPU).
+
+1. oracle/m355_oracle.c  vs  the stock torch-CPU ops the reference executes
+   (torch is what the reference calls).
+2. oracle/torch_ref.py   vs  golden vectors produced by the REAL reference modules
+   (tools/gen_golden.py).
+3. oracle/m355_oracle.c chained end-to-end vs the same golden vectors (loss fixture).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as R
+
+torch.manual_seed(0)
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"max err {err:.3e} (ref scale {ref:.3e})"
+
+
+# ------------------------------------------------------------- C oracle vs torch
+CONV_CASES = [
+    # N, Cin, Cout, D, H, W, k, stride, pad
+    (1, 4, 8, 6, 7, 5, 3, 1, 1),
+    (2, 5, 3, 8, 8, 8, 3, 1, 1),
+    (1, 6, 6, 8, 8, 8, 4, 2, 1),   # Blur-conv geometry
+    (1, 3, 4, 5, 5, 5, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_c_conv3d_matches_torch(oracle, case):
+    N, Ci, Co, D, H, W, k, s, p = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1).requires_grad_(), rnd(Co, Ci, k, k, k, seed=2).requires_grad_(), rnd(Co, seed=3).requires_grad_()
+    y = F.conv3d(x, w, b, stride=s, padding=p)
+    add = rnd(*y.shape, seed=4)
+    close(oracle.conv3d_fwd(x, w, b, add, s, p), y + add)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy)
+    close(oracle.conv3d_bwd_data(dy, w, x.shape, s, p), x.grad)
+    dw, db = oracle.conv3d_bwd_weight(x, dy, k, s, p)
+    close(dw, w.grad, 1e-5, 1e-4)
+    close(db, b.grad, 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("case", [(1, 4, 6, 3, 4, 5, 2, 2, 0, 0), (2, 3, 3, 4, 4, 4, 4, 2, 1, 0), (1, 2, 5, 3, 3, 3, 3, 2, 1, 1)])
+def test_c_conv_transpose3d_matches_torch(oracle, case):
+    N, Ci, Co, D, H, W, k, s, p, op = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1).requires_grad_(), rnd(Ci, Co, k, k, k, seed=2).requires_grad_(), rnd(Co, seed=3).requires_grad_()
+    y = F.conv_transpose3d(x, w, b, stride=s, padding=p, output_padding=op)
+    close(oracle.convt_fwd(x, w, b, s, p, op), y)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy)
+    close(oracle.convt_bwd_data(dy, w, x.shape, s, p, op), x.grad)
+    dw, db = oracle.convt_bwd_weight(x, dy, k, s, p, op)
+    close(dw, w.grad, 1e-5, 1e-4)
+    close(db, b.grad, 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("groups,act", [(4, 1), (0, 1), (8, 2), (0, 0)])
+def test_c_norm_act_matches_torch(oracle, groups, act):
+    x = (rnd(2, 8, 4, 5, 6, seed=1) * 2 + 0.5).requires_grad_()
+    gamma, beta = rnd(8, seed=2).requires_grad_(), rnd(8, seed=3).requires_grad_()
+    rm, rv = torch.zeros(8), torch.ones(8)
+    if groups:
+        pre = F.group_norm(x, groups, gamma, beta, 1e-5)
+    else:
+        pre = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    ref = {0: pre, 1: F.relu(pre), 2: F.leaky_relu(pre, 0.01)}[act]
+    mean, rstd, orm, orv = oracle.norm_stats(x, groups, running=None if groups else (torch.zeros(8), torch.ones(8)))
+    y = oracle.norm_act_fwd(x, mean, rstd, gamma, beta, groups, act)
+    close(y, ref)
+    if not groups:
+        close(orm, rm)
+        close(orv, rv)
+    dy = rnd(*x.shape, seed=7)
+    ref.backward(dy)
+    dx, dg, db = oracle.norm_act_bwd(x, dy, mean, rstd, gamma, beta, groups, act)
+    close(dx, x.grad, 1e-5, 1e-5)
+    close(dg, gamma.grad, 1e-5, 1e-4)
+    close(db, beta.grad, 1e-5, 1e-4)
+
+
+def test_c_batchnorm_eval_mode(oracle):
+    x = rnd(2, 4, 3, 3, 3, seed=1).requires_grad_()
+    gamma, beta, rm, rv = rnd(4, seed=2), rnd(4, seed=3), rnd(4, seed=4) * 0.1, torch.rand(4) + 0.5
+    ref = F.relu(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    d = oracle.norm_desc(x, 0)
+    import ctypes as C
+    mean, rstd = torch.empty(4), torch.empty(4)
+    oracle.fn("norm_stats_from_running")(C.byref(d), C.c_void_p(rm.data_ptr()), C.c_void_p(rv.data_ptr()),
+                                         C.c_void_p(mean.data_ptr()), C.c_void_p(rstd.data_ptr()), None)
+    close(oracle.norm_act_fwd(x, mean, rstd, gamma, beta, 0, 1), ref)
+    dy = rnd(*x.shape, seed=9)
+    ref.backward(dy)
+    dx, _, _ = oracle.norm_act_bwd(x, dy, mean, rstd, gamma, beta, 0, 1, training=0)
+    close(dx, x.grad)
+
+
+def test_c_pool_upsample_softmax_match_torch(oracle):
+    x = rnd(2, 3, 4, 6, 8, seed=1).requires_grad_()
+    y = F.avg_pool3d(x, 2, 2, count_include_pad=False)
+    close(oracle.avgpool_fwd(x), y)
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy)
+    close(oracle.avgpool_bwd(dy, x.shape), x.grad)
+
+    for shape in [(1, 2, 3, 4, 5), (2, 1, 1, 2, 2), (1, 1, 8, 8, 8)]:
+        x = rnd(*shape, seed=3).requires_grad_()
+        y = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
+        close(oracle.upsample_fwd(x), y, 1e-6, 1e-6)
+        dy = rnd(*y.shape, seed=4)
+        y.backward(dy)
+        close(oracle.upsample_bwd(dy, x.shape), x.grad, 1e-5, 1e-5)
+
+    x = (rnd(2, 3, 3, 4, 5, seed=5) * 3).requires_grad_()
+    y = torch.softmax(x, dim=1)
+    close(oracle.softmax_fwd(x), y, 1e-6, 1e-7)
+    dy = rnd(*y.shape, seed=6)
+    y.backward(dy)
+    close(oracle.softmax_bwd(y, dy), x.grad, 1e-5, 1e-7)
+
+
+def test_c_patches_and_confusion(oracle):
+    vol = rnd(2, 9, 8, 7, seed=1)
+    locs = R.grid_locations((9, 8, 7), (4, 4, 4), (1, 1, 1))
+    loc = torch.tensor(locs, dtype=torch.int32)
+    patches = oracle.patch_gather(vol, loc, (4, 4, 4))
+    for p, (i, j, k) in zip(patches, locs):
+        assert torch.equal(p, vol[:, i:i + 4, j:j + 4, k:k + 4])
+    out, count = oracle.patch_aggregate(patches, loc, (9, 8, 7))
+    assert count.min() >= 1
+    close(out, vol, 1e-6, 1e-6)           # a pointwise "model" must reproduce the volume
+    close(out, R.aggregate_average(patches, locs, (9, 8, 7)), 1e-6, 1e-6)
+
+    prob = torch.softmax(rnd(2, 3, 4, 4, 4, seed=2), dim=1)
+    tgt = torch.randint(0, 3, (2, 4, 4, 4), generator=torch.Generator().manual_seed(3))
+    am, counts = oracle.argmax_confusion(prob, tgt)
+    assert torch.equal(am.long(), prob.argmax(dim=1))
+    for n in range(2):
+        rows = R.hard_dice_table(prob[n].argmax(dim=0), tgt[n], 3)
+        for c, (tp, fp, fn, tn, _) in enumerate(rows):
+            assert counts[n, c].tolist() == [tp, fp, fn, tn]
+
+
+def test_hard_dice_hand_computed():
+    """evaluators/segmentation_evaluator.py:69-86 on a case small enough to do by hand."""
+    pred = torch.tensor([0, 0, 1, 1, 1, 2])
+    tgt = torch.tensor([0, 1, 1, 1, 2, 2])
+    rows = R.hard_dice_table(pred, tgt, 3)
+    assert rows[0][:4] == (1, 1, 0, 4) and rows[0][4] == pytest.approx(2 / 3)
+    assert rows[1][:4] == (2, 1, 1, 2) and rows[1][4] == pytest.approx(4 / 6)
+    assert rows[2][:4] == (1, 0, 1, 4) and rows[2][4] == pytest.approx(2 / 3)
+
+
+# ------------------------------------------------ golden vectors from the reference
+def test_c_loss_matches_reference_golden(oracle, golden):
+    g = golden("hybrid_loss.npz")
+    p, t = g.t("p"), g.t("t")
+    for i in range(3):
+        cfg = g[f"case{i}.cfg"]
+        dw, sq, cw = float(cfg[0]), bool(cfg[1]), (torch.tensor(cfg[2:], dtype=torch.float32) if len(cfg) > 2 else None)
+        out3, sums = oracle.loss_fwd(p, t, dw, cw, sq)
+        np.testing.assert_allclose(out3.numpy(), g[f"case{i}.out"], rtol=2e-6, atol=1e-7)
+        dp = oracle.loss_bwd(p, t, sums, 1.0, dw, cw, sq)
+        close(dp, g.t(f"case{i}.dp"), 1e-5, 1e-7)
+        # the torch restatement too
+        ld = R.hybrid_logistic_dice_loss(p, t, dw, None if cw is None else cw.tolist(), sq)
+        np.testing.assert_allclose([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()],
+                                   g[f"case{i}.out"], rtol=1e-6)
+
+
+SPECS = {
+    "unet_default_bn.npz": R.UNetSpec(4, 3, [8, 16, 32], 3),
+    "unet_gn_convt.npz": R.UNetSpec(4, 3, [8, 16, 32], 3, norm="group", groups=8, up="convT"),
+    "unet_res_blur.npz": R.UNetSpec(2, 2, [8, 8, 16], 3, residual=True, down="blur", up="blurT"),
+}
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_torch_ref_reproduces_reference_unet(golden, name):
+    g = golden(name)
+    spec = SPECS[name]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "kernel" not in k)
+          for k, v in g.state_dict("m.sd.").items()}
+    x, y = g.t("x"), g.t("y")
+    p = R.unet_forward(sd, spec, x, training=True)
+    np.testing.assert_allclose(p.detach().numpy(), g["m.probs_train"], rtol=0, atol=2e-6)
+    cw = [1, 100] if name == "unet_res_blur.npz" else None
+    ld = R.hybrid_logistic_dice_loss(p, y, 0.5, cw, True)
+    assert ld["loss"].item() == pytest.approx(float(g["m.loss"]), rel=1e-5)
+    ld["loss"].backward()
+    for k, v in sd.items():
+        gk = f"m.grad.{k}"
+        if gk in g.keys():
+            close(v.grad, g.t(gk), 1e-4, 1e-6)
+    sd_eval = {k: v for k, v in g.state_dict("m.sd_after.").items()}
+    with torch.no_grad():
+        pe = R.unet_forward(sd_eval, spec, x, training=False)
+    np.testing.assert_allclose(pe.numpy(), g["m.probs_eval"], rtol=0, atol=2e-6)
+
+
+def test_split_and_flip_fixture(golden):
+    g = golden("components.npz")
+    x = g.t("split.x")
+    y = R.split_and_flip(x)
+    assert torch.equal(y, g.t("split.y"))
+    assert torch.equal(R.reverse_split_and_flip(y), x)
+
+
+def test_c_softmax_stochastic_matrix_golden(oracle, golden):
+    g = golden("components.npz")
+    close(oracle.softmax_fwd(g.t("sm.x"), inner=2, diag_bias=5.0), g.t("sm.y"), 1e-6, 1e-7)
+    close(oracle.softmax_fwd(torch.zeros(1, 4, 1, 1, 1), inner=2, diag_bias=5.0), g.t("sm.zeros"), 1e-6, 1e-7)
+
+
+def test_grid_locations_match_documented_torchio_behaviour():
+    # cfg4: 256^3 volume, patch 160, overlap 20 -> starts (0, 96) per axis, 8 patches
+    locs = R.grid_locations((256, 256, 256), (160, 160, 160), (20, 20, 20))
+    assert len(locs) == 8 and locs[0] == (0, 0, 0) and locs[-1] == (96, 96, 96)
+    assert R.grid_locations((10, 10, 10), (4, 4, 4), (0, 0, 0))[:3] == [(0, 0, 0), (0, 0, 4), (0, 0, 6)]

@@ -1,0 +1,273 @@
+"""Generate tests/golden/*.npz from the REAL reference modules (build container only).
+
+The reference (efirdc/Segmentation-Pipeline, /root/reference) is pure Python on
+torch; its arithmetic files import on torch-CPU once `segmentation_pipeline/__init__.py`
+(which needs torchio) is bypassed with empty package shells.  This
+script runs the reference's own ModularUNet / NestedResUNet / Blur convs /
+StochasticMatrix / ensembles / HybridLogisticDiceLoss on seeded synthetic inputs and
+stores inputs, reference-keyed state_dicts and outputs as small fixtures.  Nothing
+of the reference itself (source, bytecode) is stored; the GPU box only sees the
+.npz data.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+from collections.abc import Sequence
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+REF = "/root/reference/segmentation_pipeline"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def load_reference():
+    def shell(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__package__ = name
+        sys.modules[name] = m
+        return m
+
+    shell("segmentation_pipeline", REF)
+    u = shell("segmentation_pipeline.utils", REF + "/utils")
+    u.is_sequence = lambda x: isinstance(x, Sequence) and not isinstance(x, str)  # utils/utils.py:19-20
+    import segmentation_pipeline.models as M
+
+    spec = importlib.util.spec_from_file_location(
+        "segmentation_pipeline.criterions.hybrid_logistic_dice_loss",
+        REF + "/criterions/hybrid_logistic_dice_loss.py")
+    C = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = C
+    spec.loader.exec_module(C)
+    return M, C
+
+
+def synth(shape, n_classes, seed):
+    """SURVEY.md §8d synthetic data: X ~ N(0,1), labels uniform -> one-hot float."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    lab = torch.randint(0, n_classes, (shape[0],) + tuple(shape[2:]), generator=g)
+    y = torch.nn.functional.one_hot(lab, n_classes).permute(0, 4, 1, 2, 3).float()
+    return x, lab, y
+
+
+def structured(shape, n_classes, seed):
+    """Smooth class blobs + mild noise, so top-2 probability gaps are large (bit-exact argmax)."""
+    g = torch.Generator().manual_seed(seed)
+    N, Cc, D, H, W = shape
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, D), torch.linspace(-1, 1, H), torch.linspace(-1, 1, W),
+                                indexing="ij")
+    x = torch.zeros(shape)
+    for c in range(Cc):
+        cz, cy, cx = (torch.rand(3, generator=g) * 1.2 - 0.6).tolist()
+        x[:, c] = torch.exp(-((zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2) * 3.0) * 2.0
+    return x + 0.1 * torch.randn(shape, generator=g)
+
+
+def sd_np(model, prefix="sd."):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def run_model(model, crit, x, y, tag, out):
+    """train-mode forward + loss + backward, then eval-mode forward"""
+    out.update(sd_np(model, f"{tag}.sd."))
+    model.train()
+    p = model(x)
+    ld = crit(p, y)
+    model.zero_grad()
+    ld["loss"].backward()
+    out[f"{tag}.probs_train"] = p.detach().numpy()
+    for k, v in ld.items():
+        out[f"{tag}.{k}"] = np.float32(v.item())
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            out[f"{tag}.grad.{k}"] = v.grad.numpy().copy()
+    out.update(sd_np(model, f"{tag}.sd_after."))  # BN running stats moved
+    model.eval()
+    with torch.no_grad():
+        out[f"{tag}.probs_eval"] = model(x).numpy()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    M, C = load_reference()
+    torch.set_num_threads(8)
+    meta = {"torch": torch.__version__}
+
+    # 1. default config: BN / AvgPool / trilinear (cfg1 family)
+    out = {}
+    torch.manual_seed(0)
+    model = M.ModularUNet(4, 3, [8, 16, 32], 3)
+    x, lab, y = synth((2, 4, 16, 16, 16), 3, 1234)
+    out["x"], out["y"], out["labels"] = x.numpy(), y.numpy(), lab.numpy().astype(np.int32)
+    run_model(model, C.HybridLogisticDiceLoss(), x, y, "m", out)
+    np.savez_compressed(os.path.join(OUT, "unet_default_bn.npz"), **out)
+
+    # 2. north-star variant (cfg2 family, small): GroupNorm(8) + ConvTranspose3d(k2,s2)
+    out = {}
+    torch.manual_seed(0)
+    mk = lambda: M.ModularUNet(4, 3, [8, 16, 32], 3, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                               upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+    model = mk()
+    x, lab, y = synth((2, 4, 16, 16, 16), 3, 1234)
+    out["x"], out["y"], out["labels"] = x.numpy(), y.numpy(), lab.numpy().astype(np.int32)
+    crit = C.HybridLogisticDiceLoss()
+    run_model(model, crit, x, y, "m", out)
+    # structured volume: argmax must be reproduced bit-exactly
+    xs = structured((1, 4, 16, 16, 16), 3, 7)
+    model.eval()
+    with torch.no_grad():
+        ps = model(xs)
+    top2 = ps.topk(2, dim=1).values
+    out["xs"], out["probs_struct"] = xs.numpy(), ps.numpy()
+    out["argmax_struct"] = ps.argmax(dim=1).numpy().astype(np.int32)
+    out["min_top2_gap"] = np.float32((top2[:, 0] - top2[:, 1]).min().item())
+    # 3-step SGD trajectory (segmentation_trainer.py:162-180 order; msseg2.py:94 optimizer)
+    torch.manual_seed(0)
+    model = mk()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)
+    losses = []
+    for step in range(3):
+        model.train()
+        p = model(x)
+        ld = crit(p, y)
+        opt.zero_grad()
+        ld["loss"].backward()
+        opt.step()
+        model.eval()
+        losses.append([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()])
+    out["sgd_losses"] = np.asarray(losses, dtype=np.float32)
+    out.update(sd_np(model, "sgd.sd_final."))
+    np.savez_compressed(os.path.join(OUT, "unet_gn_convt.npz"), **out)
+
+    # 3. msseg2 variant: residual blocks + BlurConv3d / BlurConvTranspose3d (msseg2.py:84-93)
+    out = {}
+    torch.manual_seed(0)
+    model = M.ModularUNet(2, 2, [8, 8, 16], 3, block_params={'residual': True},
+                          downsample_class=M.BlurConv3d,
+                          downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1},
+                          upsample_class=M.BlurConvTranspose3d,
+                          upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0})
+    x, lab, y = synth((1, 2, 16, 16, 16), 2, 99)
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    run_model(model, C.HybridLogisticDiceLoss(logistic_class_weights=[1, 100]), x, y, "m", out)
+    np.savez_compressed(os.path.join(OUT, "unet_res_blur.npz"), **out)
+
+    # 4. NestedResUNet (dmri_hippo default family, main_config.py:123-127)
+    out = {}
+    torch.manual_seed(0)
+    model = M.NestedResUNet(3, 2, 8)
+    x, lab, y = synth((1, 3, 16, 16, 16), 2, 5)
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    run_model(model, C.HybridLogisticDiceLoss(), x, y, "m", out)
+    np.savez_compressed(os.path.join(OUT, "nested_res_unet.npz"), **out)
+
+    # 5. loss alone, incl. dL/dp
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.softmax(torch.randn((2, 3, 6, 5, 4), generator=g) * 2, dim=1)
+    lab = torch.randint(0, 3, (2, 6, 5, 4), generator=g)
+    t = torch.nn.functional.one_hot(lab, 3).permute(0, 4, 1, 2, 3).float()
+    out["p"], out["t"] = p0.numpy(), t.numpy()
+    for i, (dw, cw, sq) in enumerate([(0.5, None, True), (0.3, [1.0, 2.0, 3.0], False), (0.5, [1, 100, 1], True)]):
+        p = p0.clone().requires_grad_(True)
+        ld = C.HybridLogisticDiceLoss(dw, cw, sq)(p, t)
+        ld["loss"].backward()
+        out[f"case{i}.cfg"] = np.asarray([dw, float(sq)] + (list(map(float, cw)) if cw else []), dtype=np.float64)
+        out[f"case{i}.out"] = np.asarray([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()],
+                                         dtype=np.float32)
+        out[f"case{i}.dp"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "hybrid_loss.npz"), **out)
+
+    # 6. components: Blur convs, WSConv3d, StochasticMatrix, ensembles, split/flip index check
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(1)
+    bc = M.BlurConv3d(8, 8, 3, stride=2, padding=1)
+    xin = torch.randn((1, 8, 8, 8, 8), generator=g, requires_grad=True)
+    yb = bc(xin)
+    yb.sum().backward()
+    out["blur.x"], out["blur.y"], out["blur.dx"] = xin.detach().numpy(), yb.detach().numpy(), xin.grad.numpy()
+    out["blur.dw"] = bc.weight.grad.numpy()
+    out.update(sd_np(bc, "blur.sd."))
+    bt = M.BlurConvTranspose3d(8, 8, 3, stride=2, padding=1, output_padding=0, weight_standardization=True)
+    xin = torch.randn((1, 8, 4, 4, 4), generator=g, requires_grad=True)
+    yt = bt(xin)
+    (yt * yt).sum().backward()
+    out["blurT.x"], out["blurT.y"], out["blurT.dx"] = xin.detach().numpy(), yt.detach().numpy(), xin.grad.numpy()
+    out["blurT.dw"] = bt.weight.grad.numpy()
+    out.update(sd_np(bt, "blurT.sd."))
+    ws = M.WSConv3d(4, 6, 3, padding=1)
+    xin = torch.randn((1, 4, 6, 6, 6), generator=g)
+    out["ws.x"], out["ws.y"] = xin.numpy(), ws(xin).detach().numpy()
+    out.update(sd_np(ws, "ws.sd."))
+    sm = M.StochasticMatrix(2, diag_bias=5)
+    xin = torch.randn((2, 4, 3, 3, 3), generator=g)
+    out["sm.x"], out["sm.y"] = xin.numpy(), sm(xin).numpy()
+    out["sm.zeros"] = sm(torch.zeros(1, 4, 1, 1, 1)).numpy()
+    # apply_strategy on a stack of fake predictions
+    from segmentation_pipeline.models.ensemble import apply_strategy
+    preds = [torch.softmax(torch.randn((2, 3, 4, 4, 4), generator=g), dim=1) for _ in range(5)]
+    out["ens.preds"] = torch.stack(preds).numpy()
+    out["ens.mean"] = apply_strategy(preds, "mean").numpy()
+    out["ens.majority"] = apply_strategy(preds, "majority").numpy().astype(np.int64)
+    # EnsembleFlips(mean) around the tiny GN/ConvT model
+    torch.manual_seed(0)
+    model = M.ModularUNet(4, 3, [8, 16], 2, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                          upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+    model.eval()
+    xin = torch.randn((1, 4, 8, 8, 8), generator=g)
+    with torch.no_grad():
+        out["flips.x"] = xin.numpy()
+        out["flips.mean"] = M.EnsembleFlips(model, "mean")(xin).numpy()
+        out["flips.majority34"] = M.EnsembleFlips(model, "majority", spatial_dims=(3, 4))(xin).numpy().astype(np.int64)
+    out.update(sd_np(model, "flips.sd."))
+    # split_and_flip: transcribed here (prediction.py:16-27 cannot be imported: torchio) -- the
+    # fixture is plain index data produced by those four torch calls
+    a = torch.arange(2 * 3 * 8 * 2 * 2, dtype=torch.float32).reshape(2, 3, 8, 2, 2)
+    parts = list(a.split(a.shape[2] // 2, dim=2))
+    parts[1] = parts[1].flip(2)
+    out["split.x"], out["split.y"] = a.numpy(), torch.cat(parts, dim=0).numpy()
+    np.savez_compressed(os.path.join(OUT, "components.npz"), **out)
+
+    # 7. the real cfg2 architecture at a reduced patch (weights re-created from seed 0 on the box)
+    out = {}
+    torch.manual_seed(0)
+    model = M.ModularUNet(4, 3, [32, 64, 128, 256, 320], 5,
+                          block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                          upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+    out["n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+    out["param_sums"] = np.asarray([p.double().sum().item() for p in model.parameters()])
+    out["param_abs_sums"] = np.asarray([p.double().abs().sum().item() for p in model.parameters()])
+    x, lab, y = synth((1, 4, 32, 32, 32), 3, 1234)
+    crit = C.HybridLogisticDiceLoss()
+    model.train()
+    p = model(x)
+    ld = crit(p, y)
+    ld["loss"].backward()
+    out["probs_sub"] = p.detach().numpy()[:, :, ::3, ::3, ::3]
+    out["argmax"] = p.argmax(dim=1).numpy().astype(np.int8)
+    top2 = p.detach().topk(2, dim=1).values
+    out["top2_gap"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)
+    out["losses"] = np.asarray([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()], dtype=np.float32)
+    out["grad_norms"] = np.asarray([p_.grad.double().norm().item() for p_ in model.parameters()])
+    out["grad_heads"] = np.stack([np.resize(p_.grad.flatten()[:8].numpy(), 8) for p_ in model.parameters()])
+    np.savez_compressed(os.path.join(OUT, "cfg2_arch_32cube.npz"), **out)
+
+    with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
+        f.write("Generated by tools/gen_golden.py from the reference modules at /root/reference\n")
+        f.write(f"torch {meta['torch']}\n")
+        for name in sorted(os.listdir(OUT)):
+            if name.endswith(".npz"):
+                f.write(f"{name} {os.path.getsize(os.path.join(OUT, name))} bytes\n")
+    print("golden fixtures written to", os.path.abspath(OUT))
+
+
+if __name__ == "__main__":
+    main()
