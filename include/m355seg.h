@@ -71,6 +71,12 @@ int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
                     const float* bias, const float* add, float* y,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
+ * which: 0 = forward, 1 = data gradient.  out[0] = 1 if the MFMA implicit-GEMM path is
+ * used (0 = generic direct kernel), out[1] = voxel groups per wave (NTW), out[2] = lanes
+ * along x per group (GX), out[3] = split-K factor.  Pure host function. */
+int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4);
+
 /* dx = conv-transpose of dy with w (autograd of the op above w.r.t. x).
  * desc describes the FORWARD op; dx has x's shape and x_batch_stride,
  * dy has y's shape and y_batch_stride. */

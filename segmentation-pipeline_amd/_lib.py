@@ -44,6 +44,7 @@ SIGNATURES = {
     "m355_last_error": (C.c_char_p, []),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
     "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_plan": (C.c_int, [_CD, _i32, C.POINTER(C.c_int32)]),
     "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
     "m355_conv3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_weight_workspace": (_sz, [_CD]),

@@ -728,6 +728,16 @@ extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const 
   return check_launch("conv3d_direct_fwd");
 }
 
+extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
+  M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (!is_k3s1p1(d)) return M355_OK;
+  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W)
+                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W);
+  out4[0] = 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  return M355_OK;
+}
+
 extern "C" size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W);

@@ -110,6 +110,13 @@ def _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad=0):
     return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs)
 
 
+def conv_plan(desc, which=0):
+    """(mfma, ntw, gx, ksplit) of the kernel variant the library picks (profiling only)."""
+    out = (C.c_int32 * 4)()
+    check(_lib.lib().m355_conv3d_plan(C.byref(desc), which, out), "conv3d_plan")
+    return tuple(out)
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, add, meta: _ConvMeta, *parts):
@@ -139,7 +146,7 @@ class _Conv3dFn(torch.autograd.Function):
         if prof is not None:
             e1.record()
             flops = 2.0 * k ** 3 * Cin * Cout * N * oshape[2] * oshape[3] * oshape[4]
-            prof.append(("conv3d_fwd", flops, e0, e1))
+            prof.append(("conv3d_fwd", flops, e0, e1, conv_plan(d, 0)))
         ctx.meta, ctx.desc = meta, d
         ctx.has_bias, ctx.has_add = bias is not None, add is not None
         ctx.part_channels = [p.shape[1] for p in parts]
@@ -171,7 +178,7 @@ class _Conv3dFn(torch.autograd.Function):
                                            _stream()), "conv3d_bwd_weight")
             if prof is not None:
                 e1.record()
-                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1))
+                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1, None))
         if need_x:
             # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part
             dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
@@ -184,7 +191,7 @@ class _Conv3dFn(torch.autograd.Function):
                                          _stream()), "conv3d_bwd_data")
             if prof is not None:
                 e1.record()
-                prof.append(("conv3d_bwd_data", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1))
+                prof.append(("conv3d_bwd_data", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1, conv_plan(dd, 1)))
             c0 = 0
             for i, cc in enumerate(ctx.part_channels):
                 if ctx.needs_input_grad[4 + i]:

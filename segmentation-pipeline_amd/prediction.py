@@ -1,0 +1,130 @@
+"""Tensor-level predictors: the arithmetic of segmentation_pipeline/prediction.py
+(reference) without the torchio Subject plumbing.
+
+* split_and_flip / reverse_split_and_flip (:16-27): index-only views.
+* StandardPredict.predict (:73-102): optional sagittal split, one model call; the
+  prediction stays on the device (the reference's per-subject `.detach().cpu()`, :97,
+  is an evaluator concern and forces a sync every iteration).
+* PatchPredict.predict (:124-152): torchio GridSampler / GridAggregator('average')
+  become a deterministic tile list + the patch_gather / patch_accumulate kernels;
+  with torch.distributed initialised the tiles are sharded over the ranks and
+  returned by a single all_gather (distributed.gather_tiles).
+"""
+import itertools
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import distributed as D
+from . import ops
+
+
+def split_and_flip(x: torch.Tensor) -> torch.Tensor:
+    first, second = x.split(x.shape[2] // 2, dim=2)
+    return torch.cat([first, second.flip(2)], dim=0)
+
+
+def reverse_split_and_flip(x: torch.Tensor) -> torch.Tensor:
+    first, second = x.split(x.shape[0] // 2, dim=0)
+    return torch.cat([first, second.flip(2)], dim=2)
+
+
+def grid_locations(volume_shape, patch_size, patch_overlap):
+    """Corner indices of torchio 0.18.45's GridSampler with padding_mode=None (the
+    configuration of research/msseg2/msseg2.py:139-146): per axis
+    range(0, size - patch + 1, patch - overlap), plus size - patch if the border is not
+    reached; patches enumerated in itertools.product order."""
+    axes = []
+    for size, p, o in zip(volume_shape, patch_size, patch_overlap):
+        if p > size:
+            raise ValueError(f"patch size {p} exceeds volume size {size}")
+        if o >= p:
+            raise ValueError(f"patch overlap {o} must be smaller than patch size {p}")
+        starts = list(range(0, size - p + 1, p - o))
+        if starts[-1] != size - p:
+            starts.append(size - p)
+        axes.append(starts)
+    return [tuple(c) for c in itertools.product(*axes)]
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class StandardPredict:
+    """Whole-image prediction (reference :57-102), tensors in, tensors out."""
+
+    def __init__(self, image_names: Sequence[str] = ("X",), sagittal_split: bool = False, refine_image: str = None):
+        image_names = list(image_names)
+        if refine_image is not None and refine_image not in image_names:
+            image_names.append(refine_image)
+        self.image_names = image_names
+        self.sagittal_split = sagittal_split
+        self.refine_image = refine_image
+
+    def predict(self, model, device, batch, label_attributes=None):
+        """batch: dict of stacked tensors (collate_subjects, utils/utils.py:75-85)."""
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        x = batch["X"]
+        if self.sagittal_split:
+            y_pred = reverse_split_and_flip(model(split_and_flip(x).contiguous()))
+        else:
+            y_pred = model(x)
+        batch["y_pred"] = y_pred
+        return batch
+
+
+class PatchPredict:
+    """Sliding-window prediction with overlap averaging (reference :105-152)."""
+
+    def __init__(self, image_names: Sequence[str] = ("X",), patch_batch_size: int = 16, patch_size=None,
+                 patch_overlap=(0, 0, 0), padding_mode=None, overlap_mode: str = "average", ops_backend=ops):
+        if overlap_mode != "average":
+            raise NotImplementedError("only overlap_mode='average' (the mode the reference uses) is implemented")
+        if padding_mode is not None:
+            raise NotImplementedError("padding_mode is not implemented (the reference's configs use None)")
+        self.image_names = image_names
+        self.patch_batch_size = patch_batch_size
+        self.patch_size = _triple(patch_size)
+        self.patch_overlap = _triple(patch_overlap)
+        self.padding_mode = padding_mode
+        self.overlap_mode = overlap_mode
+        self._ops = ops_backend  # the HIP ops; tests inject a CPU double for the gloo plumbing test
+
+    def predict_volume(self, model, volume: torch.Tensor) -> torch.Tensor:
+        """volume [C, V0, V1, V2] on the device -> averaged prediction [C_out, V0, V1, V2]."""
+        k = self._ops
+        vshape = tuple(volume.shape[1:])
+        locs = grid_locations(vshape, self.patch_size, self.patch_overlap)
+        world = torch.distributed.get_world_size() if D.is_distributed() else 1
+        rank = torch.distributed.get_rank() if D.is_distributed() else 0
+        mine = D.shard_indices(len(locs), rank, world)
+        outs = []
+        with torch.no_grad():
+            for s in range(0, len(mine), self.patch_batch_size):
+                idx = mine[s:s + self.patch_batch_size]
+                loc = torch.tensor([locs[i] for i in idx], dtype=torch.int32, device=volume.device)
+                outs.append(model(k.patch_gather(volume, loc, self.patch_size)))
+        local = torch.cat(outs, dim=0) if outs else None
+        if local is not None:
+            c_out, dtype = local.shape[1], local.dtype
+            meta = torch.tensor([c_out], device=volume.device)
+        else:
+            meta = torch.tensor([0], device=volume.device)
+        if world > 1:  # ranks without tiles learn the channel count (tiny, once per volume)
+            torch.distributed.all_reduce(meta, op=torch.distributed.ReduceOp.MAX)
+        c_out = int(meta.item())
+        tiles = D.gather_tiles(local, len(locs), (c_out,) + self.patch_size, torch.float32, volume.device)
+        # aggregation in grid order on every rank: identical bits regardless of world size
+        accum = torch.zeros((c_out,) + vshape, dtype=torch.float32, device=volume.device)
+        count = torch.zeros(vshape, dtype=torch.float32, device=volume.device)
+        all_loc = torch.tensor(locs, dtype=torch.int32, device=volume.device)
+        for s in range(0, len(locs), self.patch_batch_size):  # same batching as the reference loop (:136-141)
+            k.patch_accumulate(tiles[s:s + self.patch_batch_size], all_loc[s:s + self.patch_batch_size], accum, count)
+        return k.patch_finalize(accum, count)
+
+    def predict(self, model, device, batch, label_attributes=None):
+        x = batch["X"].to(device)
+        batch = dict(batch)
+        batch["y_pred"] = torch.stack([self.predict_volume(model, v) for v in x])
+        return batch

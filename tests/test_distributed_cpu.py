@@ -1,0 +1,190 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: bucketed gradient all-reduce
+and tile sharding + single gather.  The arithmetic kernels are not involved: the wrapped
+module is a stock torch model and the patch ops are a CPU test double defined here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from oracle import torch_ref as R
+from segmentation_pipeline_amd import distributed as D
+from segmentation_pipeline_amd.prediction import PatchPredict, grid_locations
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        torch.set_num_threads(1)
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv3d(2, 8, 3, padding=1)
+        self.n1 = nn.GroupNorm(4, 8)
+        self.c2 = nn.Conv3d(8, 3, 3, padding=1)
+        self.unused = nn.Parameter(torch.zeros(5))  # like the Blur convs' bias: never gets a grad
+
+    def forward(self, x):
+        return torch.softmax(self.c2(torch.relu(self.n1(self.c1(x)))), dim=1)
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn((1, 2, 6, 6, 6), generator=g)
+    lab = torch.randint(0, 3, (1, 6, 6, 6), generator=g)
+    return x, torch.nn.functional.one_hot(lab, 3).permute(0, 4, 1, 2, 3).float()
+
+
+def _ddp_worker(rank, world):
+    model = Net()
+    if rank == 1:  # replicas start different: the wrapper must broadcast rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    ddp = D.PatchParallel(model, bucket_bytes=4096)  # tiny buckets -> several collectives
+    assert len(ddp.buckets) > 1
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    x, y = _data(rank)
+    losses = []
+    for _ in range(2):
+        ddp.zero_grad()
+        loss = R.hybrid_logistic_dice_loss(ddp(x), y)["loss"]
+        loss.backward()
+        ddp.finish_gradient_sync()
+        opt.step()
+        losses.append(loss.item())
+    assert model.unused.grad is None
+    vals = D.all_reduce_mean_scalars(torch.tensor([float(rank), 1.0]))
+    return {k: v.clone() for k, v in model.state_dict().items()}, losses, vals
+
+
+def test_patch_parallel_equals_single_process_mean_gradient():
+    results = spawn(_ddp_worker)
+    (sd0, l0, v0), (sd1, l1, v1) = results
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged at {k}"
+    assert torch.equal(v0, torch.tensor([0.5, 1.0]))
+    # single-process reference: gradient of the mean of the two per-rank losses
+    torch.manual_seed(0)
+    model = Net()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for step in range(2):
+        opt.zero_grad()
+        per_rank = [R.hybrid_logistic_dice_loss(model(_data(r)[0]), _data(r)[1])["loss"] for r in range(2)]
+        assert per_rank[0].item() == pytest.approx(l0[step], rel=1e-5)
+        assert per_rank[1].item() == pytest.approx(l1[step], rel=1e-5)
+        ((per_rank[0] + per_rank[1]) / 2).backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        torch.testing.assert_close(sd0[k], v, rtol=1e-5, atol=1e-6)
+
+
+class CpuPatchOps:
+    """Test double with the signature of ops.patch_* (plain torch indexing on CPU)."""
+
+    @staticmethod
+    def patch_gather(volume, loc, ps):
+        return torch.stack([volume[:, i:i + ps[0], j:j + ps[1], k:k + ps[2]] for i, j, k in loc.tolist()])
+
+    @staticmethod
+    def patch_accumulate(patches, loc, accum, count):
+        ps = patches.shape[2:]
+        for p, (i, j, k) in zip(patches, loc.tolist()):
+            accum[:, i:i + ps[0], j:j + ps[1], k:k + ps[2]] += p
+            count[i:i + ps[0], j:j + ps[1], k:k + ps[2]] += 1
+
+    @staticmethod
+    def patch_finalize(accum, count):
+        return accum / count
+
+
+class TileModel(nn.Module):
+    """Not pointwise (neighbouring voxels mix through the rolls, so overlapping tiles really
+    disagree and the averaging matters) yet bitwise independent of batching / thread count."""
+
+    def forward(self, x):
+        h = x * 2.0 + torch.roll(x, 1, dims=-1) - 0.5 * torch.roll(x, -1, dims=-2)
+        h = torch.cat([h, h[:, :1] * h[:, 1:2]], dim=1)
+        return torch.softmax(h, dim=1)
+
+
+def _volume():
+    return torch.randn((2, 14, 12, 13), generator=torch.Generator().manual_seed(7))
+
+
+def _predict(rank=0, world=1):
+    torch.set_num_threads(1)  # torch-CPU softmax bits depend on the thread split; the double must be deterministic
+    pp = PatchPredict(patch_batch_size=2, patch_size=6, patch_overlap=2, ops_backend=CpuPatchOps)
+    return pp.predict_volume(TileModel(), _volume())
+
+
+def test_sharded_sliding_window_is_bit_identical_to_unsharded():
+    nthreads = torch.get_num_threads()
+    single = _predict()
+    torch.set_num_threads(nthreads)
+    r0, r1 = spawn(_predict)
+    assert torch.equal(r0, r1)
+    assert torch.equal(r0, single), "tile sharding + one gather must not change a single bit"
+    # and both equal the oracle's restatement of GridSampler + GridAggregator('average')
+    vol = _volume()
+    locs = R.grid_locations(vol.shape[1:], (6, 6, 6), (2, 2, 2))
+    with torch.no_grad():
+        patches = TileModel()(CpuPatchOps.patch_gather(vol, torch.tensor(locs), (6, 6, 6)))
+    torch.testing.assert_close(single, R.aggregate_average(patches, locs, vol.shape[1:]), rtol=0, atol=1e-6)
+
+
+def _gather_worker(rank, world):
+    n_tiles = 5  # not divisible by the world size
+    mine = D.shard_indices(n_tiles, rank, world)
+    local = torch.stack([torch.full((2, 3), float(i)) for i in mine])
+    return D.gather_tiles(local, n_tiles, (2, 3), torch.float32, torch.device("cpu"))
+
+
+def test_gather_tiles_restores_global_order():
+    for out in spawn(_gather_worker):
+        assert out.shape == (5, 2, 3)
+        assert out[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def test_grid_locations_and_validation():
+    assert grid_locations((256,) * 3, (160,) * 3, (20,) * 3) == R.grid_locations((256,) * 3, (160,) * 3, (20,) * 3)
+    assert len(grid_locations((256,) * 3, (160,) * 3, (20,) * 3)) == 8
+    assert grid_locations((10, 10, 10), (10, 10, 10), (0, 0, 0)) == [(0, 0, 0)]
+    with pytest.raises(ValueError):
+        grid_locations((8, 8, 8), (10, 10, 10), (0, 0, 0))
+    with pytest.raises(NotImplementedError):
+        PatchPredict(patch_size=8, overlap_mode="crop")
+    assert D.shard_indices(8, 3, 8) == [3] and D.shard_indices(5, 1, 2) == [1, 3]
+
+
+def test_split_and_flip_matches_fixture(golden):
+    from segmentation_pipeline_amd.prediction import reverse_split_and_flip, split_and_flip
+    g = golden("components.npz")
+    x = g.t("split.x")
+    assert torch.equal(split_and_flip(x), g.t("split.y"))
+    assert torch.equal(reverse_split_and_flip(split_and_flip(x)), x)

@@ -52,7 +52,8 @@ def test_cfg2_architecture_param_count_and_init(golden):
     torch.manual_seed(0)
     model = ModularUNet(4, 3, [32, 64, 128, 256, 320], 5, block_params=dict(GN8), **CONVT)
     assert sum(p.numel() for p in model.parameters()) == int(g["n_params"]) == 18080419
-    np.testing.assert_allclose([p.double().sum().item() for p in model.parameters()], g["param_sums"], rtol=0, atol=0)
+    # (the double sums are thread-count dependent in the last bits; the weights themselves are exact)
+    np.testing.assert_allclose([p.double().sum().item() for p in model.parameters()], g["param_sums"], rtol=1e-10, atol=1e-10)
 
 
 def test_constructor_signatures_mirror_reference():

@@ -1,0 +1,228 @@
+"""HIP kernels vs the CPU oracle, called through the C ABI on the same seeded inputs.
+
+fp32 tolerance: the oracle accumulates in double; the kernels in fp32 (MFMA = k-ordered
+fma chain).  Per-element bound used here: |err| <= 2e-5 * sum|terms| scale, written as
+rtol/atol on the output scale.  Edge cases: ragged sizes that do not divide the tiles,
+channels not multiple of 32 (and odd, for the MFMA k-pair), N > 1, tiny volumes, the
+split-K path, concat-slot batch strides.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def close(a, b, rtol=2e-5, atol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} (ref scale {ref:.3e})"
+
+
+CONV3 = [
+    # N, Cin, Cout, D, H, W      -- all 3x3x3 / s1 / p1 (MFMA implicit GEMM)
+    (1, 4, 32, 16, 16, 32),      # first-layer shape family (Cin=4)
+    (1, 32, 32, 8, 16, 64),      # GX=32 tiles
+    (2, 5, 7, 9, 10, 33),        # ragged everything, odd Cin (zero k-pair), N=2
+    (1, 64, 40, 8, 8, 16),       # GX=16, Cout not multiple of 32
+    (1, 96, 32, 8, 8, 8),        # GX=8, concat-sized Cin
+    (1, 3, 3, 4, 4, 4),          # tiny: W < 8
+    (1, 320, 64, 4, 4, 4),       # deep level: split-K over channel chunks
+    (2, 16, 3, 6, 6, 40),        # out-conv family (Cout=3)
+]
+
+
+@pytest.mark.parametrize("case", CONV3)
+def test_conv3d_3x3x3_fwd_bwd(hip, oracle, case):
+    N, Ci, Co, D, H, W = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Co, Ci, 3, 3, 3, seed=2) * (1.0 / (27 * Ci) ** 0.5), rnd(Co, seed=3)
+    add = rnd(N, Co, D, H, W, seed=4)
+    scale = 1.0
+    close(hip.conv3d_fwd(x, w, b, add), oracle.conv3d_fwd(x, w, b, add), what="fwd")
+    close(hip.conv3d_fwd(x, w), oracle.conv3d_fwd(x, w), what="fwd nobias")
+    dy = rnd(N, Co, D, H, W, seed=5)
+    close(hip.conv3d_bwd_data(dy, w, x.shape), oracle.conv3d_bwd_data(dy, w, x.shape), what="bwd_data")
+    dw_h, db_h = hip.conv3d_bwd_weight(x, dy, 3)
+    dw_o, db_o = oracle.conv3d_bwd_weight(x, dy, 3)
+    close(dw_h, dw_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what="bwd_weight")
+    close(db_h, db_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what="dbias")
+
+
+@pytest.mark.parametrize("case", [(1, 6, 6, 8, 8, 8, 4, 2, 1), (2, 3, 5, 7, 6, 5, 3, 2, 1), (1, 4, 4, 5, 5, 5, 1, 1, 0)])
+def test_conv3d_generic_direct(hip, oracle, case):
+    N, Ci, Co, D, H, W, k, s, p = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Co, Ci, k, k, k, seed=2) * 0.2, rnd(Co, seed=3)
+    yo = oracle.conv3d_fwd(x, w, b, None, s, p)
+    close(hip.conv3d_fwd(x, w, b, None, s, p), yo)
+    dy = rnd(*yo.shape, seed=5)
+    close(hip.conv3d_bwd_data(dy, w, x.shape, s, p), oracle.conv3d_bwd_data(dy, w, x.shape, s, p))
+    dw_h, db_h = hip.conv3d_bwd_weight(x, dy, k, s, p)
+    dw_o, db_o = oracle.conv3d_bwd_weight(x, dy, k, s, p)
+    close(dw_h, dw_o, 3e-5, 1e-4)
+    close(db_h, db_o, 3e-5, 1e-4)
+
+
+def test_conv3d_deterministic(hip):
+    x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
+    dy = rnd(1, 32, 8, 16, 32, seed=3)
+    a, b = hip.conv3d_fwd(x, w), hip.conv3d_fwd(x, w)
+    assert torch.equal(a, b)
+    (d1, _), (d2, _) = hip.conv3d_bwd_weight(x, dy, 3), hip.conv3d_bwd_weight(x, dy, 3)
+    assert torch.equal(d1, d2)
+
+
+CONVT = [
+    # N, Cin, Cout, D, H, W, k, s, p, out_pad
+    (1, 64, 64, 4, 4, 8, 2, 2, 0, 0),
+    (2, 5, 7, 3, 5, 6, 2, 2, 0, 0),     # ragged channel tiles
+    (1, 320, 48, 2, 2, 2, 2, 2, 0, 0),
+    (1, 8, 8, 4, 4, 4, 4, 2, 1, 0),     # BlurConvTranspose3d geometry
+    (1, 3, 4, 3, 3, 3, 3, 2, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONVT)
+def test_conv_transpose3d_fwd_bwd(hip, oracle, case):
+    N, Ci, Co, D, H, W, k, s, p, op = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Ci, Co, k, k, k, seed=2) * (1.0 / Ci ** 0.5), rnd(Co, seed=3)
+    yo = oracle.convt_fwd(x, w, b, s, p, op)
+    close(hip.convt_fwd(x, w, b, s, p, op), yo, what="fwd")
+    dy = rnd(*yo.shape, seed=5)
+    close(hip.convt_bwd_data(dy, w, x.shape, s, p, op), oracle.convt_bwd_data(dy, w, x.shape, s, p, op), what="bwd_data")
+    dw_h, db_h = hip.convt_bwd_weight(x, dy, k, s, p, op)
+    dw_o, db_o = oracle.convt_bwd_weight(x, dy, k, s, p, op)
+    close(dw_h, dw_o, 3e-5, 1e-4, what="bwd_weight")
+    close(db_h, db_o, 3e-5, 1e-4, what="dbias")
+
+
+NORM = [
+    # N, C, D, H, W, groups, act
+    (1, 32, 16, 16, 16, 8, 1),
+    (2, 16, 5, 6, 7, 4, 1),      # S not multiple of 4 -> scalar path
+    (2, 8, 8, 8, 8, 0, 1),       # batch norm
+    (3, 6, 3, 3, 5, 0, 2),       # BN, leaky, ragged
+    (1, 40, 8, 8, 8, 8, 0),      # 5 channels per group, no activation
+    (1, 8, 32, 32, 32, 1, 1),    # one group of 262144 elements: multi-block partials
+]
+
+
+@pytest.mark.parametrize("case", NORM)
+def test_norm_act_fwd_bwd(hip, oracle, case):
+    N, Cc, D, H, W, groups, act = case
+    x = rnd(N, Cc, D, H, W, seed=1) * 1.7 + 0.3
+    gamma, beta = rnd(Cc, seed=2), rnd(Cc, seed=3)
+    add = rnd(N, Cc, D, H, W, seed=4)
+    running = None if groups else (rnd(Cc, seed=5) * 0.1, torch.rand(Cc) + 0.5)
+    mh, rh, rmh, rvh = hip.norm_stats(x, groups, running=running)
+    mo, ro, rmo, rvo = oracle.norm_stats(x, groups, running=running)
+    close(mh, mo, 1e-6, 1e-6, "mean")
+    close(rh, ro, 2e-6, 1e-6, "rstd")
+    if running is not None:
+        close(rmh, rmo, 1e-6, 1e-6, "running_mean")
+        close(rvh, rvo, 2e-6, 1e-6, "running_var")
+    close(hip.norm_act_fwd(x, mo, ro, gamma, beta, groups, act, add), oracle.norm_act_fwd(x, mo, ro, gamma, beta, groups, act, add),
+          what="fwd")
+    dy = rnd(N, Cc, D, H, W, seed=7)
+    for training in ((1,) if groups else (1, 0)):
+        dxh, dgh, dbh = hip.norm_act_bwd(x, dy, mo, ro, gamma, beta, groups, act, training)
+        dxo, dgo, dbo = oracle.norm_act_bwd(x, dy, mo, ro, gamma, beta, groups, act, training)
+        close(dxh, dxo, 2e-5, 2e-5, "dx")
+        close(dgh, dgo, 2e-5, 1e-4, "dgamma")
+        close(dbh, dbo, 2e-5, 1e-4, "dbeta")
+
+
+def test_pool_upsample_softmax(hip, oracle):
+    for shape in [(1, 3, 4, 6, 8), (2, 5, 2, 2, 6), (1, 2, 16, 16, 32)]:
+        x = rnd(*shape, seed=1)
+        yo = oracle.avgpool_fwd(x)
+        close(hip.avgpool_fwd(x), yo, 1e-6, 1e-6, "pool fwd")
+        dy = rnd(*yo.shape, seed=2)
+        close(hip.avgpool_bwd(dy, x.shape), oracle.avgpool_bwd(dy, x.shape), 0, 0, "pool bwd")
+    for shape in [(1, 2, 3, 4, 5), (2, 1, 1, 2, 2), (1, 3, 8, 8, 8), (1, 1, 2, 2, 2)]:
+        x = rnd(*shape, seed=3)
+        yo = oracle.upsample_fwd(x)
+        close(hip.upsample_fwd(x), yo, 2e-6, 2e-6, "up fwd")
+        dy = rnd(*yo.shape, seed=4)
+        close(hip.upsample_bwd(dy, x.shape), oracle.upsample_bwd(dy, x.shape), 1e-5, 1e-5, "up bwd")
+    for C_, inner, bias in [(3, 1, 0.0), (7, 1, 0.0), (2, 2, 5.0)]:
+        x = rnd(2, C_ * inner, 4, 5, 6, seed=5) * 3
+        yo = oracle.softmax_fwd(x, inner, bias)
+        yh = hip.softmax_fwd(x, inner, bias)
+        close(yh, yo, 2e-6, 1e-7, "softmax fwd")
+        dy = rnd(*x.shape, seed=6)
+        close(hip.softmax_bwd(yo, dy, inner), oracle.softmax_bwd(yo, dy, inner), 1e-5, 1e-6, "softmax bwd")
+
+
+@pytest.mark.parametrize("cfg", [(0.5, None, True), (0.3, [1.0, 2.0, 3.0], False), (0.5, [1.0, 100.0, 1.0], True)])
+def test_hybrid_loss_fwd_bwd(hip, oracle, cfg):
+    dw, cw, sq = cfg
+    p = torch.softmax(rnd(2, 3, 9, 10, 11, seed=1) * 2, dim=1)
+    lab = torch.randint(0, 3, (2, 9, 10, 11), generator=torch.Generator().manual_seed(2))
+    t = torch.nn.functional.one_hot(lab, 3).permute(0, 4, 1, 2, 3).float().contiguous()
+    cwt = None if cw is None else torch.tensor(cw)
+    oh, sh = hip.loss_fwd(p, t, dw, cwt, sq)
+    oo, so = oracle.loss_fwd(p, t, dw, cwt, sq)
+    close(oh, oo, 2e-6, 1e-7, "loss")
+    close(sh, so, 2e-6, 1e-6, "sums")
+    close(hip.loss_bwd(p, t, so, 0.7, dw, cwt, sq), oracle.loss_bwd(p, t, so, 0.7, dw, cwt, sq), 1e-5, 1e-9, "dp")
+
+
+def test_loss_golden(hip, golden):
+    g = golden("hybrid_loss.npz")
+    p, t = g.t("p"), g.t("t")
+    for i in range(3):
+        cfg = g[f"case{i}.cfg"]
+        dw, sq = float(cfg[0]), bool(cfg[1])
+        cw = torch.tensor(cfg[2:], dtype=torch.float32) if len(cfg) > 2 else None
+        out3, sums = hip.loss_fwd(p, t, dw, cw, sq)
+        close(out3, g.t(f"case{i}.out"), 2e-6, 1e-7)
+        close(hip.loss_bwd(p, t, sums, 1.0, dw, cw, sq), g.t(f"case{i}.dp"), 1e-5, 1e-8)
+
+
+def test_patches_roundtrip_and_confusion(hip, oracle):
+    from oracle import torch_ref as R
+    vol = rnd(2, 20, 18, 22, seed=1)
+    locs = R.grid_locations((20, 18, 22), (8, 8, 8), (2, 2, 2))
+    loc = torch.tensor(locs, dtype=torch.int32)
+    ph = hip.patch_gather(vol, loc, (8, 8, 8))
+    po = oracle.patch_gather(vol, loc, (8, 8, 8))
+    assert torch.equal(ph.cpu(), po)
+    outh, cnth = hip.patch_aggregate(ph, loc, (20, 18, 22))
+    outo, cnto = oracle.patch_aggregate(po, loc, (20, 18, 22))
+    assert torch.equal(cnth.cpu(), cnto)
+    close(outh, outo, 1e-6, 1e-6)
+    close(outh, vol, 1e-6, 1e-6)  # tiling a pointwise model reproduces the volume
+    # non-trivial patch values (aggregation order == patch order)
+    pv = rnd(*po.shape, seed=9)
+    a, _ = hip.patch_aggregate(pv, loc, (20, 18, 22))
+    b, _ = oracle.patch_aggregate(pv, loc, (20, 18, 22))
+    close(a, b, 1e-6, 1e-6)
+
+    prob = torch.softmax(rnd(2, 4, 9, 9, 9, seed=2), dim=1)
+    prob[0, 1, 0, 0, 0] = prob[0, 2, 0, 0, 0] = 0.4  # tie: first maximum wins
+    prob[0, 0, 0, 0, 0] = prob[0, 3, 0, 0, 0] = 0.1
+    tgt = torch.randint(0, 4, (2, 9, 9, 9), generator=torch.Generator().manual_seed(3))
+    amh, ch = hip.argmax_confusion(prob, tgt)
+    amo, co = oracle.argmax_confusion(prob, tgt)
+    assert torch.equal(amh.cpu(), amo) and torch.equal(ch.cpu(), co)
+    assert torch.equal(amo.long(), prob.argmax(dim=1))
+
+
+def test_error_paths_gpu(hip):
+    from segmentation_pipeline_amd import _lib
+    L = hip.lib
+    x = torch.zeros(1, 2, 3, 4, 4, device="cuda")
+    rc = L.m355_avgpool3d_2x_fwd(C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 1, 2, 3, 4, 4, 0, 0, None)
+    assert rc == _lib.M355_OK - 2
+    d = _lib.ConvDesc(1, 4, 4, 4, 4, 4, 3, 1, 1, 0, 0, 0)
+    w = torch.zeros(4, 4, 3, 3, 3, device="cuda")
+    rc = L.m355_conv3d_fwd(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), None, None,
+                           C.c_void_p(x.data_ptr()), None, 0, None)
+    assert rc == -4 and b"workspace" in L.m355_last_error()
