@@ -89,11 +89,12 @@ def test_model_matches_reference_golden(golden, name):
 def test_argmax_bit_exact_on_structured_volume(golden):
     g = golden("unet_gn_convt.npz")
     model = BUILDERS["unet_gn_convt.npz"][0]()
-    model.load_state_dict(g.state_dict("m.sd."))
+    model.load_state_dict(g.state_dict("struct.sd."))
     model = model.cuda().eval()
     with torch.no_grad():
         p = model(g.t("xs").cuda())
     assert maxerr(p, g["probs_struct"]) <= PROB_TOL
+    assert (g["struct_class_hist"] > 0).all(), "every class must win somewhere"
     assert float(g["min_top2_gap"]) > 10 * PROB_TOL, "fixture must have clear winners"
     am, counts = ops.argmax_confusion(p, g.t("argmax_struct").cuda())
     assert torch.equal(am.cpu(), g.t("argmax_struct"))

@@ -119,15 +119,27 @@ def main():
     out["x"], out["y"], out["labels"] = x.numpy(), y.numpy(), lab.numpy().astype(np.int32)
     crit = C.HybridLogisticDiceLoss()
     run_model(model, crit, x, y, "m", out)
-    # structured volume: argmax must be reproduced bit-exactly
-    xs = structured((1, 4, 16, 16, 16), 3, 7)
-    model.eval()
+    # structured volume: argmax must be reproduced bit-exactly.  An untrained net is nearly
+    # uniform, so sharpen the out conv (x25) and search the input seed for a clear minimum
+    # top-2 gap (>= 2e-3 at EVERY voxel, 20x the probability tolerance).
     with torch.no_grad():
-        ps = model(xs)
-    top2 = ps.topk(2, dim=1).values
+        model.out_conv.weight.mul_(25.0)
+    model.eval()
+    for seed in range(7, 400):
+        xs = structured((1, 4, 16, 16, 16), 3, seed)
+        with torch.no_grad():
+            ps = model(xs)
+        top2 = ps.topk(2, dim=1).values
+        gap = (top2[:, 0] - top2[:, 1]).min().item()
+        if gap >= 2e-3:
+            break
+    else:
+        raise RuntimeError("no structured volume with a clear argmax found")
+    out.update(sd_np(model, "struct.sd."))
     out["xs"], out["probs_struct"] = xs.numpy(), ps.numpy()
     out["argmax_struct"] = ps.argmax(dim=1).numpy().astype(np.int32)
-    out["min_top2_gap"] = np.float32((top2[:, 0] - top2[:, 1]).min().item())
+    out["min_top2_gap"] = np.float32(gap)
+    out["struct_class_hist"] = np.bincount(out["argmax_struct"].ravel(), minlength=3)
     # 3-step SGD trajectory (segmentation_trainer.py:162-180 order; msseg2.py:94 optimizer)
     torch.manual_seed(0)
     model = mk()
