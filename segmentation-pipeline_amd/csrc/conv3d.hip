@@ -17,6 +17,14 @@
 namespace m355 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Opaque copy: stops LICM from hoisting per-element address decode out of a loop (which
+// would keep hundreds of loop-invariant registers alive and spill).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // ---------------------------------------------------------------- weight pack
 // fwd:      wp[(c*27 + tap)*cout_pad + o]          = w[(o*Cin + c)*27 + tap]
@@ -57,8 +65,12 @@ struct FwdTile {
   static constexpr int NROWS = CC * (TZ + 2) * (TY + 2);
 };
 
+// One workgroup per CU by design (128 accumulator + prefetch registers -> 1 wave per SIMD):
+// the next chunk's input halo tile and weights are fetched into registers BEFORE the MFMA loop
+// of the current chunk and written to the other LDS buffer after it, so global-memory latency
+// hides under ~14k cycles of MFMA work; one barrier per chunk.
 template <int NTW, int GX>
-__global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
+__global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
@@ -66,8 +78,12 @@ __global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS = T::CS, CC = T::CC;
-  __shared__ float xs[CC * CS];
-  __shared__ __attribute__((aligned(16))) float ws[CC * 27 * 32];
+  constexpr int XE = CC * CS;                 // floats of one staged input chunk
+  constexpr int XPER = (XE + 255) / 256;      // per-thread elements
+  constexpr int WE4 = CC * 27 * 8;            // float4s of one staged weight chunk
+  constexpr int WPER = (WE4 + 255) / 256;
+  __shared__ float xs[2][XE];
+  __shared__ __attribute__((aligned(16))) float ws[2][CC * 27 * 32];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,6 +108,25 @@ __global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
 
   const float* xn = x + (int64_t)n * xbs;
   const int64_t HW = (int64_t)H * W;
+  const int DHW = (int)(HW * D);
+
+  // chunk-invariant gather offsets of this thread's elements (-1: zero padding, -2: past the tile)
+  int goff[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    int off = -2;
+    if (e < XE) {
+      const int c = e / CS, r = e - c * CS;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      off = (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                ? c * DHW + gz * (int)HW + gy * W + gx
+                : -1;
+    }
+    goff[i] = off;
+  }
 
   f32x16 acc[NTW];
 #pragma unroll
@@ -99,55 +134,47 @@ __global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
-  const float* xb = xs + half * CS + wave * PS + ly * RS + lx;
-  const float* wb = ws + half * (27 * 32) + l32;
+  float xr[XPER];
+  f32x4 wr[WPER];
+  auto fetch = [&](int ch) {
+    const int c0 = ch * CC;
+    const float* xc = xn + (int64_t)c0 * DHW;
+    const bool full = (c0 + CC <= Cin);
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+      bool ok = goff[i] >= 0;
+      if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
+      xr[i] = ok ? xc[goff[i]] : 0.f;
+    }
+    const float* wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
+#pragma unroll
+    for (int j = 0; j < WPER; ++j) {
+      const int idx = tid + 256 * j;
+      const int idc = idx < WE4 ? idx : WE4 - 1;  // clamp: keeps the array fully scalarised
+      wr[j] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = xr[i];
+#pragma unroll
+    for (int j = 0; j < WPER; ++j)
+      if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
+  };
+
+  if (ch_begin < ch_end) {
+    fetch(ch_begin);
+    commit(0);
+  }
+  __syncthreads();
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int c0 = ch * CC;
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage the input halo tile (zero padded) ----
-    if constexpr (RS <= 32) {
-      // two rows per wave instruction
-      const int sub = lane >> 5, col = lane & 31;
-      for (int rp = wave * 2; rp < T::NROWS; rp += 8) {
-        const int row = rp + sub;
-        const int c = row / ((TZ + 2) * (TY + 2));
-        const int rem = row - c * ((TZ + 2) * (TY + 2));
-        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + col - 1;
-        if (row < T::NROWS && col < RS) {
-          float v = 0.f;
-          if (gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
-          xs[row * RS + col] = v;
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int row = wave; row < T::NROWS; row += 4) {
-        const int c = row / ((TZ + 2) * (TY + 2));
-        const int rem = row - c * ((TZ + 2) * (TY + 2));
-        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
-        const bool rok = (gc < Cin) && gz >= 0 && gz < D && gy >= 0 && gy < H;
-        if (lane < RS) {
-          const int gx = x0 + lane - 1;
-          float v = 0.f;
-          if (rok && gx >= 0 && gx < W) v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
-          xs[row * RS + lane] = v;
-        }
-      }
-    }
-    // ---- stage the packed weights of this chunk / o-tile: CC*27 rows of 32 floats ----
-    {
-      const float* wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
-      for (int i = tid; i < CC * 27 * 8; i += 256) {
-        const int row = i >> 3, q = i & 7;
-        const float4 v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * cout_pad + q * 4);
-        *reinterpret_cast<float4*>(ws + row * 32 + q * 4) = v;
-      }
-    }
-    __syncthreads();
+    const int cur = (ch - ch_begin) & 1;
+    const bool more = ch + 1 < ch_end;
+    if (more) fetch(ch + 1);  // in flight during the MFMA loop below
+    const float* xb = xs[cur] + half * CS + wave * PS + ly * RS + lx;
+    const float* wb = ws[cur] + half * (27 * 32) + l32;
     // ---- MFMA over K = CC * 27 ----
 #pragma unroll
     for (int cp = 0; cp < CC / 2; ++cp) {
@@ -162,6 +189,8 @@ __global__ __launch_bounds__(256) void conv3_mfma_fwd_kernel(
         }
       }
     }
+    if (more) commit(cur ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -246,13 +275,16 @@ struct BwTile {
 };
 
 template <int GX>
-__global__ __launch_bounds__(256) void conv3_mfma_bww_kernel(
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
     int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
     int64_t xbs, int64_t ybs) {
   using T = BwTile<GX>;
-  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, CSW = T::CSW,
-                DSW = T::DSW;
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, HV = T::HV,
+                CSW = T::CSW, DSW = T::DSW, NV = T::NV;
+  constexpr int XE = 32 * HV;
+  constexpr int XPER = (XE + 255) / 256;
+  static_assert(NV == 256, "one dy voxel per thread");
   __shared__ float xs[32 * CSW];
   __shared__ float ds[32 * DSW];
 
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_kernel(
   const int ctile = blockIdx.x, otile = blockIdx.y, split = blockIdx.z;
   const int c0 = ctile * 32, o0 = otile * 32;
   const int64_t HW = (int64_t)H * W;
+  const int64_t DHW = HW * D;
 
   int toff[7];
 #pragma unroll
@@ -282,7 +315,14 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_kernel(
 
   const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
   const int ntiles = N * tiles_per_n;
-  for (int tile = split; tile < ntiles; tile += nsplit) {
+  // this thread's dy voxel inside a tile
+  const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
+
+  // The next tile is fetched into registers while the MFMAs of the current one run
+  // (1 workgroup per CU: nothing else would hide the global-memory latency).
+  float xr[XPER];
+  float dr[32];
+  auto fetch = [&](int tile) {
     int t = tile;
     const int n = t / tiles_per_n;
     t -= n * tiles_per_n;
@@ -293,68 +333,69 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_kernel(
     const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
     const float* xn = x + (int64_t)n * xbs;
     const float* dn = dy + (int64_t)n * ybs;
-
-    __syncthreads();
-    // stage x halo tile [32 c][TZ+2][TY+2][TX+2]
-    if constexpr (RS <= 32) {
-      const int sub = lane >> 5, col = lane & 31;
-      for (int rp = wave * 2; rp < T::XROWS; rp += 8) {
-        const int row = rp + sub;
-        const int c = row / ((TZ + 2) * (TY + 2));
-        const int rem = row - c * ((TZ + 2) * (TY + 2));
-        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + col - 1;
-        if (row < T::XROWS && col < RS) {
-          float v = 0.f;
-          if (gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
-          xs[c * CSW + zz * PS + yy * RS + col] = v;
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int row = wave; row < T::XROWS; row += 4) {
-        const int c = row / ((TZ + 2) * (TY + 2));
-        const int rem = row - c * ((TZ + 2) * (TY + 2));
-        const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
-        const bool rok = (gc < Cin) && gz >= 0 && gz < D && gy >= 0 && gy < H;
-        if (lane < RS) {
-          const int gx = x0 + lane - 1;
-          float v = 0.f;
-          if (rok && gx >= 0 && gx < W) v = xn[((int64_t)gc * D + gz) * HW + (int64_t)gy * W + gx];
-          xs[c * CSW + zz * PS + yy * RS + lane] = v;
-        }
+    {
+      // e = tid + 256*i walks the [32 c][halo] tile; (c, r) advance incrementally
+      int r = opaque(tid), c = 0;
+      while (r >= HV) { r -= HV; ++c; }
+#pragma unroll
+      for (int i = 0; i < XPER; ++i) {
+        const int zz = r / PS, r2 = r - zz * PS;
+        const int yy = r2 / RS, xx = r2 - yy * RS;
+        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1, gc = c0 + c;
+        const bool ok = c < 32 && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xr[i] = ok ? xn[(int64_t)gc * DHW + (int64_t)gz * HW + gy * W + gx] : 0.f;
+        r += 256;
+        if (r >= HV) { r -= HV; ++c; }
       }
     }
-    // stage dy tile [32 o][TZ*TY*TX]
-    for (int i = tid; i < 32 * T::NV; i += 256) {
-      const int o = i / T::NV;
-      const int v = i - o * T::NV;
-      const int vz = v / (TY * TX), vy = (v / TX) % TY, vx = v % TX;
-      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx, go = o0 + o;
-      float val = 0.f;
-      if (go < Cout && gz < D && gy < H && gx < W)
-        val = dn[((int64_t)go * D + gz) * HW + (int64_t)gy * W + gx];
-      ds[o * DSW + v] = val;
+    const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+    const bool vok = gz < D && gy < H && gx < W;
+    const int64_t sp = (int64_t)gz * HW + (int64_t)gy * W + gx;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dr[j] = (vok && o0 + j < Cout) ? dn[(int64_t)(o0 + j) * DHW + sp] : 0.f;
+  };
+  auto commit = [&]() {
+    {
+      int r = opaque(tid), c = 0;
+      while (r >= HV) { r -= HV; ++c; }
+#pragma unroll
+      for (int i = 0; i < XPER; ++i) {
+        if (c < 32) xs[c * CSW + r] = xr[i];
+        r += 256;
+        if (r >= HV) { r -= HV; ++c; }
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = dr[j];
+  };
 
-    for (int vz = 0; vz < TZ; ++vz) {
-      for (int vy = 0; vy < TY; ++vy) {
-        const float* xr = xb + vz * PS + vy * RS;
-        const float* dr = db + (vz * TY + vy) * TX;
+  if (split < ntiles) {
+    fetch(split);
+    commit();
+  }
+  __syncthreads();
+
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    if (more) fetch(tile + nsplit);
+    for (int z = 0; z < TZ; ++z) {
+      for (int yy = 0; yy < TY; ++yy) {
+        const float* xr_ = xb + z * PS + yy * RS;
+        const float* dr_ = db + (z * TY + yy) * TX;
 #pragma unroll
         for (int xp = 0; xp < TX / 2; ++xp) {
-          const float a = dr[2 * xp];
+          const float a = dr_[2 * xp];
 #pragma unroll
           for (int t = 0; t < 7; ++t) {
-            const float b = xr[2 * xp + toff[t]];
+            const float b = xr_[2 * xp + toff[t]];
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
           }
         }
       }
     }
+    __syncthreads();  // every wave is done reading this tile
+    if (more) commit();
+    __syncthreads();
   }
 
   // partial dW -> slab[split][Cout][Cin][27]
@@ -383,25 +424,32 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
-// dbias[o] = sum_{n,s} dy[n,o,s]; one block per o, double accumulation.
-__global__ __launch_bounds__(256) void dbias_kernel(const float* __restrict__ dy,
-                                                    float* __restrict__ dbias, int N, int Cout,
-                                                    int64_t S, int64_t ybs) {
+// dbias[o] = sum_{n,s} dy[n,o,s]: grid (chunks, Cout) of partial sums, then a fixed-order
+// finalize (deterministic).  Short fp32 runs per thread, double across threads / blocks.
+constexpr int DBIAS_CHUNK = 32768;
+__global__ __launch_bounds__(256) void dbias_partial_kernel(const float* __restrict__ dy,
+                                                            double* __restrict__ partial, int N,
+                                                            int64_t S, int64_t ybs, int nblk) {
   __shared__ double scratch[4];
-  const int o = blockIdx.x;
+  const int b = blockIdx.x, o = blockIdx.y;
+  const int64_t begin = (int64_t)b * DBIAS_CHUNK, end = min(S, begin + DBIAS_CHUNK);
   double acc = 0.0;
   for (int n = 0; n < N; ++n) {
     const float* p = dy + (int64_t)n * ybs + (int64_t)o * S;
     float part = 0.f;
-    int cnt = 0;
-    for (int64_t s = threadIdx.x; s < S; s += 256) {
-      part += p[s];
-      if (++cnt == 64) { acc += part; part = 0.f; cnt = 0; }
-    }
+    for (int64_t s = begin + threadIdx.x; s < end; s += 256) part += p[s];
     acc += part;
   }
   const double tot = block_sum<double, 256>(acc, scratch);
-  if (threadIdx.x == 0) dbias[o] = (float)tot;
+  if (threadIdx.x == 0) partial[(int64_t)o * nblk + b] = tot;
+}
+__global__ void dbias_finalize_kernel(const double* __restrict__ partial, float* __restrict__ dbias,
+                                      int Cout, int nblk) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= Cout) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblk; ++b) acc += partial[(int64_t)o * nblk + b];
+  dbias[o] = (float)acc;
 }
 
 // ------------------------------------------------------ generic direct kernels
@@ -767,9 +815,28 @@ extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, 
   return check_launch("conv3d_direct_bwd_data");
 }
 
+static size_t dbias_ws_bytes(int Cout, int64_t S) {
+  return (size_t)round_up((int64_t)Cout * ceil_div(S, DBIAS_CHUNK) * 8, 256);
+}
+
+// dbias through the shared two-stage reduction; `ws` must hold dbias_ws_bytes()
+int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int64_t ybs, void* ws,
+                 hipStream_t st) {
+  const int nblk = (int)ceil_div(S, DBIAS_CHUNK);
+  hipLaunchKernelGGL(dbias_partial_kernel, dim3((unsigned)nblk, (unsigned)Cout), dim3(256), 0, st, dy,
+                     (double*)ws, N, S, ybs, nblk);
+  hipLaunchKernelGGL(dbias_finalize_kernel, dim3((unsigned)ceil_div(Cout, 64)), dim3(64), 0, st,
+                     (const double*)ws, dbias, Cout, nblk);
+  return M355_OK;
+}
+
 extern "C" size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d) {
-  if (!d || !is_k3s1p1(d)) return 0;
-  return plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes;
+  if (!d) return 0;
+  const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
+            OW = out_dim(d->W, d->k, d->stride, d->pad);
+  const size_t db = dbias_ws_bytes(d->Cout, (int64_t)OD * OH * OW);
+  if (!is_k3s1p1(d)) return db;
+  return plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes + db;
 }
 
 extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
@@ -814,8 +881,11 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
                        d->stride, d->pad, xbs, ybs);
   }
   if (dbias) {
-    hipLaunchKernelGGL(dbias_kernel, dim3((unsigned)d->Cout), dim3(256), 0, st, dy, dbias, d->N,
-                       d->Cout, (int64_t)OD * OH * OW, ybs);
+    const int64_t OS = (int64_t)OD * OH * OW;
+    const size_t slab_b = is_k3s1p1(d) ? plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes : 0;
+    M355_REQUIRE(workspace && workspace_bytes >= slab_b + dbias_ws_bytes(d->Cout, OS), M355_EWORKSPACE,
+                 "conv3d_bwd_weight: workspace too small for the bias gradient");
+    launch_dbias(dy, dbias, d->N, d->Cout, OS, ybs, (char*)workspace + slab_b, st);
   }
   return check_launch("conv3d_bwd_weight");
 }

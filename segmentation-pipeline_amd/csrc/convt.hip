@@ -200,26 +200,6 @@ __global__ void convt_slab_reduce_kernel(const float* __restrict__ slab, float* 
   }
 }
 
-__global__ __launch_bounds__(256) void convt_dbias_kernel(const float* __restrict__ dy,
-                                                          float* __restrict__ dbias, int N,
-                                                          int64_t OS, int64_t ybs) {
-  __shared__ double scratch[4];
-  const int o = blockIdx.x;
-  double acc = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const float* p = dy + (int64_t)n * ybs + (int64_t)o * OS;
-    float part = 0.f;
-    int cnt = 0;
-    for (int64_t s = threadIdx.x; s < OS; s += 256) {
-      part += p[s];
-      if (++cnt == 64) { acc += part; part = 0.f; cnt = 0; }
-    }
-    acc += part;
-  }
-  const double tot = block_sum<double, 256>(acc, scratch);
-  if (threadIdx.x == 0) dbias[o] = (float)tot;
-}
-
 // ----------------------------------------------------- generic direct kernels
 // y[n,o,oz,oy,ox] = bias[o] + sum_{c, taps: (o + pad - d) % stride == 0} x[n,c,(o+pad-d)/stride] * w[c,o,d]
 __global__ void convt_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -377,9 +357,20 @@ static int validate_convt(const m355_conv3d_desc* d, const char* who) {
 
 using namespace m355;
 
+// shared with conv3d.hip
+int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int64_t ybs, void* ws,
+                 hipStream_t st);
+static size_t convt_slab_bytes(const m355_conv3d_desc* d) {
+  return is_k2s2(d) ? (size_t)round_up((int64_t)convt_nsplit(d) * d->Cin * d->Cout * 8 * 4, 256) : 0;
+}
+static size_t convt_dbias_bytes(const m355_conv3d_desc* d) {
+  const int64_t OS = (int64_t)convt_out(d->D, d) * convt_out(d->H, d) * convt_out(d->W, d);
+  return (size_t)round_up((int64_t)d->Cout * ceil_div(OS, 32768) * 8, 256);
+}
+
 extern "C" size_t m355_conv_transpose3d_workspace(const m355_conv3d_desc* d) {
-  if (!d || !is_k2s2(d)) return 0;
-  return (size_t)round_up((int64_t)convt_nsplit(d) * d->Cin * d->Cout * 8 * 4, 256);
+  if (!d) return 0;
+  return convt_slab_bytes(d) + convt_dbias_bytes(d);
 }
 
 extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
@@ -443,7 +434,7 @@ extern "C" int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0) {
     const int nsplit = convt_nsplit(d);
-    const size_t need = m355_conv_transpose3d_workspace(d);
+    const size_t need = convt_slab_bytes(d);
     M355_REQUIRE(workspace && workspace_bytes >= need, M355_EWORKSPACE,
                  "conv_transpose3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                  need);
@@ -462,8 +453,10 @@ extern "C" int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const
                        dw, d->N, d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k, d->stride,
                        d->pad, xbs, ybs);
   }
-  if (dbias)
-    hipLaunchKernelGGL(convt_dbias_kernel, dim3((unsigned)d->Cout), dim3(256), 0, st, dy, dbias, d->N,
-                       (int64_t)OD * OH * OW, ybs);
+  if (dbias) {
+    M355_REQUIRE(workspace && workspace_bytes >= convt_slab_bytes(d) + convt_dbias_bytes(d), M355_EWORKSPACE,
+                 "conv_transpose3d_bwd_weight: workspace too small for the bias gradient");
+    launch_dbias(dy, dbias, d->N, d->Cout, (int64_t)OD * OH * OW, ybs, (char*)workspace + convt_slab_bytes(d), st);
+  }
   return check_launch("conv_transpose3d_bwd_weight");
 }
