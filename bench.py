@@ -65,7 +65,8 @@ def cpu_baseline(cfg, batch):
     x = torch.randn((batch, cin) + patch, generator=g)
     lab = torch.randint(0, cout, (batch,) + patch, generator=g)
     y = torch.nn.functional.one_hot(lab, cout).permute(0, 4, 1, 2, 3).float().contiguous()
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host cores (os.cpu_count() reports the whole host)
+    cores = min(os.cpu_count() or 1, int(os.environ.get("M355_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.95)
@@ -215,7 +216,7 @@ def main():
                        "parallelism": f"patch-parallel dp{world}" if world > 1 else "single GPU",
                        "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95)"},
             "infer": infer, "phases_ms": phases, "conv_kernels": conv_summary, "roofline": roofline,
-            "final_loss": float(loss_dict["loss"]),
+            "final_loss": float(loss_dict["loss"].detach()),
             "dice": {"gpu_soft_dice_loss_step0": gpu_dice0, "gpu_hard_dice_step0": hard0},
         }
         if not args.no_cpu_baseline and world == 1:

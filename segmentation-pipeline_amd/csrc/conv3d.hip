@@ -134,6 +134,10 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
+  // Loads are UNCONDITIONAL (the select is on the address, clamped to element 0 of the chunk,
+  // never on the value): a `cond ? load : 0` makes hipcc branch around each load and wait
+  // vmcnt(0) at every join, which serialises the prefetch.  Zero padding is applied when the
+  // registers are committed to LDS, after the MFMA loop.
   float xr[XPER];
   f32x4 wr[WPER];
   auto fetch = [&](int ch) {
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     for (int i = 0; i < XPER; ++i) {
       bool ok = goff[i] >= 0;
       if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
-      xr[i] = ok ? xc[goff[i]] : 0.f;
+      xr[i] = xc[ok ? goff[i] : 0];
     }
     const float* wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
 #pragma unroll
@@ -154,10 +158,15 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
       wr[j] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int ch) {
+    const int c0 = ch * CC;
+    const bool full = (c0 + CC <= Cin);
 #pragma unroll
-    for (int i = 0; i < XPER; ++i)
-      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = xr[i];
+    for (int i = 0; i < XPER; ++i) {
+      bool ok = goff[i] >= 0;
+      if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
+      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = ok ? xr[i] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < WPER; ++j)
       if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 
   if (ch_begin < ch_end) {
     fetch(ch_begin);
-    commit(0);
+    commit(0, ch_begin);
   }
   __syncthreads();
 
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
         }
       }
     }
-    if (more) commit(cur ^ 1);
+    if (more) commit(cur ^ 1, ch + 1);
     __syncthreads();
   }
 
@@ -274,16 +283,14 @@ struct BwTile {
   static constexpr int XROWS = 32 * (TZ + 2) * (TY + 2);
 };
 
-template <int GX>
+template <int GX, bool VEC>
 __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
     int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
     int64_t xbs, int64_t ybs) {
   using T = BwTile<GX>;
-  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, HV = T::HV,
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS,
                 CSW = T::CSW, DSW = T::DSW, NV = T::NV;
-  constexpr int XE = 32 * HV;
-  constexpr int XPER = (XE + 255) / 256;
   static_assert(NV == 256, "one dy voxel per thread");
   __shared__ float xs[32 * CSW];
   __shared__ float ds[32 * DSW];
@@ -319,9 +326,23 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
   const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
 
   // The next tile is fetched into registers while the MFMAs of the current one run
-  // (1 workgroup per CU: nothing else would hide the global-memory latency).
-  float xr[XPER];
+  // (1 workgroup per CU: nothing else would hide the global-memory latency).  The halo
+  // tile is fetched as aligned float4 interior rows + two scalar halo columns, with 32-bit
+  // offsets from a uniform base, to keep the address arithmetic per tile small.
+  constexpr int RPC = (TZ + 2) * (TY + 2);   // rows per channel
+  constexpr int ROWS = 32 * RPC;
+  constexpr int Q = TX / 4;                  // float4 per interior row
+  constexpr int NI = ROWS * Q;
+  constexpr int IPER = (NI + 255) / 256;
+  constexpr int NH = ROWS * 2;
+  constexpr int HPER = (NH + 255) / 256;
+  f32x4 xi[IPER];
+  float xh[HPER];
   float dr[32];
+  // validity bits of the prefetched registers (zero padding is applied at commit time; the
+  // loads themselves are unconditional from clamped addresses -- see the forward kernel)
+  unsigned mi[4], mh, md;
+  const int iDHW = (int)DHW, iHW = (int)HW;
   auto fetch = [&](int tile) {
     int t = tile;
     const int n = t / tiles_per_n;
@@ -333,40 +354,78 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
     const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
     const float* xn = x + (int64_t)n * xbs;
     const float* dn = dy + (int64_t)n * ybs;
-    {
-      // e = tid + 256*i walks the [32 c][halo] tile; (c, r) advance incrementally
-      int r = opaque(tid), c = 0;
-      while (r >= HV) { r -= HV; ++c; }
+    const int tq = opaque(tid);
+    mi[0] = mi[1] = mi[2] = mi[3] = 0u;
+    mh = 0u;
 #pragma unroll
-      for (int i = 0; i < XPER; ++i) {
-        const int zz = r / PS, r2 = r - zz * PS;
-        const int yy = r2 / RS, xx = r2 - yy * RS;
-        const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1, gc = c0 + c;
-        const bool ok = c < 32 && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xr[i] = ok ? xn[(int64_t)gc * DHW + (int64_t)gz * HW + gy * W + gx] : 0.f;
-        r += 256;
-        if (r >= HV) { r -= HV; ++c; }
+    for (int k = 0; k < IPER; ++k) {
+      const int m = tq + 256 * k;
+      const int q = m % Q, row = m / Q;
+      const int c = row / RPC, rem = row - c * RPC;
+      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + 4 * q;
+      const bool rok = m < NI && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
+      const int off = gc * iDHW + gz * iHW + gy * W + gx;
+      if constexpr (VEC) {
+        const bool ok = rok && gx < W;
+        xi[k] = *reinterpret_cast<const f32x4*>(xn + (ok ? off : 0));
+        const unsigned bit = ok ? (1u << k) : 0u;
+        mi[0] |= bit; mi[1] |= bit; mi[2] |= bit; mi[3] |= bit;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rok && gx + e < W;
+          xi[k][e] = xn[ok ? off + e : 0];
+          mi[e] |= ok ? (1u << k) : 0u;
+        }
       }
+    }
+#pragma unroll
+    for (int j = 0; j < HPER; ++j) {
+      const int h = tq + 256 * j;
+      const int side = h & 1, row = h >> 1;
+      const int c = row / RPC, rem = row - c * RPC;
+      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = side ? x0 + TX : x0 - 1;
+      const bool ok = h < NH && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xh[j] = xn[ok ? gc * iDHW + gz * iHW + gy * W + gx : 0];
+      mh |= ok ? (1u << j) : 0u;
     }
     const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
     const bool vok = gz < D && gy < H && gx < W;
-    const int64_t sp = (int64_t)gz * HW + (int64_t)gy * W + gx;
+    const int sp = vok ? gz * iHW + gy * W + gx : 0;
+    md = 0u;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) dr[j] = (vok && o0 + j < Cout) ? dn[(int64_t)(o0 + j) * DHW + sp] : 0.f;
+    for (int j = 0; j < 32; ++j) {
+      const bool ok = vok && o0 + j < Cout;
+      dr[j] = dn[ok ? (o0 + j) * iDHW + sp : 0];
+      md |= ok ? (1u << j) : 0u;
+    }
   };
   auto commit = [&]() {
-    {
-      int r = opaque(tid), c = 0;
-      while (r >= HV) { r -= HV; ++c; }
+    const int tq = opaque(tid);
 #pragma unroll
-      for (int i = 0; i < XPER; ++i) {
-        if (c < 32) xs[c * CSW + r] = xr[i];
-        r += 256;
-        if (r >= HV) { r -= HV; ++c; }
+    for (int k = 0; k < IPER; ++k) {
+      const int m = tq + 256 * k;
+      const int q = m % Q, row = m / Q;
+      const int c = row / RPC, rem = row - c * RPC;
+      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+      if (m < NI) {
+        float* p = xs + c * CSW + zz * PS + yy * RS + 1 + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = ((mi[e] >> k) & 1u) ? xi[k][e] : 0.f;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = dr[j];
+    for (int j = 0; j < HPER; ++j) {
+      const int h = tq + 256 * j;
+      const int side = h & 1, row = h >> 1;
+      const int c = row / RPC, rem = row - c * RPC;
+      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+      if (h < NH) xs[c * CSW + zz * PS + yy * RS + (side ? TX + 1 : 0)] = ((mh >> j) & 1u) ? xh[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = ((md >> j) & 1u) ? dr[j] : 0.f;
   };
 
   if (split < ntiles) {
@@ -856,18 +915,28 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
                  p.slab_bytes);
     float* slab = (float*)workspace;
     dim3 grid((unsigned)p.ctiles, (unsigned)p.otiles, (unsigned)p.nsplit);
+    // float4 interior rows need 16-byte aligned rows; per-sample extents must fit int32 offsets
+    const bool vec = (d->W % 4 == 0) && (xbs % 4 == 0) && (((uintptr_t)x) & 15) == 0;
+#define M355_BWW_LAUNCH(GXV)                                                                      \
+  {                                                                                               \
+    if (vec)                                                                                      \
+      hipLaunchKernelGGL((conv3_mfma_bww_kernel<GXV, true>), grid, dim3(256), 0, st, x, dy, slab, \
+                         d->N, d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles,       \
+                         p.tx_tiles, p.nsplit, xbs, ybs);                                        \
+    else                                                                                          \
+      hipLaunchKernelGGL((conv3_mfma_bww_kernel<GXV, false>), grid, dim3(256), 0, st, x, dy,      \
+                         slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, \
+                         p.tx_tiles, p.nsplit, xbs, ybs);                                        \
+  }
+    M355_REQUIRE((int64_t)d->Cin * d->D * d->H * d->W < (1ll << 31) &&
+                     (int64_t)d->Cout * d->D * d->H * d->W < (1ll << 31),
+                 M355_EUNSUPPORTED, "conv3d_bwd_weight: tensor exceeds 2^31 elements per sample");
     if (p.gx == 32)
-      hipLaunchKernelGGL((conv3_mfma_bww_kernel<32>), grid, dim3(256), 0, st, x, dy, slab, d->N,
-                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                         p.nsplit, xbs, ybs);
+      M355_BWW_LAUNCH(32)
     else if (p.gx == 16)
-      hipLaunchKernelGGL((conv3_mfma_bww_kernel<16>), grid, dim3(256), 0, st, x, dy, slab, d->N,
-                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                         p.nsplit, xbs, ybs);
+      M355_BWW_LAUNCH(16)
     else
-      hipLaunchKernelGGL((conv3_mfma_bww_kernel<8>), grid, dim3(256), 0, st, x, dy, slab, d->N,
-                         d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                         p.nsplit, xbs, ybs);
+      M355_BWW_LAUNCH(8)
     const int64_t total = (int64_t)d->Cout * d->Cin * 27;
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, total,
