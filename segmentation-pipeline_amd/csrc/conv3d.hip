@@ -473,6 +473,105 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
   }
 }
 
+// ------------------------------------------- bwd-weight, tiny channel count on one side
+// dW[o,c,tap] when Cin <= 4 (first conv) or Cout <= 4 (out conv).  The generic kernel would
+// pad the narrow side to 32 MFMA rows/cols (8-10x waste).  Here the narrow channel AND the
+// tap share the lane index: j = (s = l32>>3, t8 = l32&7), tap = wave*8 + t8 (27 of 32 used),
+// so ONE MFMA per k-step per wave covers all taps:
+//    G[i, (s,tap)] = sum_v P[i, v] * Q[s, v + off(tap)]
+//  swap=0 (Cin small):  P = dy (wide = Cout), Q = x,  dW[o=i][c=s][tap]
+//  swap=1 (Cout small): P = x (wide = Cin),  Q = dy read at v - off(tap) = v + off(26-tap),
+//                       dW[o=s][c=i][tap]
+// 16 accumulators -> several workgroups per CU hide the (synchronous) staging.
+template <int GX>
+__global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ slab, int N,
+    int CP, int CQ, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
+    int64_t pbs, int64_t qbs, int swap, int Cin, int Cout) {
+  using T = BwTile<GX>;
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, HV = T::HV,
+                DSW = T::DSW, NV = T::NV;
+  constexpr int QS = HV + 1;
+  __shared__ float ps[32 * DSW];
+  __shared__ float qs[4 * QS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int p0 = blockIdx.x * 32, split = blockIdx.y;
+  const int iHW = H * W, iDHW = D * H * W;
+
+  const int s_l = l32 >> 3, t8 = l32 & 7;
+  const int tap_raw = wave * 8 + t8;
+  const int tap_eff = min(swap ? 26 - tap_raw : tap_raw, 26);
+  const int toff = (max(tap_eff, 0) / 9) * PS + ((max(tap_eff, 0) / 3) % 3) * RS + (max(tap_eff, 0) % 3);
+  const float* qb = qs + s_l * QS + toff + half;
+  const float* pb = ps + l32 * DSW + half;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles;
+    const int tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    const float* Pn = P + (int64_t)n * pbs;
+    const float* Qn = Q + (int64_t)n * qbs;
+    __syncthreads();
+    {  // wide tile: 32 channels x 256 voxels, one voxel per thread
+      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+      const bool vok = gz < D && gy < H && gx < W;
+      const int sp = vok ? gz * iHW + gy * W + gx : 0;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        const bool ok = vok && p0 + j < CP;
+        const float v = Pn[ok ? (p0 + j) * iDHW + sp : 0];
+        ps[j * DSW + tid] = ok ? v : 0.f;
+      }
+    }
+    // narrow halo tile: 4 channels x (TZ+2)(TY+2)(TX+2)
+    for (int e = tid; e < 4 * HV; e += 256) {
+      const int c = e / HV, r = e - c * HV;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      const bool ok = c < CQ && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float v = Qn[ok ? c * iDHW + gz * iHW + gy * W + gx : 0];
+      qs[c * QS + r] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    for (int z = 0; z < TZ; ++z)
+      for (int yy = 0; yy < TY; ++yy) {
+        const float* pr = pb + (z * TY + yy) * TX;
+        const float* qr = qb + z * PS + yy * RS;
+#pragma unroll
+        for (int xp = 0; xp < TX / 2; ++xp)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2 * xp], qr[2 * xp], acc, 0, 0, 0);
+      }
+  }
+  float* sl = slab + (int64_t)split * Cout * Cin * 27;
+  if (tap_raw < 27 && s_l < CQ) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = p0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < CP) {
+        const int o = swap ? s_l : i, c = swap ? i : s_l;
+        sl[((int64_t)o * Cin + c) * 27 + tap_raw] = acc[r];
+      }
+    }
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                    int64_t total, int nsplit) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -707,6 +806,10 @@ static bool is_k3s1p1(const m355_conv3d_desc* d) {
 
 static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
+static bool small_bww(const m355_conv3d_desc* d) {
+  return (d->Cin <= 4 || d->Cout <= 4) && !env_int("M355_NO_SMALL", 0);
+}
+
 template <int NTW, int GX>
 static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
@@ -786,6 +889,8 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
   const int64_t ntiles = (int64_t)N * p.tz_tiles * p.ty_tiles * p.tx_tiles;
   const int64_t pairs = (int64_t)p.otiles * p.ctiles;
   int64_t nsplit = std::max<int64_t>(1, 256 / pairs);
+  if (Cin <= 4 || Cout <= 4)  // tap-on-lane kernel: small LDS footprint, ~3 workgroups per CU
+    nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
   nsplit = std::min<int64_t>(nsplit, ntiles);
   p.nsplit = (int)nsplit;
   p.slab_bytes = (size_t)round_up((int64_t)p.nsplit * Cout * Cin * 27 * 4, 256);
@@ -914,6 +1019,26 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
                  "conv3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                  p.slab_bytes);
     float* slab = (float*)workspace;
+    M355_REQUIRE((int64_t)d->Cin * d->D * d->H * d->W < (1ll << 31) &&
+                     (int64_t)d->Cout * d->D * d->H * d->W < (1ll << 31),
+                 M355_EUNSUPPORTED, "conv3d_bwd_weight: tensor exceeds 2^31 elements per sample");
+    if (small_bww(d)) {
+      // narrow side (<= 4 channels) shares the lane index with the taps
+      const int swap = d->Cin <= 4 ? 0 : 1;
+      const float* P = swap ? x : dy;
+      const float* Q = swap ? dy : x;
+      const int CP = swap ? d->Cin : d->Cout, CQ = swap ? d->Cout : d->Cin;
+      const int64_t pbs = swap ? xbs : ybs, qbs = swap ? ybs : xbs;
+      dim3 g2((unsigned)ceil_div(CP, 32), (unsigned)p.nsplit);
+#define M355_BWS_LAUNCH(GXV)                                                                       \
+  hipLaunchKernelGGL((conv3_mfma_bww_small_kernel<GXV>), g2, dim3(256), 0, st, P, Q, slab, d->N, CP, \
+                     CQ, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.nsplit, pbs, qbs,  \
+                     swap, d->Cin, d->Cout);
+      if (p.gx == 32) { M355_BWS_LAUNCH(32) } else if (p.gx == 16) { M355_BWS_LAUNCH(16) } else { M355_BWS_LAUNCH(8) }
+      const int64_t total = (int64_t)d->Cout * d->Cin * 27;
+      const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, total, p.nsplit);
+    } else {
     dim3 grid((unsigned)p.ctiles, (unsigned)p.otiles, (unsigned)p.nsplit);
     // float4 interior rows need 16-byte aligned rows; per-sample extents must fit int32 offsets
     const bool vec = (d->W % 4 == 0) && (xbs % 4 == 0) && (((uintptr_t)x) & 15) == 0;
@@ -941,6 +1066,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, total,
                        p.nsplit);
+    }
   } else {
     const int k3 = d->k * d->k * d->k;
     const int64_t nblk = (int64_t)d->Cout * d->Cin * k3;

@@ -7,186 +7,278 @@
 //
 // k=2,s=2,p=0 is a non-overlapping scatter: every input voxel produces its own
 // 2x2x2 output block, i.e. a [8*Cout x Cin] x [Cin x voxels] GEMM with AI ~ 28
-// flop/B in fp32 -> HBM-bound.  The fast path keeps one
-// input voxel per lane (coalesced x reads, float2-coalesced y writes) and reads
-// the weights through the scalar cache (block-uniform addresses).
+// flop/B in fp32 -> HBM-bound.  The three k2s2 ops run as
+// fp32-MFMA GEMMs with the voxel on the lane (coalesced x reads, float2-coalesced
+// y / dy accesses); any other geometry takes the generic direct kernels below.
 #include "common.hpp"
 
 namespace m355 {
 
-constexpr int CT_OT = 4;  // output channels per thread in the k2s2 forward (32 accumulators)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// grid: (voxel blocks, Cout/CT_OT, N).  w: [Cin, Cout, 2,2,2]
-__global__ __launch_bounds__(256) void convt_k2s2_fwd_kernel(
+// =============================== k2s2 as fp32-MFMA GEMMs ===============================
+// Every input voxel owns its 2x2x2 output block, so with t = a*4 + b*2 + c (the position
+// inside the block) and m = o*8 + t:
+//   fwd        Y[m, v]  = bias[o] + sum_ci W[ci, m] * X[ci, v]          M = 8*Cout, K = Cin
+//   bwd-data   dX[ci,v] =           sum_m  W[ci, m] * dYr[m, v]         M = Cin,    K = 8*Cout
+//   bwd-weight dW[ci,m] =           sum_v  X[ci, v] * dYr[m, v]         M = Cin, N = 8*Cout, K = voxels
+// where dYr[m, v] = dY[o, 2z+a, 2y+b, 2x+c] is the output block gathered per input voxel and
+// the torch weight layout [Cin][Cout][2][2][2] is already W[ci][m] with m contiguous.
+// All three are HBM-bound (AI ~ 28 flop/B); the MFMA only has to keep up with the stream.
+// Small accumulator footprints -> several workgroups per CU hide the synchronous staging.
+
+// ---- forward: workgroup = 256 consecutive input voxels (wave w: 2 groups of 32), loops over
+// the 32-row m-tiles (4 output channels each).  The x tile [KC ci][256] is staged once when
+// Cin <= KC.  C/D layout puts t = (r&3) + 4*half on the lane's registers, so (r, r+1) is the
+// (c=0, c=1) pair of one (o, a, b): float2 stores, 256 B contiguous per 32 lanes.
+constexpr int CTF_KC = 64;
+constexpr int CTF_MTG = 4;  // m-tiles (of 4 output channels) per workgroup
+__global__ __launch_bounds__(256) void convt_k2s2_fwd_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs) {
-  const int64_t S = (int64_t)D * H * W;
-  const int64_t v = blockIdx.x * 256ll + threadIdx.x;
-  const int o0 = blockIdx.y * CT_OT;
+  constexpr int NVT = 256, KC = CTF_KC;
+  __shared__ float xs[KC * NVT];
+  __shared__ float ws[KC * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int v0 = blockIdx.x * NVT;
   const int n = blockIdx.z;
-  const bool active = v < S;
-  const float* xp = x + (int64_t)n * xbs + (active ? v : 0);
-  float acc[CT_OT][8];
+  const float* xn = x + (int64_t)n * xbs;
+  float* yn = y + (int64_t)n * ybs;
+  const int nchunks = (Cin + KC - 1) / KC;
+  const int mtiles = (Cout + 3) / 4;
+  // blockIdx.y owns CTF_MTG consecutive m-tiles (16 output channels): more workgroups in flight,
+  // and concurrent workgroups write different output planes
+  const int mt_begin = blockIdx.y * CTF_MTG, mt_end = min(mtiles, mt_begin + CTF_MTG);
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t OS = (int64_t)S * 8;
+
+  // output coordinates of this lane's two voxels
+  int64_t obase[2];
+  bool vok[2];
 #pragma unroll
-  for (int j = 0; j < CT_OT; ++j) {
-    const float b = (bias && o0 + j < Cout) ? bias[o0 + j] : 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[j][t] = b;
+  for (int g = 0; g < 2; ++g) {
+    const int v = v0 + (wave * 2 + g) * 32 + l32;
+    vok[g] = v < S;
+    const int vv = vok[g] ? v : 0;
+    const int ix = vv % W, iy = (vv / W) % H, iz = vv / (W * H);
+    obase[g] = ((int64_t)(2 * iz + half) * OH + 2 * iy) * OW + 2 * ix;  // a = half
   }
-  const int no = min(CT_OT, Cout - o0);
-  for (int c = 0; c < Cin; ++c) {
-    const float xv = active ? xp[(int64_t)c * S] : 0.f;
-    const float* wc = w + ((int64_t)c * Cout + o0) * 8;  // block-uniform -> scalar loads
+
+  for (int mt = mt_begin; mt < mt_end; ++mt) {
+    const int o0 = mt * 4;
+    f32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < CT_OT; ++j) {
-      if (j < no) {
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[j][t] = fmaf(xv, wc[j * 8 + t], acc[j][t]);
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * KC;
+      const int kc = min(KC, Cin - c0);
+      __syncthreads();
+      if (nchunks > 1 || mt == mt_begin) {
+        const int v = v0 + tid;
+        const bool vin = v < S;
+        const float* xp = xn + (int64_t)c0 * S + (vin ? v : 0);
+        // unconditional loads (clamped), all KC rows written (rows >= kc are zero)
+#pragma unroll 16
+        for (int c = 0; c < KC; ++c) {
+          const bool ok = vin && c < kc;
+          const float val = xp[ok ? (int64_t)c * S : 0];
+          xs[c * NVT + tid] = ok ? val : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KC * 32 / 256; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i >> 5, m = i & 31;
+        const int o = o0 + (m >> 3);
+        const bool ok = c < kc && o < Cout;
+        const float val = w[ok ? ((int64_t)(c0 + c) * Cout + o) * 8 + (m & 7) : 0];
+        ws[i] = ok ? val : 0.f;
+      }
+      __syncthreads();
+      const float* wb = ws + half * 32 + l32;
+      const float* xb = xs + half * NVT + wave * 64 + l32;
+      const int kce = (kc + 7) & ~7;  // rows up to KC are zero-filled
+#pragma unroll 1
+      for (int k = 0; k < kce; k += 8) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+          const float a = wb[(k + kk) * 32];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[(k + kk) * NVT + g * 32], acc[g], 0, 0, 0);
+        }
       }
     }
-  }
-  if (!active) return;
-  const int ix = (int)(v % W);
-  const int iy = (int)((v / W) % H);
-  const int iz = (int)(v / ((int64_t)W * H));
-  const int OH = 2 * H, OW = 2 * W;
-  const int64_t OS = S * 8;
 #pragma unroll
-  for (int j = 0; j < CT_OT; ++j) {
-    if (j < no) {
-      float* yo = y + (int64_t)n * ybs + (int64_t)(o0 + j) * OS;
+    for (int g = 0; g < 2; ++g) {
+      if (!vok[g]) continue;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int q = 0; q < 4; ++q) {  // q = output channel inside the tile (r >> 2)
+        const int o = o0 + q;
+        if (o >= Cout) continue;
+        const float bv = bias ? bias[o] : 0.f;
+        float* yo = yn + (int64_t)o * OS + obase[g];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          float2 val = make_float2(acc[j][a * 4 + b * 2], acc[j][a * 4 + b * 2 + 1]);
-          *reinterpret_cast<float2*>(yo + ((int64_t)(2 * iz + a) * OH + (2 * iy + b)) * OW + 2 * ix) =
-              val;
-        }
+        for (int b = 0; b < 2; ++b)
+          *reinterpret_cast<float2*>(yo + (int64_t)b * OW) =
+              make_float2(acc[g][q * 4 + b * 2] + bv, acc[g][q * 4 + b * 2 + 1] + bv);
+      }
     }
   }
 }
 
-constexpr int CT_CT = 16;  // input channels per thread in the k2s2 data gradient
-
-// dx[n,c,v] = sum_{o,t} dy[n,o,2v+t] * w[c,o,t]; grid: (voxel blocks, Cin/CT_CT, N)
-__global__ __launch_bounds__(256) void convt_k2s2_bwd_data_kernel(
+// ---- data gradient: workgroup = 256 input voxels x 64 input channels (2 m-tiles, so dY is read
+// once for Cin <= 64); K is walked 4 output channels (32 k) at a time.  dY is de-interleaved
+// while staging: dys[(o,t)][v], the k-pair is (c=0, c=1) of one (o,a,b).
+__global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
     int Cout, int D, int H, int W, int64_t xbs, int64_t ybs) {
-  const int64_t S = (int64_t)D * H * W;
-  const int64_t v = blockIdx.x * 256ll + threadIdx.x;
-  const int c0 = blockIdx.y * CT_CT;
+  constexpr int NVT = 256, KO = 4, KK = KO * 8;
+  __shared__ float dys[KK * NVT];
+  __shared__ float ws[KK * 65];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int v0 = blockIdx.x * NVT;
+  const int c0 = blockIdx.y * 64;
   const int n = blockIdx.z;
-  if (v >= S) return;
-  const int ix = (int)(v % W);
-  const int iy = (int)((v / W) % H);
-  const int iz = (int)(v / ((int64_t)W * H));
+  const float* dyn = dy + (int64_t)n * ybs;
   const int OH = 2 * H, OW = 2 * W;
-  const int64_t OS = S * 8;
-  const int nc = min(CT_CT, Cin - c0);
-  float acc[CT_CT];
+  const int64_t OS = (int64_t)S * 8;
+  // this thread's staging voxel
+  const int sv = v0 + tid;
+  const bool sok = sv < S;
+  const int svv = sok ? sv : 0;
+  const int64_t sbase = ((int64_t)(2 * (svv / (W * H))) * OH + 2 * ((svv / W) % H)) * OW + 2 * (svv % W);
+
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int j = 0; j < CT_CT; ++j) acc[j] = 0.f;
-  const float* dp = dy + (int64_t)n * ybs + ((int64_t)(2 * iz) * OH + 2 * iy) * OW + 2 * ix;
-  for (int o = 0; o < Cout; ++o) {
-    const float* q = dp + (int64_t)o * OS;
-    float g[8];
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float2 t = *reinterpret_cast<const float2*>(q + ((int64_t)a * OH + b) * OW);
-        g[a * 4 + b * 2] = t.x;
-        g[a * 4 + b * 2 + 1] = t.y;
+      for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.f;
+
+  for (int o0 = 0; o0 < Cout; o0 += KO) {
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < KO; ++o)
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        float2 val = make_float2(0.f, 0.f);
+        if (sok && o0 + o < Cout)
+          val = *reinterpret_cast<const float2*>(dyn + (int64_t)(o0 + o) * OS + sbase +
+                                                 (int64_t)(ab >> 1) * OH * OW + (int64_t)(ab & 1) * OW);
+        dys[(o * 8 + ab * 2) * NVT + tid] = val.x;
+        dys[(o * 8 + ab * 2 + 1) * NVT + tid] = val.y;
       }
-#pragma unroll
-    for (int j = 0; j < CT_CT; ++j) {
-      if (j < nc) {
-        const float* wc = w + ((int64_t)(c0 + j) * Cout + o) * 8;  // block-uniform
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[j] = fmaf(g[t], wc[t], acc[j]);
-      }
+    // weights of this k-slab, transposed to ws[k][ci] (row stride 65: conflict-free both ways)
+    for (int i = tid; i < 64 * KK; i += 256) {
+      const int k = i & (KK - 1), c = i >> 5;  // KK == 32
+      const int o = o0 + (k >> 3);
+      ws[k * 65 + c] = (c0 + c < Cin && o < Cout) ? w[((int64_t)(c0 + c) * Cout + o) * 8 + (k & 7)] : 0.f;
+    }
+    __syncthreads();
+    const float* wb = ws + half * 65 + l32;
+    const float* db = dys + half * NVT + wave * 64 + l32;
+#pragma unroll 4
+    for (int k = 0; k < KK; k += 2) {
+      const float a0 = wb[k * 65], a1 = wb[k * 65 + 32];
+      const float b0 = db[k * NVT], b1 = db[k * NVT + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
+  float* dxn = dx + (int64_t)n * xbs;
 #pragma unroll
-  for (int j = 0; j < CT_CT; ++j)
-    if (j < nc) dx[(int64_t)n * xbs + (int64_t)(c0 + j) * S + v] = acc[j];
+  for (int g = 0; g < 2; ++g) {
+    const int v = v0 + (wave * 2 + g) * 32 + l32;
+    if (v >= S) continue;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < Cin) dxn[(int64_t)c * S + v] = acc[m][g][r];
+      }
+  }
 }
 
-// dw[c,o,t] = sum_{n,v} x[n,c,v] * dy[n,o,2v+t].
-// grid: (splits, ceil(Cout/8), ceil(Cin/32)).  A block owns a 32 c x 8 o tile and walks its
-// slice of voxels 64 at a time through LDS: xs[c][v] (stride 65: conflict-free per c) and
-// dys[o][v][8 taps] (block-broadcast b128 reads).  Thread (c = tid&31, o = tid>>5) keeps the
-// 8 taps of its (c,o) pair; fp32 over 64 voxels, flushed to double every step.
-__global__ __launch_bounds__(256) void convt_k2s2_bwd_weight_kernel(
+// ---- weight gradient: workgroup = 64 input channels (2 m-tiles) x 16 output channels (wave w:
+// o-group w, N-tile = 4 o x 8 t), persistent over 64-voxel tiles of its split; partial
+// dW -> slab[split][Cin][Cout][8] (coalesced: the lane index IS (o,t)), fixed-order reduce.
+__global__ __launch_bounds__(256) void convt_k2s2_bwd_weight_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
     int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs, int nsplit) {
-  __shared__ float xs[32 * 65];
-  __shared__ __attribute__((aligned(16))) float dys[8 * 64 * 8];
-  const int tid = threadIdx.x;
-  const int split = blockIdx.x, o0 = blockIdx.y * 8, c0 = blockIdx.z * 32;
-  const int64_t S = (int64_t)D * H * W;
+  constexpr int NV = 64;
+  __shared__ float xs[64 * (NV + 1)];
+  __shared__ float dys[128 * (NV + 1)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int split = blockIdx.x, o0 = blockIdx.y * 16, c0 = blockIdx.z * 64;
+  const int S = D * H * W;
   const int OH = 2 * H, OW = 2 * W;
-  const int64_t OS = S * 8;
+  const int64_t OS = (int64_t)S * 8;
   const int64_t total = (int64_t)N * S;
-  const int64_t nsteps = (total + 63) / 64;
-  const int64_t per = (nsteps + nsplit - 1) / nsplit;
-  const int64_t step_begin = split * per, step_end = min(nsteps, step_begin + per);
-  const int tc = tid & 31, to = tid >> 5;
-  double dacc[8];
+  const int64_t ntiles = (total + NV - 1) / NV;
+
+  f32x16 acc[2];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) dacc[t] = 0.0;
-  for (int64_t step = step_begin; step < step_end; ++step) {
-    const int64_t g0 = step * 64;
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  const int sv = tid & 63, sq = tid >> 6;  // staging: voxel, quarter
+  for (int64_t tile = split; tile < ntiles; tile += nsplit) {
+    const int64_t g = tile * NV + sv;
+    const bool ok = g < total;
+    const int64_t nn = ok ? g / S : 0;
+    const int v = ok ? (int)(g - nn * S) : 0;
     __syncthreads();
-    // stage x: 32 channels x 64 voxels
-    for (int i = tid; i < 32 * 64; i += 256) {
-      const int c = i >> 6, vv = i & 63;
-      const int64_t g = g0 + vv;
-      float val = 0.f;
-      if (g < total && c0 + c < Cin) {
-        const int64_t n = g / S, v = g - n * S;
-        val = x[n * xbs + (int64_t)(c0 + c) * S + v];
-      }
-      xs[c * 65 + vv] = val;
-    }
-    // stage dy: 8 o x 64 voxels x (2x2) float2
-    for (int i = tid; i < 8 * 4 * 64; i += 256) {
-      const int vv = i & 63, ab = (i >> 6) & 3, o = i >> 8;
-      const int64_t g = g0 + vv;
+#pragma unroll 4
+    for (int c = sq; c < 64; c += 4)
+      xs[c * (NV + 1) + sv] = (ok && c0 + c < Cin) ? x[nn * xbs + (int64_t)(c0 + c) * S + v] : 0.f;
+    const int64_t sbase = nn * ybs + ((int64_t)(2 * (v / (W * H))) * OH + 2 * ((v / W) % H)) * OW + 2 * (v % W);
+#pragma unroll 4
+    for (int i = sq; i < 64; i += 4) {  // i = o_local*4 + ab
+      const int o = o0 + (i >> 2), ab = i & 3;
       float2 val = make_float2(0.f, 0.f);
-      if (g < total && o0 + o < Cout) {
-        const int64_t n = g / S, v = g - n * S;
-        const int ix = (int)(v % W);
-        const int iy = (int)((v / W) % H);
-        const int iz = (int)(v / ((int64_t)W * H));
-        val = *reinterpret_cast<const float2*>(
-            dy + n * ybs + (int64_t)(o0 + o) * OS +
-            ((int64_t)(2 * iz + (ab >> 1)) * OH + (2 * iy + (ab & 1))) * OW + 2 * ix);
-      }
-      *reinterpret_cast<float2*>(dys + (o * 64 + vv) * 8 + ab * 2) = val;
+      if (ok && o < Cout)
+        val = *reinterpret_cast<const float2*>(dy + sbase + (int64_t)o * OS + (int64_t)(ab >> 1) * OH * OW +
+                                               (int64_t)(ab & 1) * OW);
+      dys[((i >> 2) * 8 + ab * 2) * (NV + 1) + sv] = val.x;
+      dys[((i >> 2) * 8 + ab * 2 + 1) * (NV + 1) + sv] = val.y;
     }
     __syncthreads();
-    float part[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) part[t] = 0.f;
+    const float* xb = xs + l32 * (NV + 1) + half;
+    const float* db = dys + (wave * 32 + l32) * (NV + 1) + half;
 #pragma unroll 8
-    for (int vv = 0; vv < 64; ++vv) {
-      const float xv = xs[tc * 65 + vv];
-      const float4 d0 = *reinterpret_cast<const float4*>(dys + (to * 64 + vv) * 8);
-      const float4 d1 = *reinterpret_cast<const float4*>(dys + (to * 64 + vv) * 8 + 4);
-      part[0] = fmaf(xv, d0.x, part[0]); part[1] = fmaf(xv, d0.y, part[1]);
-      part[2] = fmaf(xv, d0.z, part[2]); part[3] = fmaf(xv, d0.w, part[3]);
-      part[4] = fmaf(xv, d1.x, part[4]); part[5] = fmaf(xv, d1.y, part[5]);
-      part[6] = fmaf(xv, d1.z, part[6]); part[7] = fmaf(xv, d1.w, part[7]);
+    for (int k = 0; k < NV; k += 2) {
+      const float b = db[k];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[k], b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[32 * (NV + 1) + k], b, acc[1], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) dacc[t] += (double)part[t];
   }
-  if (c0 + tc < Cin && o0 + to < Cout) {
-    float* out = slab + (((int64_t)split * Cin + (c0 + tc)) * Cout + (o0 + to)) * 8;
+  // D[i = ci][j = (o,t)]
+  const int o = o0 + wave * 4 + (l32 >> 3);
+  if (o < Cout) {
+    float* sl = slab + (int64_t)split * Cin * Cout * 8;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) out[t] = (float)dacc[t];
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < Cin) sl[((int64_t)c * Cout + o) * 8 + (l32 & 7)] = acc[m][r];
+      }
   }
 }
 
@@ -334,11 +426,14 @@ static int convt_out(int in, const m355_conv3d_desc* d) {
   return (in - 1) * d->stride - 2 * d->pad + d->k + d->out_pad;
 }
 static int convt_nsplit(const m355_conv3d_desc* d) {
-  const int64_t tiles = ceil_div(d->Cin, 32) * ceil_div(d->Cout, 8);
+  const int64_t tiles = ceil_div(d->Cin, 64) * ceil_div(d->Cout, 16);
   const int64_t nsteps = ceil_div((int64_t)d->N * d->D * d->H * d->W, 64);
-  int64_t ns = std::max<int64_t>(1, 1024 / tiles);
+  int64_t ns = std::max<int64_t>(1, 768 / tiles);
   ns = std::min<int64_t>(ns, nsteps);
   return (int)ns;
+}
+static bool convt_fits_i32(const m355_conv3d_desc* d) {
+  return (int64_t)d->D * d->H * d->W * 8 * std::max(d->Cin, d->Cout) < (1ll << 31);
 }
 
 static int validate_convt(const m355_conv3d_desc* d, const char* who) {
@@ -384,11 +479,11 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
   M355_REQUIRE(OD > 0 && OH > 0 && OW > 0, M355_EINVALID_ARG, "conv_transpose3d_fwd: empty output");
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0) {
+  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
-    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(d->Cout, CT_OT), (unsigned)d->N);
-    hipLaunchKernelGGL(convt_k2s2_fwd_kernel, grid, dim3(256), 0, st, x, w, bias, y, d->Cin, d->Cout,
-                       d->D, d->H, d->W, xbs, ybs);
+    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(ceil_div(d->Cout, 4), CTF_MTG), (unsigned)d->N);
+    hipLaunchKernelGGL(convt_k2s2_fwd_mfma_kernel, grid, dim3(256), 0, st, x, w, bias, y, d->Cin,
+                       d->Cout, d->D, d->H, d->W, xbs, ybs);
     return check_launch("convt_k2s2_fwd");
   }
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
@@ -408,10 +503,10 @@ extern "C" int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const f
   const int OD = convt_out(d->D, d), OH = convt_out(d->H, d), OW = convt_out(d->W, d);
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0) {
+  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
-    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(d->Cin, CT_CT), (unsigned)d->N);
-    hipLaunchKernelGGL(convt_k2s2_bwd_data_kernel, grid, dim3(256), 0, st, dy, w, dx, d->Cin,
+    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(d->Cin, 64), (unsigned)d->N);
+    hipLaunchKernelGGL(convt_k2s2_bwd_data_mfma_kernel, grid, dim3(256), 0, st, dy, w, dx, d->Cin,
                        d->Cout, d->D, d->H, d->W, xbs, ybs);
     return check_launch("convt_k2s2_bwd_data");
   }
@@ -432,15 +527,15 @@ extern "C" int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const
   const int OD = convt_out(d->D, d), OH = convt_out(d->H, d), OW = convt_out(d->W, d);
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0) {
+  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0 && convt_fits_i32(d)) {
     const int nsplit = convt_nsplit(d);
     const size_t need = convt_slab_bytes(d);
     M355_REQUIRE(workspace && workspace_bytes >= need, M355_EWORKSPACE,
                  "conv_transpose3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                  need);
     float* slab = (float*)workspace;
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(d->Cout, 8), (unsigned)ceil_div(d->Cin, 32));
-    hipLaunchKernelGGL(convt_k2s2_bwd_weight_kernel, grid, dim3(256), 0, st, x, dy, slab, d->N,
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(d->Cout, 16), (unsigned)ceil_div(d->Cin, 64));
+    hipLaunchKernelGGL(convt_k2s2_bwd_weight_mfma_kernel, grid, dim3(256), 0, st, x, dy, slab, d->N,
                        d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, nsplit);
     const int64_t total = (int64_t)d->Cin * d->Cout * 8;
     hipLaunchKernelGGL(convt_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1024)),
