@@ -108,8 +108,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_ddp = os.environ.get("M355_FORCE_DDP", "0") == "1"  # exercise the RCCL path with one rank
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from segmentation_pipeline_amd import distributed as D
@@ -123,14 +125,14 @@ def main():
     model = build_model(cfg).to(device)
     crit = HybridLogisticDiceLoss()
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)  # research/msseg2/msseg2.py:94
-    runner = D.PatchParallel(model) if world > 1 else model
+    runner = D.PatchParallel(model, force_collectives=force_ddp) if (world > 1 or force_ddp) else model
     predictor = StandardPredict(image_names=["X", "y"])
     x, lab, y = synth((args.batch, cin) + patch, cout, 1234 + rank, device)
     batch = {"X": x, "y": y}
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +235,7 @@ def main():
             })
             out["cpu_baseline"] = cb
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -35,18 +35,21 @@ class PatchParallel(nn.Module):
     """
 
     def __init__(self, module: nn.Module, bucket_bytes: int = 25 << 20, process_group=None,
-                 broadcast_parameters: bool = True):
+                 broadcast_parameters: bool = True, force_collectives: bool = False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives: run the hooks / all-reduces even with one rank (exercises the RCCL path
+        # on a single-GPU box; numerically a no-op)
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.params = [p for p in module.parameters() if p.requires_grad]
         self._build_buckets(bucket_bytes)
         self._pending: List = []
         self._ready = [0] * len(self.buckets)
         self._used = [set() for _ in self.buckets]
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             if broadcast_parameters:
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=self.group)
@@ -122,7 +125,7 @@ class PatchParallel(nn.Module):
     def finish_gradient_sync(self):
         """Call after loss.backward(): flushes buckets with unused parameters, waits for the
         collectives and turns the sums into means (gradient of the mean loss over ranks)."""
-        if self.world <= 1:
+        if not self.active:
             return
         launched = {b for b, _ in self._pending}
         for b in range(len(self.buckets)):
