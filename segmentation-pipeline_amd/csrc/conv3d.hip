@@ -343,6 +343,33 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
   // loads themselves are unconditional from clamped addresses -- see the forward kernel)
   unsigned mi[4], mh, md;
   const int iDHW = (int)DHW, iHW = (int)HW;
+
+  // Tile-invariant part of every prefetch item, computed once: global offset relative to the
+  // tile origin, LDS address, and a one-hot code (bit zz | bit 8+yy | bit 20+q) that a
+  // per-tile uniform mask of valid rows / columns turns into a 2-instruction bounds check.
+  int relI[IPER], ldsI[IPER], relH[HPER], ldsH[HPER];
+  unsigned codeI[IPER], codeH[HPER];
+#pragma unroll
+  for (int k = 0; k < IPER; ++k) {
+    const int m = tid + 256 * k;
+    const int q = m % Q, row = m / Q;
+    const int c = row / RPC, rem = row - c * RPC;
+    const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+    relI[k] = c * iDHW + zz * iHW + yy * W + 4 * q;
+    ldsI[k] = m < NI ? c * CSW + zz * PS + yy * RS + 1 + 4 * q : -1;
+    codeI[k] = (m < NI && c0 + c < Cin) ? ((1u << zz) | (1u << (8 + yy)) | (1u << (20 + q))) : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int j = 0; j < HPER; ++j) {
+    const int h = tid + 256 * j;
+    const int side = h & 1, row = h >> 1;
+    const int c = row / RPC, rem = row - c * RPC;
+    const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+    relH[j] = c * iDHW + zz * iHW + yy * W + (side ? TX : -1);
+    ldsH[j] = h < NH ? c * CSW + zz * PS + yy * RS + (side ? TX + 1 : 0) : -1;
+    codeH[j] = (h < NH && c0 + c < Cin) ? ((1u << zz) | (1u << (8 + yy)) | (1u << (20 + side))) : 0xFFFFFFFFu;
+  }
+
   auto fetch = [&](int tile) {
     int t = tile;
     const int n = t / tiles_per_n;
@@ -354,41 +381,41 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
     const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
     const float* xn = x + (int64_t)n * xbs;
     const float* dn = dy + (int64_t)n * ybs;
-    const int tq = opaque(tid);
+    // uniform masks of the halo rows / interior float4s / halo sides that fall inside the volume
+    unsigned zy = 0u;
+    for (int zz = 0; zz < TZ + 2; ++zz)
+      if (z0 + zz - 1 >= 0 && z0 + zz - 1 < D) zy |= 1u << zz;
+    for (int yy = 0; yy < TY + 2; ++yy)
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) zy |= 1u << (8 + yy);
+    unsigned qm[4] = {0u, 0u, 0u, 0u};
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (x0 + 4 * q + e < W) qm[e] |= 1u << (20 + q);
+    const unsigned sm = (x0 - 1 >= 0 ? (1u << 20) : 0u) | (x0 + TX < W ? (1u << 21) : 0u);
+    const int base = c0 * iDHW + (z0 - 1) * iHW + (y0 - 1) * W + x0;
     mi[0] = mi[1] = mi[2] = mi[3] = 0u;
     mh = 0u;
 #pragma unroll
     for (int k = 0; k < IPER; ++k) {
-      const int m = tq + 256 * k;
-      const int q = m % Q, row = m / Q;
-      const int c = row / RPC, rem = row - c * RPC;
-      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = x0 + 4 * q;
-      const bool rok = m < NI && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
-      const int off = gc * iDHW + gz * iHW + gy * W + gx;
       if constexpr (VEC) {
-        const bool ok = rok && gx < W;
-        xi[k] = *reinterpret_cast<const f32x4*>(xn + (ok ? off : 0));
+        const bool ok = (codeI[k] & ~(zy | qm[0])) == 0u;  // W % 4 == 0: a float4 is in or out as a whole
+        xi[k] = *reinterpret_cast<const f32x4*>(xn + (ok ? base + relI[k] : 0));
         const unsigned bit = ok ? (1u << k) : 0u;
         mi[0] |= bit; mi[1] |= bit; mi[2] |= bit; mi[3] |= bit;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool ok = rok && gx + e < W;
-          xi[k][e] = xn[ok ? off + e : 0];
+          const bool ok = (codeI[k] & ~(zy | qm[e])) == 0u;
+          xi[k][e] = xn[ok ? base + relI[k] + e : 0];
           mi[e] |= ok ? (1u << k) : 0u;
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < HPER; ++j) {
-      const int h = tq + 256 * j;
-      const int side = h & 1, row = h >> 1;
-      const int c = row / RPC, rem = row - c * RPC;
-      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c, gx = side ? x0 + TX : x0 - 1;
-      const bool ok = h < NH && gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      xh[j] = xn[ok ? gc * iDHW + gz * iHW + gy * W + gx : 0];
+      const bool ok = (codeH[j] & ~(zy | sm)) == 0u;
+      xh[j] = xn[ok ? base + relH[j] : 0];
       mh |= ok ? (1u << j) : 0u;
     }
     const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
@@ -403,27 +430,17 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
     }
   };
   auto commit = [&]() {
-    const int tq = opaque(tid);
 #pragma unroll
     for (int k = 0; k < IPER; ++k) {
-      const int m = tq + 256 * k;
-      const int q = m % Q, row = m / Q;
-      const int c = row / RPC, rem = row - c * RPC;
-      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-      if (m < NI) {
-        float* p = xs + c * CSW + zz * PS + yy * RS + 1 + 4 * q;
+      if (ldsI[k] >= 0) {
+        float* p = xs + ldsI[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) p[e] = ((mi[e] >> k) & 1u) ? xi[k][e] : 0.f;
       }
     }
 #pragma unroll
-    for (int j = 0; j < HPER; ++j) {
-      const int h = tq + 256 * j;
-      const int side = h & 1, row = h >> 1;
-      const int c = row / RPC, rem = row - c * RPC;
-      const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
-      if (h < NH) xs[c * CSW + zz * PS + yy * RS + (side ? TX + 1 : 0)] = ((mh >> j) & 1u) ? xh[j] : 0.f;
-    }
+    for (int j = 0; j < HPER; ++j)
+      if (ldsH[j] >= 0) xs[ldsH[j]] = ((mh >> j) & 1u) ? xh[j] : 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = ((md >> j) & 1u) ? dr[j] : 0.f;
   };
@@ -769,7 +786,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W) {
   const int target = env_int("M355_CONV_TARGET_WG", 512);
   const int force_ntw = env_int("M355_CONV_NTW", 0);
   const int force_ks = env_int("M355_CONV_KSPLIT", 0);
-  const int cands[4] = {8, 4, 2, 1};
+  // NTW=4 (2 workgroups per CU) measured 3-9% faster than NTW=8 on levels 0-2
+  const int cands[4] = {4, 8, 2, 1};
   int chosen = 1, chosen_ks = 1;
   for (int i = 0; i < 4; ++i) {
     const int ntw = cands[i];
