@@ -593,8 +593,17 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
                                    int64_t total, int nsplit) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    float v = slab[i];
-    for (int s = 1; s < nsplit; ++s) v += slab[(int64_t)s * total + i];
+    // fixed summation order; the loads of 8 splits are independent and stay in flight together
+    float v = 0.f;
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(s + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < nsplit; ++s) v += slab[(int64_t)s * total + i];
     out[i] = v;
   }
 }
@@ -1081,8 +1090,8 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     else
       M355_BWW_LAUNCH(8)
     const int64_t total = (int64_t)d->Cout * d->Cin * 27;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, total,
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total,
                        p.nsplit);
     }
   } else {

@@ -90,17 +90,20 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
   }
 }
 
-__global__ void norm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
+// one wave (64 lanes) per statistic: lanes stride over the partials, fixed-order shuffle tree
+__global__ __launch_bounds__(64) void norm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
                                      float* __restrict__ rstd, float* __restrict__ running_mean,
                                      float* __restrict__ running_var, float momentum, float eps,
                                      int64_t nstats, int nblk, int64_t count) {
-  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (s >= nstats) return;
+  const int64_t s = blockIdx.x;
   double t1 = 0.0, t2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = threadIdx.x; b < nblk; b += 64) {
     t1 += partial[(s * nblk + b) * 2 + 0];
     t2 += partial[(s * nblk + b) * 2 + 1];
   }
+  t1 = wave_sum(t1);
+  t2 = wave_sum(t2);
+  if (threadIdx.x != 0) return;
   const double m = t1 / (double)count;
   double var = t2 / (double)count - m * m;
   if (var < 0.0) var = 0.0;
@@ -215,14 +218,30 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(
   }
 }
 
-// Backward finalize: AB[n*C+c] = (A,B); dgamma[c] = sum_n B; dbeta[c] = sum_n A;
-// per-statistic means m1 = mean(dxhat), m2 = mean(dxhat*xhat) -> stat_m[s*2+{0,1}]
-__global__ void norm_bwd_finalize_kernel(const double* __restrict__ partial,
+// Backward finalize, stage 1: AB[(n*C + c)*2 + {0,1}] = sum over blocks (one wave per (n,c)).
+__global__ __launch_bounds__(64) void norm_bwd_collapse_kernel(const double* __restrict__ partial,
+                                                                double* __restrict__ ab, int nblk) {
+  const int64_t nc = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) {
+    a += partial[(nc * nblk + k) * 2];
+    b += partial[(nc * nblk + k) * 2 + 1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    ab[nc * 2] = a;
+    ab[nc * 2 + 1] = b;
+  }
+}
+
+// Stage 2: dgamma[c] = sum_n B; dbeta[c] = sum_n A; per-statistic means
+// m1 = mean(dxhat), m2 = mean(dxhat*xhat) -> stat_m[s*2+{0,1}]
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ ab,
                                          const float* __restrict__ gamma,
                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
                                          float* __restrict__ stat_m, int N, int C, int groups,
-                                         int nblk, int64_t count, int training) {
-  // one thread per statistic; loops are tiny (C/groups channels or N samples)
+                                         int64_t count, int training) {
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s < nstats) {
@@ -230,12 +249,10 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ partial,
     if (groups == 0) {
       const int c = (int)s;
       const double g = gamma ? (double)gamma[c] : 1.0;
-      for (int n = 0; n < N; ++n)
-        for (int b = 0; b < nblk; ++b) {
-          const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
-          m1 += partial[o];
-          m2 += partial[o + 1];
-        }
+      for (int n = 0; n < N; ++n) {
+        m1 += ab[((int64_t)n * C + c) * 2];
+        m2 += ab[((int64_t)n * C + c) * 2 + 1];
+      }
       m1 *= g;
       m2 *= g;
     } else {
@@ -244,30 +261,21 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ partial,
       for (int cc = 0; cc < cpg; ++cc) {
         const int c = gi * cpg + cc;
         const double g = gamma ? (double)gamma[c] : 1.0;
-        double a = 0.0, bb = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-          const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
-          a += partial[o];
-          bb += partial[o + 1];
-        }
-        m1 += g * a;
-        m2 += g * bb;
+        m1 += g * ab[((int64_t)n * C + c) * 2];
+        m2 += g * ab[((int64_t)n * C + c) * 2 + 1];
       }
     }
     if (!training) { m1 = 0.0; m2 = 0.0; }
     stat_m[s * 2 + 0] = (float)(m1 / (double)count);
     stat_m[s * 2 + 1] = (float)(m2 / (double)count);
   }
-  // dgamma / dbeta: one thread per channel
   if (s < C && (dgamma || dbeta)) {
     const int c = (int)s;
     double a = 0.0, bb = 0.0;
-    for (int n = 0; n < N; ++n)
-      for (int b = 0; b < nblk; ++b) {
-        const int64_t o = (((int64_t)n * C + c) * nblk + b) * 2;
-        a += partial[o];
-        bb += partial[o + 1];
-      }
+    for (int n = 0; n < N; ++n) {
+      a += ab[((int64_t)n * C + c) * 2];
+      bb += ab[((int64_t)n * C + c) * 2 + 1];
+    }
     if (dbeta) dbeta[c] = (float)a;
     if (dgamma) dgamma[c] = (float)bb;
   }
@@ -342,7 +350,8 @@ extern "C" size_t m355_norm_workspace(const m355_norm_desc* d) {
   const NormGeom g = geom(d);
   const size_t fwd = (size_t)g.nstats * g.nblk * 2 * sizeof(double);
   const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
-  const size_t bwd = (size_t)d->N * d->C * nblk_c * 2 * sizeof(double) +
+  const size_t bwd = (size_t)round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256) +
+                     (size_t)round_up((int64_t)d->N * d->C * 2 * sizeof(double), 256) +
                      (size_t)g.nstats * 2 * sizeof(float) + 256;
   return std::max(fwd, bwd) + 256;
 }
@@ -370,9 +379,8 @@ extern "C" int m355_norm_stats(const m355_norm_desc* d, const float* x, float* m
     hipLaunchKernelGGL(norm_partial_kernel<false>, dim3((unsigned)g.nblk, (unsigned)g.nstats),
                        dim3(256), 0, st, x, partial, d->groups, d->C, d->S, xbs, g.runs, g.len,
                        g.nblk);
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)ceil_div(g.nstats, 64)), dim3(64), 0, st,
-                     partial, mean, rstd, running_mean, running_var, momentum, d->eps, g.nstats,
-                     g.nblk, g.count);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, mean,
+                     rstd, running_mean, running_var, momentum, d->eps, g.nstats, g.nblk, g.count);
   return check_launch("norm_stats");
 }
 
@@ -425,8 +433,8 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
   const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
   double* partial = (double*)workspace;
-  float* stat_m = (float*)((char*)workspace +
-                           round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
+  double* ab = (double*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
+  float* stat_m = (float*)((char*)ab + round_up((int64_t)d->N * d->C * 2 * sizeof(double), 256));
   const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) &&
                    (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
   if (vec)
@@ -440,9 +448,10 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
                        dy, mean, rstd, gamma, beta, partial, d->C, d->S, d->groups, d->act,
                        d->act_slope, xbs, ybs, nblk_c);
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
+  hipLaunchKernelGGL(norm_bwd_collapse_kernel, dim3((unsigned)(d->N * d->C)), dim3(64), 0, st, partial, ab,
+                     nblk_c);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)ceil_div(nthreads, 64)), dim3(64), 0,
-                     st, partial, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, nblk_c,
-                     g.count, training);
+                     st, ab, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, g.count, training);
   const int64_t work = vec ? d->S / 4 : d->S;
   const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
   dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
