@@ -51,6 +51,21 @@ def build_model(cfg):
                        upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed PMC passes of this same command
+    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)["kernels"]
+        for name, rec in data.items():
+            if kernel_substr in name:
+                return rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(cfg, batch):
     """Stock torch-CPU restatement of the reference path (oracle/torch_ref.py, pinned to the real
     reference by tests/golden) on a bounded sample: ONE no-grad forward + ONE train step of the
@@ -201,7 +216,7 @@ def main():
             tot_f, tot_ms = sum(f for f, _ in sel), sum(ms for _, ms in sel)
             ach = tot_f / (tot_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(f"conv3_mfma_fwd_kernel<{dom[0]}, {dom[1]}>"),
                         "kernel": f"conv3_mfma_fwd_kernel<{dom[0]},{dom[1]}>", "launches": len(sel),
                         "avg_launch_ms": tot_ms / len(sel), "avg_gflop_per_launch": tot_f / len(sel) / 1e9}
         by_tag = {}
