@@ -289,3 +289,34 @@ def test_standard_predict_sagittal_split_on_gpu(golden):
         a, b = model(x[:, :, :8].contiguous()), model(x[:, :, 8:].flip(2).contiguous()).flip(2)
     assert y.shape == (2, 3, 16, 8, 8)
     assert maxerr(y, torch.cat([a, b], dim=2).cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("shape,cin,cout,filters", [
+    ((1, 3, 8, 32, 16), 3, 7, [8, 16, 24]),      # cfg5 family: anisotropic patch, 7 classes, odd Cin
+    ((2, 2, 4, 12, 20), 2, 2, [8, 16]),          # sizes that divide no tile dimension, N = 2
+])
+def test_anisotropic_and_ragged_volumes_match_cpu_oracle(shape, cin, cout, filters):
+    """Forward, loss and every gradient against the torch-CPU restatement of the reference
+    (oracle/torch_ref.py, itself pinned to the reference goldens) on non-cubic volumes."""
+    from oracle import torch_ref as R
+    depth = len(filters)
+    torch.manual_seed(3)
+    model = ModularUNet(cin, cout, filters, depth, block_params=dict(GN8), **CONVT)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g)
+    lab = torch.randint(0, cout, (shape[0],) + tuple(shape[2:]), generator=g)
+    y = torch.nn.functional.one_hot(lab, cout).permute(0, 4, 1, 2, 3).float().contiguous()
+    spec = R.UNetSpec(cin, cout, filters, depth, norm="group", groups=8, up="convT")
+    p_ref = R.unet_forward(sd, spec, x, training=True)
+    ld_ref = R.hybrid_logistic_dice_loss(p_ref, y)
+    ld_ref["loss"].backward()
+
+    model = model.cuda().train()
+    p = model(x.cuda())
+    assert maxerr(p, p_ref.detach()) <= PROB_TOL
+    ld = HybridLogisticDiceLoss()(p, y.cuda())
+    assert abs(ld["loss"].item() - ld_ref["loss"].item()) <= 1e-4
+    ld["loss"].backward()
+    for k, v in model.named_parameters():
+        grad_close(v.grad, sd[k].grad, k)
