@@ -1,7 +1,10 @@
 """Test-time ensembles (mirror of segmentation_pipeline/models/ensemble.py:9-103).
 
 The member forward passes run on the HIP kernels; the reductions over the ensemble
-axis are index / selection arithmetic on the stacked predictions.
+axis are index / selection arithmetic on the stacked predictions.  With
+torch.distributed initialised the members are independent units: member e runs on rank
+e % world and ONE all_gather returns the predictions in member order, so the result is
+bit-identical to the single-GPU ensemble.
 """
 import itertools
 from typing import Sequence
@@ -33,6 +36,28 @@ def apply_strategy(predictions: Sequence[torch.Tensor], strategy: str):
     raise RuntimeError(f"Invalid prediction strategy {strategy}")
 
 
+def _run_members(thunks):
+    """Evaluate the member forward passes, sharded over the ranks when distributed."""
+    from .. import distributed as D
+    if not D.is_distributed():
+        return [t() for t in thunks]
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = D.shard_indices(len(thunks), rank, world)
+    local = [thunks[i]().contiguous() for i in mine]
+    # every rank learns the member shape / dtype from rank 0 (which always owns member 0)
+    meta = torch.zeros(8, dtype=torch.int64, device=local[0].device if local else None)
+    if rank == 0:
+        meta[0] = local[0].dim()
+        meta[1:1 + local[0].dim()] = torch.tensor(local[0].shape)
+    dist.broadcast(meta, src=0)
+    shape = tuple(int(v) for v in meta[1:1 + int(meta[0])])
+    device = meta.device
+    stacked = torch.stack(local) if local else None
+    out = D.gather_tiles(stacked, len(thunks), shape, torch.float32, device)
+    return list(out)
+
+
 def _flip_sets(dims):
     out = []
     for order in range(len(dims) + 1):
@@ -47,7 +72,7 @@ class EnsembleModels(nn.Module):
         self.strategy = parse_strategy(strategy)
 
     def forward(self, x):
-        return apply_strategy([m(x) for m in self.models], self.strategy)
+        return apply_strategy(_run_members([(lambda m=m: m(x)) for m in self.models]), self.strategy)
 
 
 class EnsembleFlips(nn.Module):
@@ -59,8 +84,8 @@ class EnsembleFlips(nn.Module):
         self.flips = _flip_sets(tuple(spatial_dims))
 
     def forward(self, x):
-        preds = [self.model(x.flip(f).contiguous()).flip(f) for f in self.flips]
-        return apply_strategy(preds, self.strategy)
+        thunks = [(lambda f=f: self.model(x.flip(f).contiguous()).flip(f)) for f in self.flips]
+        return apply_strategy(_run_members(thunks), self.strategy)
 
 
 class EnsembleOrientations(nn.Module):
@@ -73,11 +98,10 @@ class EnsembleOrientations(nn.Module):
         self.flips = _flip_sets(dims)
 
     def forward(self, x):
-        preds = []
+        thunks = []
         for perm in self.permutations:
             inverse = tuple((torch.argsort(torch.tensor(perm)) + 2).tolist())
-            xp = x.permute(0, 1, *perm)
             for f in self.flips:
-                y = self.model(xp.flip(f).contiguous())
-                preds.append(y.flip(f).permute(0, 1, *inverse))
-        return apply_strategy(preds, self.strategy)
+                thunks.append(lambda perm=perm, inverse=inverse, f=f:
+                              self.model(x.permute(0, 1, *perm).flip(f).contiguous()).flip(f).permute(0, 1, *inverse))
+        return apply_strategy(_run_members(thunks), self.strategy)

@@ -188,3 +188,64 @@ def test_split_and_flip_matches_fixture(golden):
     x = g.t("split.x")
     assert torch.equal(split_and_flip(x), g.t("split.y"))
     assert torch.equal(reverse_split_and_flip(split_and_flip(x)), x)
+
+
+class _Member(nn.Module):
+    """Deterministic, flip-sensitive member (so the inverse flips really matter)."""
+
+    def forward(self, x):
+        ramp = torch.arange(x.shape[-1], dtype=x.dtype).reshape(1, 1, 1, 1, -1)
+        h = torch.cat([x * 2.0 + ramp * 0.1, x[:, :1] - ramp * 0.05], dim=1)
+        return torch.softmax(h, dim=1)
+
+
+def _ensemble_worker(rank=0, world=1):
+    from segmentation_pipeline_amd.models import EnsembleFlips, EnsembleOrientations
+    torch.set_num_threads(1)
+    x = torch.randn((1, 2, 4, 4, 4), generator=torch.Generator().manual_seed(21))
+    a = EnsembleFlips(_Member(), "mean")(x)
+    b = EnsembleFlips(_Member(), "majority", spatial_dims=(3, 4))(x)
+    c = EnsembleOrientations(_Member(), "mean")(x)
+    return a, b, c
+
+
+def test_sharded_ensembles_equal_single_process():
+    nthreads = torch.get_num_threads()
+    single = _ensemble_worker()
+    torch.set_num_threads(nthreads)
+    for got in spawn(_ensemble_worker):
+        for g, s in zip(got, single):
+            assert torch.equal(g, s)
+
+
+def test_samplers_index_arithmetic_and_distribution():
+    from segmentation_pipeline_amd.sampling import UniformSampler, WeightedSampler
+    g = torch.Generator().manual_seed(0)
+    vol = torch.arange(2 * 10 * 9 * 8, dtype=torch.float32).reshape(2, 10, 9, 8)
+    us = UniformSampler((4, 3, 2), ops_backend=CpuPatchOps)
+    patches, loc = us(vol, 64, generator=g)
+    assert patches.shape == (64, 2, 4, 3, 2) and loc.dtype == torch.int32
+    assert (loc >= 0).all() and (loc[:, 0] <= 6).all() and (loc[:, 1] <= 6).all() and (loc[:, 2] <= 6).all()
+    i, j, k = loc[5].tolist()
+    assert torch.equal(patches[5], vol[:, i:i + 4, j:j + 3, k:k + 2])
+    assert len(set(map(tuple, loc.tolist()))) > 30          # corners really vary
+    with pytest.raises(ValueError):
+        UniformSampler(16, ops_backend=CpuPatchOps)(vol, 1)
+
+    # weighted: lesion voxels weigh 100x the background (research/msseg2/msseg2.py:77)
+    pm = torch.ones(1, 10, 9, 8)
+    pm[0, 5, 4, 4] = 100.0
+    pm[0, 0, 0, 0] = 1e6                                      # centre where the patch cannot fit: never drawn
+    ws = WeightedSampler((4, 3, 2), ops_backend=CpuPatchOps)
+    dist_ = ws.centre_distribution(pm)
+    assert dist_.sum().item() == pytest.approx(1.0) and dist_[0].item() == 0.0
+    (patches, labels), loc = ws(vol, pm, 4000, generator=g, extra=[pm])
+    centre = loc + torch.tensor([2, 1, 1])
+    hit = ((centre == torch.tensor([5, 4, 4])).all(dim=1)).float().mean().item()
+    n_valid = 7 * 7 * 7
+    expect = 100.0 / (n_valid - 1 + 100.0)
+    assert abs(hit - expect) < 0.03
+    assert (loc >= 0).all() and (loc[:, 0] <= 6).all() and (loc[:, 1] <= 6).all() and (loc[:, 2] <= 6).all()
+    assert labels.shape == (4000, 1, 4, 3, 2) and labels[:, 0, 2, 1, 1].max() == 100.0
+    with pytest.raises(RuntimeError):
+        ws.centre_distribution(torch.zeros(1, 10, 9, 8))

@@ -320,3 +320,17 @@ def test_anisotropic_and_ragged_volumes_match_cpu_oracle(shape, cin, cout, filte
     ld["loss"].backward()
     for k, v in model.named_parameters():
         grad_close(v.grad, sd[k].grad, k)
+
+
+def test_device_side_samplers_on_gpu():
+    from segmentation_pipeline_amd.sampling import UniformSampler, WeightedSampler
+    vol = torch.randn((3, 20, 18, 22), generator=torch.Generator().manual_seed(2)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    patches, loc = UniformSampler(8)(vol, 16, generator=g)
+    for p, (i, j, k) in zip(patches, loc.tolist()):
+        assert torch.equal(p, vol[:, i:i + 8, j:j + 8, k:k + 8])
+    pm = torch.zeros((1, 20, 18, 22), device="cuda")
+    pm[0, 10, 9, 11] = 1.0                                   # all mass on one centre
+    (patches, pmaps), loc = WeightedSampler(8)(vol, pm, 5, generator=g, extra=[pm])
+    assert (loc.cpu() == torch.tensor([6, 5, 7], dtype=torch.int32)).all()
+    assert (pmaps[:, 0, 4, 4, 4] == 1.0).all()
