@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1, help="patches per rank per step")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the 3x3x3 conv fwd / data gradient (default: exact fp32, the BASELINE cfg2 mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -135,6 +137,8 @@ def main():
     from segmentation_pipeline_amd.prediction import StandardPredict
     from segmentation_pipeline_amd.trainer import PhaseTimer, hard_dice_from_counts, train_step
 
+    import segmentation_pipeline_amd as sp
+    sp.set_precision(args.precision)
     cfg = WORKLOADS[args.workload]
     cin, cout, filters, depth, patch = cfg
     model = build_model(cfg).to(device)
@@ -231,7 +235,9 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate (conv fwd + data grad), f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet(4,3,[32,64,128,256,320],5,"
                                    f"GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
                        "global_batch": world * args.batch, "params": sum(p.numel() for p in model.parameters()),

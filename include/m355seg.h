@@ -42,6 +42,13 @@ enum {
 
 enum { M355_F32 = 0 };
 
+/* arithmetic of the 3x3x3 convolutions (tensors in HBM are fp32 either way):
+ *   M355_COMPUTE_F32  exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (default)
+ *   M355_COMPUTE_BF16 operands rounded to bf16 (round-to-nearest-even) when they are staged,
+ *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE cfg3 / cfg5 family).
+ * Applies to conv3d fwd and bwd_data; the weight gradient always runs in exact fp32. */
+enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1 };
+
 /* activation fused into the normalise pass (components.py:26,54-55) */
 enum { M355_ACT_NONE = 0, M355_ACT_RELU = 1, M355_ACT_LEAKY_RELU = 2 };
 
@@ -64,6 +71,8 @@ typedef struct m355_conv3d_desc {
   int32_t out_pad;          /* conv-transpose only */
   int64_t x_batch_stride;   /* elements; 0 = dense */
   int64_t y_batch_stride;   /* elements; 0 = dense */
+  int32_t compute;          /* M355_COMPUTE_* (3x3x3 / s1 / p1 only; ignored elsewhere) */
+  int32_t reserved;         /* must be 0 */
 } m355_conv3d_desc;
 
 size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d);

@@ -36,6 +36,17 @@ static int convt_out(int in, const m355_conv3d_desc* d) {
 
 int m355o_version(void) { return M355_ABI_VERSION; }
 
+/* round-to-nearest-even fp32 -> bf16 -> fp32 (what v_cvt_pk_bf16_f32 does to an operand) */
+static float bf16r(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return f; /* NaN */
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  memcpy(&f, &u, 4);
+  return f;
+}
+#define OPND(d, v) ((d)->compute == M355_COMPUTE_BF16 ? (double)bf16r(v) : (double)(v))
+
 /* ------------------------------------------------------------------ conv3d
  * nn.Conv3d: models/components.py:36,42,51; models/modular_unet.py:83,99;
  * F.conv3d in BlurConv3d: components.py:119.  `add` = residual sum, components.py:67-68. */
@@ -67,8 +78,7 @@ int m355o_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w, 
                   for (int dx = 0; dx < k; ++dx) {
                     const int ix = ox * s + dx - p;
                     if (ix < 0 || ix >= W) continue;
-                    acc += (double)wc[(dz * k + dy) * k + dx] *
-                           (double)xc[((int64_t)iz * H + iy) * W + ix];
+                    acc += OPND(d, wc[(dz * k + dy) * k + dx]) * OPND(d, xc[((int64_t)iz * H + iy) * W + ix]);
                   }
                 }
               }
@@ -109,8 +119,8 @@ int m355o_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const floa
                   for (int dxx = 0; dxx < k; ++dxx) {
                     const int tx = ix + p - dxx;
                     if (tx < 0 || tx % s || tx / s >= OW) continue;
-                    acc += (double)wc[(dz * k + dyy) * k + dxx] *
-                           (double)dyo[((int64_t)(tz / s) * OH + ty / s) * OW + tx / s];
+                    acc += OPND(d, wc[(dz * k + dyy) * k + dxx]) *
+                           OPND(d, dyo[((int64_t)(tz / s) * OH + ty / s) * OW + tx / s]);
                   }
                 }
               }

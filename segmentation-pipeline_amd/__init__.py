@@ -7,4 +7,6 @@ Everything executes through libm355seg.so (include/m355seg.h); see DESIGN.md.
 from . import _lib, ops  # noqa: F401
 from . import models, criterions  # noqa: F401
 
-__all__ = ["models", "criterions", "ops"]
+from .ops import get_precision, precision, set_precision  # noqa: F401
+
+__all__ = ["models", "criterions", "ops", "precision", "set_precision", "get_precision"]

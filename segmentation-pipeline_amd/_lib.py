@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libm355seg.so")
 
 M355_OK = 0
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
 
 class ConvDesc(C.Structure):
@@ -21,6 +22,7 @@ class ConvDesc(C.Structure):
         ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("out_pad", C.c_int32),
         ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64),
+        ("compute", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

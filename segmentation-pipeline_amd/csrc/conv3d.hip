@@ -242,6 +242,184 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- bf16 compute mode
+// Same implicit GEMM with operands rounded to bf16 (RNE) and v_mfma_f32_32x32x16_bf16 (fp32
+// accumulate, 16x the fp32-MFMA rate).  The K-step of 16 is 16 input channels at ONE tap:
+// lanes 0-31 carry channels c..c+7, lanes 32-63 c+8..c+15, so LDS is channel-last in groups of
+// 8 bf16 = 16 B and every fragment is a single aligned ds_read_b128:
+//   xs[half][halo voxel][8]      B fragment: lane (voxel, half), tap offset = DS immediate
+//   ws[tap][half][32 o][8]       A fragment: lane (o, half)
+// At this rate the kernel is bound by staging (global -> cvt -> LDS), not by the MFMA pipe:
+// synchronous staging, two workgroups per CU overlap each other.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// packed bf16 weights: wpb[(((ch*27 + tap)*2 + half)*mout_pad + m)*8 + j], channel = ch*16 + half*8 + j
+__global__ void pack_w3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout,
+                                    int Cin, int nchunks, int mout_pad, int transpose) {
+  const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    int64_t r = i >> 3;
+    const int m = (int)(r % mout_pad);
+    r /= mout_pad;
+    const int half = (int)(r & 1);
+    r >>= 1;
+    const int tap = (int)(r % 27);
+    const int kc = (int)(r / 27) * 16 + half * 8 + j;
+    float v = 0.f;
+    if (!transpose) {
+      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
+    } else {
+      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
+    }
+    wp[i] = (__bf16)v;
+  }
+}
+
+template <int NTW, int GX>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
+    const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
+    int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
+    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride) {
+  using T = FwdTile<NTW, GX>;
+  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
+  constexpr int XI = 2 * HV;                   // (half, voxel) staging items of 8 channels
+  constexpr int XPER = (XI + 255) / 256;
+  constexpr int WI = 27 * 2 * 32;              // 16-byte weight items per chunk
+  constexpr int WPER = (WI + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16x8 xs[XI];
+  __shared__ __attribute__((aligned(16))) bf16x8 ws[WI];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const int ly = l32 / GX, lx = l32 % GX;
+
+  int bt = blockIdx.x;
+  const int txt = bt % tx_tiles;
+  bt /= tx_tiles;
+  const int tyt = bt % ty_tiles;
+  const int tzt = bt / ty_tiles;
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+  const int o0 = blockIdx.y * 32;
+  const int n = blockIdx.z / ksplit;
+  const int ks = blockIdx.z % ksplit;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  const int ch_begin = ks * cps;
+  const int ch_end = min(nchunks, ch_begin + cps);
+
+  const float* xn = x + (int64_t)n * xbs;
+  const int64_t HW = (int64_t)H * W;
+  const int DHW = (int)(HW * D);
+
+  // chunk-invariant spatial offset of this thread's staging items (-1: zero padding)
+  int goff[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    int off = -1;
+    if (e < XI) {
+      const int r = e % HV;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) off = gz * (int)HW + gy * W + gx;
+    }
+    goff[i] = off;
+  }
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  const bf16x8* xb = xs + half * HV + wave * PS + ly * RS + lx;
+  const bf16x8* wb = ws + half * 32 + l32;
+  const uint4* wsrc0 = reinterpret_cast<const uint4*>(wp);
+
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    __syncthreads();
+    // ---- stage x: item e = (half h, halo voxel r): 8 channels -> one 16-byte LDS store.
+    // Phase 1 issues EVERY global load of the chunk (x and weights) before anything consumes
+    // one, so the whole chunk is a single memory round trip; phase 2 converts and stores.
+    float xr[XPER][8];
+    uint4 wr[WPER];
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+      const int e = tid + 256 * i;
+      const int cbase = ch * 16 + (e >= HV ? 8 : 0);
+      const bool sp_ok = goff[i] >= 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // the clamp must be on the ABSOLUTE offset: channels >= Cin lie past the end of the tensor
+        const bool ok = sp_ok && cbase + j < Cin;
+        xr[i][j] = xn[ok ? (int64_t)(cbase + j) * DHW + goff[i] : 0];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int e = tid + 256 * i;
+      const int ec = e < WI ? e : WI - 1;
+      const int row = ec >> 5, o = ec & 31;  // row = tap*2 + half
+      wr[i] = wsrc0[((int64_t)ch * 54 + row) * cout_pad + o0 + o];
+    }
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+      const int e = tid + 256 * i;
+      const int cbase = ch * 16 + (e >= HV ? 8 : 0);
+      const bool sp_ok = goff[i] >= 0;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)((sp_ok && cbase + j < Cin) ? xr[i][j] : 0.f);
+      if (e < XI) xs[e] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WPER; ++i)
+      if (tid + 256 * i < WI) reinterpret_cast<uint4*>(ws)[tid + 256 * i] = wr[i];
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const bf16x8 a = wb[tap * 64];
+#pragma unroll
+      for (int g = 0; g < NTW; ++g) {
+        const bf16x8 b = xb[dz * PS + (g * GY + dy) * RS + dx];
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+      }
+    }
+  }
+
+  const int z = z0 + wave;
+  const int xg = x0 + lx;
+  if (z >= D || xg >= W) return;
+  float* outp = ksplit == 1 ? y + (int64_t)n * ybs : slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW;
+  const float* an = (ksplit == 1 && add) ? add + (int64_t)n * ybs : nullptr;
+#pragma unroll
+  for (int g = 0; g < NTW; ++g) {
+    const int yg = y0 + g * GY + ly;
+    if (yg >= H) continue;
+    const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (o < Cout) {
+        const int64_t idx = (int64_t)o * D * HW + sp;
+        float v = acc[g][r];
+        if (ksplit == 1) {
+          if (bias) v += bias[o];
+          if (an) v += an[idx];
+        }
+        outp[idx] = v;
+      }
+    }
+  }
+}
+
 // y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                      const float* __restrict__ add, float* __restrict__ y, int N,
@@ -778,15 +956,16 @@ struct FwdPlan {
 };
 
 // Plan for a 3x3x3/s1/p1 conv with K-channels `kin` and M-channels `mout`.
-static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W) {
+static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32) {
   FwdPlan p{};
   p.mfma = true;
   p.gx = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
   const int gy = 32 / p.gx;
-  p.kin_pad = (int)round_up(kin, 4);
+  const int cc = compute == M355_COMPUTE_BF16 ? 16 : 4;  // input channels per LDS chunk
+  p.kin_pad = (int)round_up(kin, cc);
   p.mout_pad = (int)round_up(mout, 32);
   p.otiles = p.mout_pad / 32;
-  p.nchunks = p.kin_pad / 4;
+  p.nchunks = p.kin_pad / cc;
   p.tz_tiles = (int)ceil_div(D, 4);
   p.tx_tiles = (int)ceil_div(W, p.gx);
   // Prefer the largest voxel tile (most reuse of the staged weights); fill the
@@ -822,7 +1001,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W) {
   p.ty_tiles = (int)ceil_div(H, p.ntw * gy);
   p.ksplit = chosen_ks;
   const int ksplit = chosen_ks;
-  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * 4, 256);
+  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (compute == M355_COMPUTE_BF16 ? 2 : 4), 256);
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
 }
@@ -850,11 +1029,59 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
 }
 
 // Runs the MFMA implicit GEMM: out[n, m, v] = bias + add + sum_{kc,tap} wp * in[n, kc, v+tap]
+template <int NTW, int GX>
+static void launch_bf16(const FwdPlan& p, const float* x, const __bf16* wp, const float* bias,
+                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
+                        int H, int W, int64_t xbs, int64_t ybs, hipStream_t st) {
+  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
+            (unsigned)(N * p.ksplit));
+  const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  hipLaunchKernelGGL((conv3_mfma_bf16_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add, y,
+                     slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
+                     p.ksplit, xbs, ybs, slab_stride);
+}
+
 static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
                          const float* bias, const float* add, float* out, int N, int kin,
                          int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
-                         size_t ws_bytes, hipStream_t st) {
-  const FwdPlan p = plan_mfma(N, kin, mout, D, H, W);
+                         size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32) {
+  const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
+  if (compute == M355_COMPUTE_BF16) {
+    M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
+                 "conv3d(bf16): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
+    M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
+    M355_REQUIRE((int64_t)std::max(kin, mout) * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
+                 "conv3d(bf16): tensor exceeds 2^31 elements per sample");
+    __bf16* wpb = (__bf16*)ws;
+    float* slab = (float*)((char*)ws + p.wp_bytes);
+    {
+      const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
+      const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+      hipLaunchKernelGGL(pack_w3_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w,
+                         p.nchunks, p.mout_pad, transpose ? 1 : 0);
+    }
+    const float* kb = p.ksplit == 1 ? bias : nullptr;
+    const float* ka = p.ksplit == 1 ? add : nullptr;
+#define M355_BF_CASE(NTW, GX)                                                                  \
+  if (p.ntw == NTW && p.gx == GX) {                                                            \
+    launch_bf16<NTW, GX>(p, in, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, st); \
+  } else
+    M355_BF_CASE(8, 32) M355_BF_CASE(4, 32) M355_BF_CASE(2, 32) M355_BF_CASE(1, 32)
+    M355_BF_CASE(8, 16) M355_BF_CASE(4, 16) M355_BF_CASE(2, 16) M355_BF_CASE(1, 16)
+    M355_BF_CASE(8, 8) M355_BF_CASE(4, 8) M355_BF_CASE(2, 8) M355_BF_CASE(1, 8) {
+      set_error("conv3d(bf16): no kernel for ntw=%d gx=%d", p.ntw, p.gx);
+      return M355_EUNSUPPORTED;
+    }
+#undef M355_BF_CASE
+    if (p.ksplit > 1) {
+      const int64_t S = (int64_t)D * H * W;
+      const int64_t total = (int64_t)N * mout * S;
+      const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out, N,
+                         mout, S, p.ksplit, total, out_bs);
+    }
+    return check_launch("conv3d_mfma_bf16");
+  }
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
@@ -931,7 +1158,7 @@ using namespace m355;
 // ---------------------------------------------------------------------- ABI
 extern "C" size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
-  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes;
 }
 
@@ -941,6 +1168,8 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
                M355_EINVALID_ARG, "%s: non-positive dimension", who);
   M355_REQUIRE(d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->pad >= 0, M355_EINVALID_ARG,
                "%s: bad k/stride/pad (%d/%d/%d)", who, d->k, d->stride, d->pad);
+  M355_REQUIRE(d->compute == M355_COMPUTE_F32 || d->compute == M355_COMPUTE_BF16, M355_EINVALID_ARG,
+               "%s: unknown compute mode %d", who, d->compute);
   return M355_OK;
 }
 
@@ -957,7 +1186,7 @@ extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const 
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   if (is_k3s1p1(d)) {
     return run_mfma_conv(x, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
-                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st);
+                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute);
   }
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
   const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
@@ -971,15 +1200,15 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
   out4[0] = out4[1] = out4[2] = out4[3] = 0;
   if (!is_k3s1p1(d)) return M355_OK;
-  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W)
-                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W);
+  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
+                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
   out4[0] = 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 
 extern "C" size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
-  const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W);
+  const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes;
 }
 
@@ -996,7 +1225,7 @@ extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, 
   if (is_k3s1p1(d)) {
     // dx = conv(dy, flipped/transposed w): K-channels = Cout, M-channels = Cin
     return run_mfma_conv(dy, w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin,
-                         d->D, d->H, d->W, ybs, xbs, workspace, workspace_bytes, st);
+                         d->D, d->H, d->W, ybs, xbs, workspace, workspace_bytes, st, d->compute);
   }
   const int64_t total = (int64_t)d->N * d->Cin * d->D * d->H * d->W;
   const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);

@@ -70,14 +70,14 @@ class RawOps:
 
     # ------------------------------------------------------------------ conv
     @staticmethod
-    def conv_desc(x_shape, Cout, k, stride, pad, out_pad=0, xbs=0, ybs=0):
+    def conv_desc(x_shape, Cout, k, stride, pad, out_pad=0, xbs=0, ybs=0, compute=0):
         N, Cin, D, H, W = x_shape
-        return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs)
+        return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs, compute, 0)
 
-    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1):
+    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0):
         x, w, bias, add = map(self.to, (x, w, bias, add))
         k = w.shape[2]
-        d = self.conv_desc(x.shape, w.shape[0], k, stride, pad)
+        d = self.conv_desc(x.shape, w.shape[0], k, stride, pad, compute=compute)
         od = lambda n: (n + 2 * pad - k) // stride + 1
         y = self.empty(x.shape[0], w.shape[0], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
         ws = self._ws("conv3d_fwd_workspace", d)
@@ -85,9 +85,9 @@ class RawOps:
                                         self._stream()), "conv3d_fwd")
         return y
 
-    def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1):
+    def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1, compute=0):
         dy, w = self.to(dy), self.to(w)
-        d = self.conv_desc(x_shape, w.shape[0], w.shape[2], stride, pad)
+        d = self.conv_desc(x_shape, w.shape[0], w.shape[2], stride, pad, compute=compute)
         dx = self.empty(*x_shape)
         ws = self._ws("conv3d_bwd_data_workspace", d)
         self._chk(self.fn("conv3d_bwd_data")(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel(), self._stream()),

@@ -226,3 +226,55 @@ def test_error_paths_gpu(hip):
     rc = L.m355_conv3d_fwd(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), None, None,
                            C.c_void_p(x.data_ptr()), None, 0, None)
     assert rc == -4 and b"workspace" in L.m355_last_error()
+
+
+@pytest.mark.parametrize("case", CONV3)
+def test_conv3d_bf16_compute_mode(hip, oracle, case):
+    """M355_COMPUTE_BF16: operands rounded to bf16 (RNE), fp32 accumulate.  Against the oracle run in
+    the same mode only the accumulation order differs (tolerance 3e-5 of the output scale); against
+    exact fp32 the operand rounding shows up at the 2^-8 level (bounded loosely here)."""
+    N, Ci, Co, D, H, W = case
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Co, Ci, 3, 3, 3, seed=2) * (1.0 / (27 * Ci) ** 0.5), rnd(Co, seed=3)
+    add = rnd(N, Co, D, H, W, seed=4)
+    yb = hip.conv3d_fwd(x, w, b, add, compute=1)
+    close(yb, oracle.conv3d_fwd(x, w, b, add, compute=1), 3e-5, 3e-5, "bf16 fwd vs bf16 oracle")
+    y32 = oracle.conv3d_fwd(x, w, b, add)
+    rel = (yb.cpu().double() - y32.double()).abs().max().item() / y32.abs().max().item()
+    assert rel < 2e-2, rel
+    dy = rnd(N, Co, D, H, W, seed=5)
+    close(hip.conv3d_bwd_data(dy, w, x.shape, compute=1), oracle.conv3d_bwd_data(dy, w, x.shape, compute=1), 3e-5, 3e-5,
+          "bf16 bwd_data vs bf16 oracle")
+
+
+def test_bf16_precision_mode_end_to_end(golden):
+    """cfg3-family precision mode on the small north-star model: probabilities within 2e-2 and soft
+    Dice within 1e-3 of the fp32 reference golden (tolerances stated for the bf16 configs in SURVEY §8d);
+    gradients flow; fp32 mode is restored afterwards."""
+    from functools import partial
+    from torch import nn
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+    from segmentation_pipeline_amd.models import ModularUNet
+    g = golden("unet_gn_convt.npz")
+    model = ModularUNet(4, 3, [8, 16, 32], 3, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                        upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+    model.load_state_dict(g.state_dict("m.sd."))
+    model = model.cuda().train()
+    x, y = g.t("x").cuda(), g.t("y").cuda()
+    with sp.precision("bf16"):
+        assert sp.get_precision() == "bf16"
+        p = model(x)
+        ld = HybridLogisticDiceLoss()(p, y)
+        ld["loss"].backward()
+    assert sp.get_precision() == "fp32"
+    err = (p.detach().cpu() - g.t("m.probs_train")).abs().max().item()
+    assert 1e-6 < err <= 2e-2, err                     # really a different arithmetic, within the stated tolerance
+    assert abs(ld["dice_loss"].item() - float(g["m.dice_loss"])) <= 1e-3
+    for k, v in model.named_parameters():
+        ref = g.t(f"m.grad.{k}").double().flatten()
+        got = v.grad.cpu().double().flatten()
+        assert torch.isfinite(got).all()
+        cos = torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30)
+        assert cos > 0.95, (k, cos.item())                # bf16 operand noise, same direction
+    with pytest.raises(ValueError):
+        sp.set_precision("fp8")

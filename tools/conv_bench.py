@@ -36,6 +36,7 @@ def main():
     ops = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd", "bwd_data", "bwd_weight"]
     layers = QUICK if "--quick" in sys.argv else CFG2
     hip = RawOps("hip")
+    compute = 1 if "--bf16" in sys.argv else 0
     tot = {o: [0.0, 0.0] for o in ops}
     print(f"{'layer':8s} {'Cin':>4s} {'Cout':>4s} {'S':>4s} " + " ".join(f"{o + ' ms':>14s} {'TF':>6s}" for o in ops))
     for name, ci, co, sp in layers:
@@ -46,9 +47,9 @@ def main():
         row = f"{name:8s} {ci:4d} {co:4d} {sp:4d} "
         for o in ops:
             if o == "fwd":
-                ms = timeit(lambda: hip.conv3d_fwd(x, w))
+                ms = timeit(lambda: hip.conv3d_fwd(x, w, compute=compute))
             elif o == "bwd_data":
-                ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape))
+                ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
             else:
                 ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False))
             tot[o][0] += ms
