@@ -46,7 +46,8 @@ enum { M355_F32 = 0 };
  *   M355_COMPUTE_F32  exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (default)
  *   M355_COMPUTE_BF16 operands rounded to bf16 (round-to-nearest-even) when they are staged,
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE cfg3 / cfg5 family).
- * Applies to conv3d fwd and bwd_data; the weight gradient always runs in exact fp32. */
+ * Applies to conv3d fwd, bwd_data and (when W % 32 == 0 and both channel counts > 4) bwd_weight;
+ * every other case of the weight gradient runs in exact fp32. */
 enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1 };
 
 /* activation fused into the normalise pass (components.py:26,54-55) */

@@ -158,8 +158,7 @@ int m355o_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const flo
               for (int ox = 0; ox < OW; ++ox) {
                 const int ix = ox * s + dxx - p;
                 if (ix < 0 || ix >= W) continue;
-                acc += (double)dyo[((int64_t)oz * OH + oy) * OW + ox] *
-                       (double)xc[((int64_t)iz * H + iy) * W + ix];
+                acc += OPND(d, dyo[((int64_t)oz * OH + oy) * OW + ox]) * OPND(d, xc[((int64_t)iz * H + iy) * W + ix]);
               }
             }
           }

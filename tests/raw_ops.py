@@ -94,10 +94,10 @@ class RawOps:
                   "conv3d_bwd_data")
         return dx
 
-    def conv3d_bwd_weight(self, x, dy, k, stride=1, pad=1, with_bias=True):
+    def conv3d_bwd_weight(self, x, dy, k, stride=1, pad=1, with_bias=True, compute=0):
         x, dy = self.to(x), self.to(dy)
         Cout = dy.shape[1]
-        d = self.conv_desc(x.shape, Cout, k, stride, pad)
+        d = self.conv_desc(x.shape, Cout, k, stride, pad, compute=compute)
         dw = self.empty(Cout, x.shape[1], k, k, k)
         db = self.empty(Cout) if with_bias else None
         ws = self._ws("conv3d_bwd_weight_workspace", d)

@@ -278,3 +278,26 @@ def test_bf16_precision_mode_end_to_end(golden):
         assert cos > 0.95, (k, cos.item())                # bf16 operand noise, same direction
     with pytest.raises(ValueError):
         sp.set_precision("fp8")
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 8, 16, 64), (2, 40, 33, 5, 6, 32), (1, 96, 64, 4, 4, 32)])
+def test_conv3d_bwd_weight_bf16_mode(hip, oracle, case):
+    """W % 32 == 0 and both channel counts > 4: bf16 weight-gradient kernel (three pre-shifted LDS
+    copies); checked against the oracle with bf16-rounded operands."""
+    N, Ci, Co, D, H, W = case
+    x, dy = rnd(N, Ci, D, H, W, seed=1), rnd(N, Co, D, H, W, seed=5)
+    dw_h, db_h = hip.conv3d_bwd_weight(x, dy, 3, compute=1)
+    dw_o, db_o = oracle.conv3d_bwd_weight(x, dy, 3, compute=1)
+    close(dw_h, dw_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, "bf16 bwd_weight vs bf16 oracle")
+    close(db_h, db_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, "dbias")
+    (d1, _), (d2, _) = hip.conv3d_bwd_weight(x, dy, 3, compute=1), hip.conv3d_bwd_weight(x, dy, 3, compute=1)
+    assert torch.equal(d1, d2)
+
+
+def test_conv3d_bwd_weight_bf16_mode_falls_back_to_exact_fp32(hip, oracle):
+    """Geometries the bf16 kernel does not cover (W % 32 != 0, tiny channel counts) stay exact fp32."""
+    for (N, Ci, Co, D, H, W) in [(1, 16, 16, 8, 8, 16), (1, 4, 32, 8, 8, 32)]:
+        x, dy = rnd(N, Ci, D, H, W, seed=1), rnd(N, Co, D, H, W, seed=5)
+        dw_h, _ = hip.conv3d_bwd_weight(x, dy, 3, compute=1)
+        dw_o, _ = oracle.conv3d_bwd_weight(x, dy, 3, compute=0)
+        close(dw_h, dw_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, "fallback")

@@ -51,7 +51,7 @@ def main():
             elif o == "bwd_data":
                 ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
             else:
-                ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False))
+                ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False, compute=compute))
             tot[o][0] += ms
             tot[o][1] += flops
             row += f"{ms:14.3f} {flops / ms / 1e9:6.1f} "
