@@ -420,6 +420,142 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
   }
 }
 
+// ------------------------------------------------------- forward, Cout <= 4 (out conv), fp32
+// A 32-row MFMA tile would carry only Cout useful rows.  z-Toeplitz packing fills the rows
+// with (o, s), s = 0..7 being eight consecutive output planes of one (y, x) column:
+//   y[o, z0+s, y, x] = sum_{c,dy,dx} sum_{u=0..9} Wz[(c,dy,dx,u), (o,s)] * x[c, z0-1+u, y+dy-1, x+dx-1]
+//   Wz[(c,dy,dx,u), (o,s)] = w[o,c,u-s,dy,dx] if 0 <= u-s <= 2 else 0
+// K grows by 10/3 but each MFMA column now yields 8 outputs: 2.4x fewer MFMAs than the padded tile.
+// Tile = 8 z x 8 y x 32 x; wave w owns rows y = 2w, 2w+1; 2 input channels (one MFMA k-pair) per chunk.
+constexpr int TZ_K = 90;  // (dy, dx, u) combinations
+__global__ void pack_w3_toeplitz_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                        int Cin, int kin_pad) {
+  const int64_t total = (int64_t)kin_pad * TZ_K * 32;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i & 31);
+    int64_t r = i >> 5;
+    const int t = (int)(r % TZ_K);
+    const int c = (int)(r / TZ_K);
+    const int u = t % 10, dyx = t / 10;  // dyx = dy*3 + dx
+    const int o = m >> 3, sft = m & 7;
+    const int dz = u - sft;
+    float v = 0.f;
+    if (c < Cin && o < Cout && dz >= 0 && dz <= 2) v = w[((int64_t)o * Cin + c) * 27 + dz * 9 + dyx];
+    wp[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_mfma_fwd_smallcout_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, int Cin, int Cout, int D, int H, int W,
+    int ty_tiles, int tx_tiles, int nchunks, int64_t xbs, int64_t ybs) {
+  constexpr int TZ = 8, TY = 8, TX = 32, RS = TX + 2, PS = (TY + 2) * RS, CS = (TZ + 2) * PS;
+  constexpr int XE = 2 * CS, XPER = (XE + 255) / 256;   // 6800 floats
+  constexpr int WE4 = 2 * TZ_K * 8, WPER = (WE4 + 255) / 256;
+  __shared__ float xs[XE];
+  __shared__ __attribute__((aligned(16))) float ws[2 * TZ_K * 32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  int bt = blockIdx.x;
+  const int txt = bt % tx_tiles;
+  bt /= tx_tiles;
+  const int tyt = bt % ty_tiles;
+  const int tzt = bt / ty_tiles;
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+  const int n = blockIdx.y;
+  const float* xn = x + (int64_t)n * xbs;
+  const int iHW = H * W, iDHW = D * H * W;
+
+  int goff[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    int off = -1;
+    if (e < XE) {
+      const int c = e / CS, r = e - c * CS;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) off = c * iDHW + gz * iHW + gy * W + gx;
+    }
+    goff[i] = off;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  const float* xb = xs + half * CS + (wave * 2) * RS + l32;
+  const float* wb = ws + half * (TZ_K * 32) + l32;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * 2;
+    __syncthreads();
+    {
+      float xr[XPER];
+      const float* xc = xn + (int64_t)c0 * iDHW;
+      const bool full = c0 + 2 <= Cin;
+#pragma unroll
+      for (int i = 0; i < XPER; ++i) {
+        bool ok = goff[i] >= 0;
+        if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
+        xr[i] = xc[ok ? goff[i] : 0];
+      }
+      f32x4 wr[WPER];
+      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (int64_t)c0 * TZ_K * 32);
+#pragma unroll
+      for (int j = 0; j < WPER; ++j) wr[j] = wsrc[min(tid + 256 * j, WE4 - 1)];
+#pragma unroll
+      for (int i = 0; i < XPER; ++i) {
+        bool ok = goff[i] >= 0;
+        if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
+        if (tid + 256 * i < XE) xs[tid + 256 * i] = ok ? xr[i] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < WPER; ++j)
+        if (tid + 256 * j < WE4) reinterpret_cast<f32x4*>(ws)[tid + 256 * j] = wr[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dyx = 0; dyx < 9; ++dyx) {
+      const int dy = dyx / 3, dx = dyx % 3;
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const float a = wb[(dyx * 10 + u) * 32];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const float b = xb[u * PS + (g + dy) * RS + dx];
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int xg = x0 + l32;
+  if (xg >= W) return;
+  float* yn = y + (int64_t)n * ybs;
+  const float* an = add ? add + (int64_t)n * ybs : nullptr;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int yg = y0 + wave * 2 + g;
+    if (yg >= H) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;  // row = o*8 + s
+      const int o = m >> 3, zg = z0 + (m & 7);
+      if (o < Cout && zg < D) {
+        const int64_t idx = (int64_t)o * iDHW + (int64_t)zg * iHW + (int64_t)yg * W + xg;
+        float v = acc[g][r];
+        if (bias) v += bias[o];
+        if (an) v += an[idx];
+        yn[idx] = v;
+      }
+    }
+  }
+}
+
 // y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                      const float* __restrict__ add, float* __restrict__ y, int N,
@@ -1181,6 +1317,14 @@ static bool is_k3s1p1(const m355_conv3d_desc* d) {
 
 static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
+// Cout <= 4 forward in exact fp32: z-Toeplitz packed rows instead of a mostly-empty 32-row tile
+static bool small_cout_fwd(const m355_conv3d_desc* d) {
+  return d->Cout <= 4 && d->compute == M355_COMPUTE_F32 && d->W >= 32 && d->D >= 8 && d->Cin >= 8 &&
+         !env_int("M355_NO_SMALL", 0) && (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 31);
+}
+static size_t small_cout_ws(const m355_conv3d_desc* d) {
+  return (size_t)round_up((int64_t)round_up(d->Cin, 2) * TZ_K * 32 * 4, 256);
+}
 static bool small_bww(const m355_conv3d_desc* d) {
   return (d->Cin <= 4 || d->Cout <= 4) && !env_int("M355_NO_SMALL", 0);
 }
@@ -1327,6 +1471,7 @@ using namespace m355;
 // ---------------------------------------------------------------------- ABI
 extern "C" size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
+  if (small_cout_fwd(d)) return small_cout_ws(d);
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes;
 }
@@ -1353,6 +1498,23 @@ extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const 
   M355_REQUIRE(OD > 0 && OH > 0 && OW > 0, M355_EINVALID_ARG, "conv3d_fwd: empty output");
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
+  if (is_k3s1p1(d) && small_cout_fwd(d)) {
+    M355_REQUIRE(workspace && workspace_bytes >= small_cout_ws(d), M355_EWORKSPACE,
+                 "conv3d_fwd: workspace too small (%zu < %zu)", workspace_bytes, small_cout_ws(d));
+    M355_REQUIRE(((uintptr_t)workspace & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
+    float* wpz = (float*)workspace;
+    const int kin_pad = (int)round_up(d->Cin, 2);
+    {
+      const int64_t total = (int64_t)kin_pad * TZ_K * 32;
+      hipLaunchKernelGGL(pack_w3_toeplitz_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)),
+                         dim3(256), 0, st, w, wpz, d->Cout, d->Cin, kin_pad);
+    }
+    const int tyt = (int)ceil_div(d->H, 8), txt = (int)ceil_div(d->W, 32);
+    dim3 grid((unsigned)(ceil_div(d->D, 8) * tyt * txt), (unsigned)d->N);
+    hipLaunchKernelGGL(conv3_mfma_fwd_smallcout_kernel, grid, dim3(256), 0, st, x, wpz, bias, add, y, d->Cin,
+                       d->Cout, d->D, d->H, d->W, tyt, txt, kin_pad / 2, xbs, ybs);
+    return check_launch("conv3_mfma_fwd_smallcout");
+  }
   if (is_k3s1p1(d)) {
     return run_mfma_conv(x, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
                          d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute);
@@ -1369,6 +1531,7 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
   out4[0] = out4[1] = out4[2] = out4[3] = 0;
   if (!is_k3s1p1(d)) return M355_OK;
+  if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
   out4[0] = 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;

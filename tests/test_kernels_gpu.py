@@ -36,6 +36,8 @@ CONV3 = [
     (1, 3, 3, 4, 4, 4),          # tiny: W < 8
     (1, 320, 64, 4, 4, 4),       # deep level: split-K over channel chunks
     (2, 16, 3, 6, 6, 40),        # out-conv family (Cout=3)
+    (1, 32, 3, 16, 16, 32),      # out conv on the z-Toeplitz small-Cout forward kernel
+    (2, 9, 2, 9, 10, 40),        # same kernel: odd Cin, ragged D/H/W, N=2
 ]
 
 
