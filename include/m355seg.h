@@ -137,6 +137,7 @@ typedef struct m355_norm_desc {
   float act_slope;          /* leaky relu negative slope */
   int64_t x_batch_stride;   /* elements; 0 = dense */
   int64_t y_batch_stride;
+  int64_t add_batch_stride; /* batch stride of the fused residual `add` (0 = dense C*S) */
 } m355_norm_desc;
 
 /* number of statistics: C for BN, N*groups for GN */

@@ -382,7 +382,8 @@ int m355o_norm_act_fwd(const m355_norm_desc* d, const float* x, const float* mea
       const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
       const float* xp = x + n * xbs + (int64_t)c * d->S;
       float* yp = y + n * ybs + (int64_t)c * d->S;
-      const float* ap = add ? add + n * ybs + (int64_t)c * d->S : NULL;
+      const int64_t abs_ = dense_or(d->add_batch_stride, (int64_t)d->C * d->S);
+      const float* ap = add ? add + n * abs_ + (int64_t)c * d->S : NULL;
       for (int64_t i = 0; i < d->S; ++i) {
         const float pre = (xp[i] - mean[s]) * rstd[s] * g + b;
         yp[i] = act_f(pre, d->act, d->act_slope) + (ap ? ap[i] : 0.f);

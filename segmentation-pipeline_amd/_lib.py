@@ -32,7 +32,7 @@ class NormDesc(C.Structure):
         ("N", C.c_int32), ("C", C.c_int32), ("S", C.c_int64),
         ("groups", C.c_int32), ("act", C.c_int32),
         ("eps", C.c_float), ("act_slope", C.c_float),
-        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64),
+        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64), ("add_batch_stride", C.c_int64),
     ]
 
 

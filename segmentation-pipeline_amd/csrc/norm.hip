@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ add,
     float* __restrict__ y, int C, int64_t S, int groups, int act, float slope, int64_t xbs,
-    int64_t ybs) {
+    int64_t ybs, int64_t abs_) {
   const int c = blockIdx.y, n = blockIdx.z;
   const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
   const float m = mean[s], r = rstd[s];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(
   const float sh = b - m * sc;
   const float* xp = x + (int64_t)n * xbs + (int64_t)c * S;
   float* yp = y + (int64_t)n * ybs + (int64_t)c * S;
-  const float* ap = add ? add + (int64_t)n * ybs + (int64_t)c * S : nullptr;
+  const float* ap = add ? add + (int64_t)n * abs_ + (int64_t)c * S : nullptr;
   if (VEC) {
     const int64_t S4 = S >> 2;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S4; i += gridDim.x * 256ll) {
@@ -333,7 +333,8 @@ static bool vec_ok(const m355_norm_desc* d, const void* a, const void* b, const 
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
-  return (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) && al(a) && al(b) && (!c || al(c));
+  const int64_t abs_ = dense_or(d->add_batch_stride, (int64_t)d->C * d->S);
+  return (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) && (abs_ % 4 == 0) && al(a) && al(b) && (!c || al(c));
 }
 
 }  // namespace m355
@@ -404,16 +405,17 @@ extern "C" int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const 
   hipStream_t st = (hipStream_t)stream;
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
+  const int64_t abs_ = dense_or(d->add_batch_stride, (int64_t)d->C * d->S);
   const bool vec = vec_ok(d, x, y, add);
   const int64_t work = vec ? d->S / 4 : d->S;
   const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
   dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
   if (vec)
     hipLaunchKernelGGL(norm_act_fwd_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma,
-                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs);
+                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_);
   else
     hipLaunchKernelGGL(norm_act_fwd_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma,
-                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs);
+                       beta, add, y, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_);
   return check_launch("norm_act_fwd");
 }
 

@@ -167,7 +167,10 @@ class _Conv3dFn(torch.autograd.Function):
         if add is not None:
             add, abs_ = _dense_channels(add)
             if abs_ != ybs:
-                raise _lib.M355Error("conv3d: `add` must share the output's batch stride")
+                add = add.contiguous()
+                if ybs != Cout * oshape[2] * oshape[3] * oshape[4]:
+                    raise _lib.M355Error("conv3d: a fused `add` needs the output's batch stride (write to a dense "
+                                         "tensor and copy_into the slot instead)")
         d = _conv_desc(N, Cin, Cout, D, H, W, k, meta.stride, meta.pad, xbs, ybs, compute=_COMPUTE[_compute_mode])
         ws = _workspace(L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
         prof = CONV_PROFILE
@@ -326,11 +329,10 @@ class _NormActFn(torch.autograd.Function):
             x, xbs = x.contiguous(), Cc * S
         y = _alloc_out(cfg.out, x.shape, x)
         y, ybs = _dense_channels(y)
+        abs_ = 0
         if add is not None:
             add, abs_ = _dense_channels(add)
-            if abs_ != ybs:
-                raise _lib.M355Error("norm_act: `add` must share the output's batch stride")
-        d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs)
+        d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs, abs_)
         ns = L.m355_norm_num_stats(C.byref(d))
         mean = torch.empty(ns, dtype=torch.float32, device=x.device)
         rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
@@ -358,7 +360,7 @@ class _NormActFn(torch.autograd.Function):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         d0 = ctx.desc
         dy, dybs = _dense_channels(dy)
-        d = NormDesc(d0.N, d0.C, d0.S, d0.groups, d0.act, d0.eps, d0.act_slope, d0.x_batch_stride, dybs)
+        d = NormDesc(d0.N, d0.C, d0.S, d0.groups, d0.act, d0.eps, d0.act_slope, d0.x_batch_stride, dybs, 0)
         dx = torch.empty_like(x)  # x was saved dense
         dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
         dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None

@@ -141,7 +141,7 @@ class RawOps:
     def norm_desc(x, groups, act=0, eps=1e-5, slope=0.01):
         N, Cc = x.shape[:2]
         S = x.numel() // (N * Cc)
-        return NormDesc(N, Cc, S, groups, act, eps, slope, 0, 0)
+        return NormDesc(N, Cc, S, groups, act, eps, slope, 0, 0, 0)
 
     def norm_stats(self, x, groups, eps=1e-5, running=None, momentum=0.1):
         x = self.to(x)

@@ -40,9 +40,9 @@ def test_host_side_queries_and_argument_validation():
     d = _lib.ConvDesc(1, 4, 32, 128, 128, 128, 3, 1, 1, 0, 0, 0)
     assert L.m355_conv3d_fwd_workspace(ctypes.byref(d)) >= 4 * 27 * 32 * 4
     assert L.m355_conv3d_bwd_weight_workspace(ctypes.byref(d)) > 0
-    nd = _lib.NormDesc(2, 32, 4096, 8, 1, 1e-5, 0.0, 0, 0)
+    nd = _lib.NormDesc(2, 32, 4096, 8, 1, 1e-5, 0.0, 0, 0, 0)
     assert L.m355_norm_num_stats(ctypes.byref(nd)) == 16
-    nd_bn = _lib.NormDesc(2, 32, 4096, 0, 1, 1e-5, 0.0, 0, 0)
+    nd_bn = _lib.NormDesc(2, 32, 4096, 0, 1, 1e-5, 0.0, 0, 0, 0)
     assert L.m355_norm_num_stats(ctypes.byref(nd_bn)) == 32
     assert L.m355_norm_workspace(ctypes.byref(nd)) > 0
     assert L.m355_hybrid_loss_workspace(1, 3, 128 ** 3) > 0
@@ -52,7 +52,7 @@ def test_host_side_queries_and_argument_validation():
     assert rc == -1 and b"conv3d_fwd" in L.m355_last_error()
     rc = L.m355_avgpool3d_2x_fwd(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 1, 3, 4, 4, 0, 0, None)
     assert rc == -2 and b"odd" in L.m355_last_error()
-    gn = _lib.NormDesc(1, 30, 64, 8, 0, 1e-5, 0.0, 0, 0)
+    gn = _lib.NormDesc(1, 30, 64, 8, 0, 1e-5, 0.0, 0, 0, 0)
     rc = L.m355_norm_act_fwd(ctypes.byref(gn), None, None, None, None, None, None, None, None)
     assert rc == -1 and b"divisible" in L.m355_last_error()
 

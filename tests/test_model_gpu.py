@@ -334,3 +334,32 @@ def test_device_side_samplers_on_gpu():
     (patches, pmaps), loc = WeightedSampler(8)(vol, pm, 5, generator=g, extra=[pm])
     assert (loc.cpu() == torch.tensor([6, 5, 7], dtype=torch.int32)).all()
     assert (pmaps[:, 0, 4, 4, 4] == 1.0).all()
+
+
+@pytest.mark.parametrize("norm", ["group", "batch"])
+def test_residual_blocks_with_batch_gt1_match_cpu_oracle(norm):
+    """Residual Block3d (components.py:41-46,67-68) with N = 2: the fused residual add is dense while
+    the block output is a strided concat slot (regression: they need separate batch strides)."""
+    from oracle import torch_ref as R
+    torch.manual_seed(5)
+    bp = {'residual': True}
+    if norm == "group":
+        bp.update(GN8)
+    model = ModularUNet(3, 2, [8, 16], 2, block_params=bp, **CONVT)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn((2, 3, 8, 8, 16), generator=g)
+    lab = torch.randint(0, 2, (2, 8, 8, 16), generator=g)
+    y = torch.nn.functional.one_hot(lab, 2).permute(0, 4, 1, 2, 3).float().contiguous()
+    spec = R.UNetSpec(3, 2, [8, 16], 2, norm=norm, groups=8, up="convT", residual=True)
+    p_ref = R.unet_forward(sd, spec, x, training=True)
+    ld_ref = R.hybrid_logistic_dice_loss(p_ref, y)
+    ld_ref["loss"].backward()
+    model = model.cuda().train()
+    p = model(x.cuda())
+    assert maxerr(p, p_ref.detach()) <= PROB_TOL
+    ld = HybridLogisticDiceLoss()(p, y.cuda())
+    ld["loss"].backward()
+    for k, v in model.named_parameters():
+        grad_close(v.grad, sd[k].grad, k)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Step time of the two architectures the reference actually trained."""
+import os, sys, time, torch
+from torch import nn
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from segmentation_pipeline_amd.models import ModularUNet, NestedResUNet, BlurConv3d, BlurConvTranspose3d
+from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+
+def run(name, model, shape, ncls, cw=None, steps=3):
+    model = model.cuda()
+    crit = HybridLogisticDiceLoss(logistic_class_weights=cw)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)
+    x = torch.randn(shape, device="cuda")
+    lab = torch.randint(0, ncls, (shape[0],) + tuple(shape[2:]), device="cuda")
+    y = torch.nn.functional.one_hot(lab, ncls).permute(0, 4, 1, 2, 3).float().contiguous()
+    def step():
+        model.train(); ld = crit(model(x), y); opt.zero_grad(); ld["loss"].backward(); opt.step(); model.eval()
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps): step()
+    torch.cuda.synchronize(); t_train = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        model(x); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps): model(x)
+        torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
+    print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)", flush=True)
+
+torch.manual_seed(0)
+run("msseg2 ModularUNet(2,2,[40,40,80,80,120,120],6,residual,Blur) 1x2x96^3",
+    ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
+                downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
+                upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0}),
+    (1, 2, 96, 96, 96), 2, [1, 100])
+run("dmri_hippo NestedResUNet(3,2,40) 8x3x48x88x24 (sagittal split of 4x3x96x88x24)",
+    NestedResUNet(3, 2, 40), (8, 3, 48, 88, 24), 2)
