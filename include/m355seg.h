@@ -231,6 +231,17 @@ int m355_channel_scale(const float* x, const float* scale, float* y, int32_t N, 
 /* y = a + b (dense, n elements): residual add when not fused. */
 int m355_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 
+/* Space-to-depth / depth-to-space by 2 along D, H, W (each other's inverse and adjoint):
+ *   s2d: y[n, c*8 + p, z, y, x] = x[n, c, 2z+pz, 2y+py, 2x+px],  p = pz*4 + py*2 + px   (input D,H,W even)
+ *   d2s: the inverse; D,H,W below are always those of the FULL-resolution tensor.
+ * They turn the reference's strided Blur convolutions (components.py:91-154: effective 4x4x4 kernel,
+ * stride 2, padding 1) into stride-1 3x3x3 convolutions that run on the MFMA path:
+ *   BlurConv3d:          conv3(s2d(x), W') ;   BlurConvTranspose3d: d2s(conv3(x, W'')). */
+int m355_space_to_depth2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                         int64_t x_batch_stride, int64_t y_batch_stride, void* stream);
+int m355_depth_to_space2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                         int64_t x_batch_stride, int64_t y_batch_stride, void* stream);
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio
  * 0.18.45 GridSampler / GridAggregator(overlap_mode='average').  These entry

@@ -680,6 +680,29 @@ int m355o_add(const float* a, const float* b, float* y, int64_t n, void* stream)
   return 0;
 }
 
+/* space-to-depth / depth-to-space by 2: pure index permutations used to run the reference's strided
+ * Blur convolutions (models/components.py:91-154) as stride-1 3x3x3 convolutions */
+static int s2d_o(const float* x, float* y, int N, int C, int D, int H, int W, int64_t xbs_, int64_t ybs_, int to_depth) {
+  const int64_t dense = (int64_t)C * D * H * W;
+  const int64_t fbs = dense_or(to_depth ? xbs_ : ybs_, dense), pbs = dense_or(to_depth ? ybs_ : xbs_, dense);
+  const int HD = D / 2, HH = H / 2, HW2 = W / 2;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (int z = 0; z < D; ++z)
+        for (int yy = 0; yy < H; ++yy)
+          for (int xx = 0; xx < W; ++xx) {
+            const int p = (z & 1) * 4 + (yy & 1) * 2 + (xx & 1);
+            const int64_t f = n * fbs + (((int64_t)c * D + z) * H + yy) * W + xx;
+            const int64_t q = n * pbs + ((((int64_t)c * 8 + p) * HD + z / 2) * HH + yy / 2) * HW2 + xx / 2;
+            if (to_depth) y[q] = x[f]; else y[f] = x[q];
+          }
+  return 0;
+}
+int m355o_space_to_depth2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                          int64_t xbs, int64_t ybs, void* stream) { (void)stream; return s2d_o(x, y, N, C, D, H, W, xbs, ybs, 1); }
+int m355o_depth_to_space2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                          int64_t xbs, int64_t ybs, void* stream) { (void)stream; return s2d_o(x, y, N, C, D, H, W, xbs, ybs, 0); }
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict: prediction.py:132-143.  The arithmetic lives in torchio 0.18.45
  * (GridSampler / GridAggregator overlap_mode='average'), absent from the reference tree:

@@ -276,9 +276,71 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
   }
 }
 
+// ---------------------------------------------- space-to-depth / depth-to-space (factor 2)
+// TO_DEPTH: full[n,c,2z+pz,2y+py,2x+px] -> packed[n,c*8+p,z,y,x]; otherwise the inverse.
+// One thread per (row pair of the full tensor): reads/writes float2 on the full-resolution side.
+template <bool TO_DEPTH>
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                                  int C, int D, int H, int W, int64_t fbs, int64_t pbs) {
+  // D,H,W: full resolution.  fbs / pbs: batch strides of the full / packed tensors.
+  const int HD = D / 2, HH = H / 2, HW2 = W / 2;
+  const int64_t total = (int64_t)N * C * D * H * HW2;  // one float2 of the full tensor per thread
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int xh = (int)(i % HW2);
+    int64_t r = i / HW2;
+    const int fy = (int)(r % H);
+    r /= H;
+    const int fz = (int)(r % D);
+    r /= D;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const int64_t fidx = (int64_t)n * fbs + (((int64_t)c * D + fz) * H + fy) * W + 2 * xh;
+    const int p0 = ((fz & 1) * 4 + (fy & 1) * 2);
+    const int64_t pidx = (int64_t)n * pbs + ((((int64_t)c * 8 + p0) * HD + (fz >> 1)) * HH + (fy >> 1)) * HW2 + xh;
+    const int64_t pstep = (int64_t)HD * HH * HW2;  // px = 1 is the next packed channel
+    if (TO_DEPTH) {
+      const float2 v = *reinterpret_cast<const float2*>(src + fidx);
+      dst[pidx] = v.x;
+      dst[pidx + pstep] = v.y;
+    } else {
+      *reinterpret_cast<float2*>(dst + fidx) = make_float2(src[pidx], src[pidx + pstep]);
+    }
+  }
+}
+
 }  // namespace m355
 
 using namespace m355;
+
+static int s2d_common(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W, int64_t xbs_,
+                      int64_t ybs_, void* stream, bool to_depth, const char* who) {
+  M355_REQUIRE(x && y, M355_EINVALID_ARG, "%s: null pointer", who);
+  M355_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, M355_EINVALID_ARG, "%s: non-positive dimension", who);
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED, "%s: odd spatial size (%d,%d,%d)", who,
+               D, H, W);
+  const int64_t dense = (int64_t)C * D * H * W;
+  // to_depth: x is the full tensor; otherwise y is
+  const int64_t fbs = dense_or(to_depth ? xbs_ : ybs_, dense), pbs = dense_or(to_depth ? ybs_ : xbs_, dense);
+  const float* full = to_depth ? x : y;
+  M355_REQUIRE(((uintptr_t)full & 7) == 0 && fbs % 2 == 0, M355_EUNSUPPORTED, "%s: full tensor not 8-byte aligned", who);
+  const int64_t total = (int64_t)N * C * D * H * (W / 2);
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), 16384));
+  if (to_depth)
+    hipLaunchKernelGGL(s2d_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, C, D, H, W, fbs, pbs);
+  else
+    hipLaunchKernelGGL(s2d_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, C, D, H, W, fbs,
+                       pbs);
+  return check_launch(who);
+}
+
+extern "C" int m355_space_to_depth2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                    int64_t x_batch_stride, int64_t y_batch_stride, void* stream) {
+  return s2d_common(x, y, N, C, D, H, W, x_batch_stride, y_batch_stride, stream, true, "space_to_depth2");
+}
+extern "C" int m355_depth_to_space2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                    int64_t x_batch_stride, int64_t y_batch_stride, void* stream) {
+  return s2d_common(x, y, N, C, D, H, W, x_batch_stride, y_batch_stride, stream, false, "depth_to_space2");
+}
 
 static int check_ncdhw(int N, int C, int D, int H, int W, const char* who) {
   M355_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, M355_EINVALID_ARG,

@@ -24,7 +24,9 @@ def _run_downsample(m, x):
         if k != 2 or s != 2 or _uniform_int(m.padding, "padding") != 0 or m.ceil_mode:
             raise NotImplementedError("only AvgPool3d(kernel_size=2, stride=2) has a HIP kernel")
         return ops.avgpool3d_2x(x)
-    if isinstance(m, nn.Conv3d):  # BlurConv3d / WSConv3d / strided nn.Conv3d
+    if isinstance(m, BlurConv3d):
+        return m(x)
+    if isinstance(m, nn.Conv3d):  # WSConv3d / strided nn.Conv3d
         return run_conv(m, x)
     raise NotImplementedError(f"downsample_class {type(m).__name__} has no HIP kernel")
 

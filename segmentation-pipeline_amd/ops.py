@@ -586,6 +586,51 @@ def copy_into(x, out: OutSlot):
     return _CopyIntoFn.apply(x, out)
 
 
+class _S2DFn(torch.autograd.Function):
+    """space-to-depth (to_depth=True) or depth-to-space by 2; each is the other's backward."""
+
+    @staticmethod
+    def forward(ctx, x, to_depth, out):
+        L = _lib.lib()
+        _require(x)
+        x, xbs = _dense_channels(x)
+        N, Cc, D, H, W = x.shape
+        if to_depth:
+            full = (N, Cc, D, H, W)
+            y = _alloc_out(out, (N, Cc * 8, D // 2, H // 2, W // 2), x)
+        else:
+            full = (N, Cc // 8, 2 * D, 2 * H, 2 * W)
+            y = _alloc_out(out, full, x)
+        y, ybs = _dense_channels(y)
+        fn = L.m355_space_to_depth2 if to_depth else L.m355_depth_to_space2
+        check(fn(_p(x), _p(y), full[0], full[1], full[2], full[3], full[4], xbs, ybs, _stream()),
+              "space_to_depth2" if to_depth else "depth_to_space2")
+        ctx.to_depth, ctx.full = to_depth, full
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        dy, dybs = _dense_channels(dy)
+        N, Cf, D, H, W = ctx.full
+        if ctx.to_depth:   # gradient of s2d is d2s
+            dx = torch.empty(ctx.full, dtype=dy.dtype, device=dy.device)
+            check(L.m355_depth_to_space2(_p(dy), _p(dx), N, Cf, D, H, W, dybs, 0, _stream()), "depth_to_space2")
+        else:
+            dx = torch.empty((N, Cf * 8, D // 2, H // 2, W // 2), dtype=dy.dtype, device=dy.device)
+            check(L.m355_space_to_depth2(_p(dy), _p(dx), N, Cf, D, H, W, dybs, 0, _stream()), "space_to_depth2")
+        return dx, None, None
+
+
+def space_to_depth2(x):
+    """[N, C, D, H, W] -> [N, 8C, D/2, H/2, W/2], channel c*8 + (pz*4 + py*2 + px)."""
+    return _S2DFn.apply(x, True, None)
+
+
+def depth_to_space2(x, out: Optional[OutSlot] = None):
+    return _S2DFn.apply(x, False, out)
+
+
 # --------------------------------------------------- sliding window / evaluation
 def patch_gather(volume, locations, patch_size):
     """volume [C,V0,V1,V2], locations int32 [P,3] (i0,j0,k0) -> patches [P,C,*patch_size]"""

@@ -207,6 +207,21 @@ class RawOps:
                   "upsample_bwd")
         return dx
 
+    def space_to_depth(self, x):
+        x = self.to(x)
+        N, Cc, D, H, W = x.shape
+        y = self.empty(N, Cc * 8, D // 2, H // 2, W // 2)
+        self._chk(self.fn("space_to_depth2")(_p(x), _p(y), N, Cc, D, H, W, 0, 0, self._stream()), "space_to_depth2")
+        return y
+
+    def depth_to_space(self, x):
+        x = self.to(x)
+        N, C8, D, H, W = x.shape
+        y = self.empty(N, C8 // 8, 2 * D, 2 * H, 2 * W)
+        self._chk(self.fn("depth_to_space2")(_p(x), _p(y), N, C8 // 8, 2 * D, 2 * H, 2 * W, 0, 0, self._stream()),
+                  "depth_to_space2")
+        return y
+
     def softmax_fwd(self, x, inner=1, diag_bias=0.0):
         x = self.to(x)
         N, Ct = x.shape[:2]

@@ -162,6 +162,57 @@ def test_pool_upsample_softmax(hip, oracle):
         close(hip.softmax_bwd(yo, dy, inner), oracle.softmax_bwd(yo, dy, inner), 1e-5, 1e-6, "softmax bwd")
 
 
+def test_space_to_depth_roundtrip(hip, oracle):
+    for shape in [(1, 3, 4, 6, 8), (2, 5, 2, 2, 6), (1, 2, 16, 16, 32)]:
+        x = rnd(*shape, seed=1)
+        yo = oracle.space_to_depth(x)
+        yh = hip.space_to_depth(x)
+        assert torch.equal(yh.cpu(), yo), "s2d is a permutation: bit-exact"
+        assert torch.equal(hip.depth_to_space(yh).cpu(), x)
+        assert torch.equal(hip.depth_to_space(yo).cpu(), oracle.depth_to_space(yo))
+    # odd sizes are refused, not silently truncated
+    with pytest.raises(RuntimeError):
+        hip.space_to_depth(rnd(1, 1, 3, 4, 4, seed=2))
+
+
+def test_blur_convs_mfma_path_matches_direct_kernels():
+    """BlurConv3d / BlurConvTranspose3d route through s2d + 3x3x3 MFMA conv; compare values and all
+    gradients with the generic direct stride-2 kernels on the same effective filter, and check that
+    the transposed conv writes straight into a concat slot."""
+    import segmentation_pipeline_amd.ops as ops
+    from segmentation_pipeline_amd.models import BlurConv3d, BlurConvTranspose3d
+    torch.manual_seed(0)
+    bc = BlurConv3d(12, 12, 3, stride=2, padding=1).cuda()
+    x = torch.randn(2, 12, 8, 12, 16, device="cuda", requires_grad=True)
+    dy = torch.randn(2, 12, 4, 6, 8, device="cuda")
+    y = bc(x)
+    y.backward(dy)
+    got = (y.detach().clone(), x.grad.clone(), bc.weight.grad.clone())
+    x.grad = None
+    bc.weight.grad = None
+    w4, _ = bc.effective()
+    y2 = ops.conv3d(x, w4, None, stride=2, padding=1)
+    y2.backward(dy)
+    for a, b, what in zip(got, (y2, x.grad, bc.weight.grad), ("y", "dx", "dw")):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), what
+
+    bt = BlurConvTranspose3d(12, 12, 3, stride=2, padding=1, output_padding=0).cuda()
+    x = torch.randn(2, 12, 4, 6, 8, device="cuda", requires_grad=True)
+    dy = torch.randn(2, 12, 8, 12, 16, device="cuda")
+    buf = torch.zeros(2, 20, 8, 12, 16, device="cuda")
+    y = bt(x, out=ops.OutSlot(buf, 8, 20))
+    assert y.data_ptr() == buf[:, 8:].data_ptr() and torch.count_nonzero(buf[:, :8]) == 0
+    y.backward(dy)
+    got = (y.detach().clone(), x.grad.clone(), bt.weight.grad.clone())
+    x.grad = None
+    bt.weight.grad = None
+    from segmentation_pipeline_amd.models.components import _box_blur
+    y2 = ops.conv_transpose3d(x, _box_blur(bt.weight, bt.kernel), None, stride=2, padding=1, output_padding=0)
+    y2.backward(dy)
+    for a, b, what in zip(got, (y2, x.grad, bt.weight.grad), ("y", "dx", "dw")):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), "T " + what
+
+
 @pytest.mark.parametrize("cfg", [(0.5, None, True), (0.3, [1.0, 2.0, 3.0], False), (0.5, [1.0, 100.0, 1.0], True)])
 def test_hybrid_loss_fwd_bwd(hip, oracle, cfg):
     dw, cw, sq = cfg

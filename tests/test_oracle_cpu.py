@@ -130,6 +130,31 @@ def test_c_pool_upsample_softmax_match_torch(oracle):
     close(oracle.softmax_bwd(y, dy), x.grad, 1e-5, 1e-7)
 
 
+def _s2d_torch(x):
+    N, Cc, D, H, W = x.shape
+    return x.reshape(N, Cc, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(
+        N, Cc * 8, D // 2, H // 2, W // 2)
+
+
+def test_c_space_to_depth_and_blur_identities(oracle):
+    """s2d/d2s are exact permutations, and the reference's strided Blur convolutions
+    (models/components.py:119,152: 4x4x4 effective filter, stride 2, padding 1) equal a stride-1
+    3x3x3 convolution over the s2d input / followed by d2s."""
+    from segmentation_pipeline_amd.models.components import _D2S_TAP, _S2D_TAP, _expand_4x4x4
+    x = rnd(2, 3, 4, 6, 8, seed=1)
+    y = oracle.space_to_depth(x)
+    assert torch.equal(y, _s2d_torch(x))
+    assert torch.equal(oracle.depth_to_space(y), x)
+
+    xd, w4 = x.double(), rnd(5, 3, 4, 4, 4, seed=2).double()
+    wexp = _expand_4x4x4(w4, _S2D_TAP).reshape(5, 24, 3, 3, 3)
+    close(F.conv3d(_s2d_torch(xd), wexp, padding=1), F.conv3d(xd, w4, stride=2, padding=1), 1e-12, 1e-12)
+    wt = rnd(3, 5, 4, 4, 4, seed=3).double()
+    wexp = _expand_4x4x4(wt, _D2S_TAP).permute(1, 2, 0, 3).reshape(40, 3, 3, 3, 3)
+    got = oracle.depth_to_space(F.conv3d(xd, wexp, padding=1).float())
+    close(got, F.conv_transpose3d(xd, wt, stride=2, padding=1).float(), 1e-6, 1e-6)
+
+
 def test_c_patches_and_confusion(oracle):
     vol = rnd(2, 9, 8, 7, seed=1)
     locs = R.grid_locations((9, 8, 7), (4, 4, 4), (1, 1, 1))
