@@ -24,21 +24,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   bwd-weight dW[ci,m] =           sum_v  X[ci, v] * dYr[m, v]         M = Cin, N = 8*Cout, K = voxels
 // where dYr[m, v] = dY[o, 2z+a, 2y+b, 2x+c] is the output block gathered per input voxel and
 // the torch weight layout [Cin][Cout][2][2][2] is already W[ci][m] with m contiguous.
-// All three are HBM-bound (AI ~ 28 flop/B); the MFMA only has to keep up with the stream.
-// Small accumulator footprints -> several workgroups per CU hide the synchronous staging.
+// AI ~ 28 flop/B: right at the fp32-MFMA / HBM ridge, so each kernel reads its large operand
+// exactly once and overlaps the stream with the MFMAs (register prefetch of the next K slab while
+// the current one is multiplied out of LDS; several workgroups per CU).
 
-// ---- forward: workgroup = 256 consecutive input voxels (wave w: 2 groups of 32), loops over
-// the 32-row m-tiles (4 output channels each).  The x tile [KC ci][256] is staged once when
-// Cin <= KC.  C/D layout puts t = (r&3) + 4*half on the lane's registers, so (r, r+1) is the
-// (c=0, c=1) pair of one (o, a, b): float2 stores, 256 B contiguous per 32 lanes.
-constexpr int CTF_KC = 64;
-constexpr int CTF_MTG = 4;  // m-tiles (of 4 output channels) per workgroup
+// ---- forward: workgroup = NVT consecutive input voxels, the whole [Cin][NVT] x tile resident in
+// LDS (read once); the four waves walk different 32-row m-tiles (4 output channels each) and read
+// their weights straight from L2 as the MFMA A operand.  C/D layout puts t = (r&3) + 4*half on the
+// lane's registers, so (r, r+1) is the (c=0, c=1) pair of one (o, a, b): float2 stores, 256 B
+// contiguous per 32 lanes.
+template <int NVT>
 __global__ __launch_bounds__(256) void convt_k2s2_fwd_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ y, int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs) {
-  constexpr int NVT = 256, KC = CTF_KC;
-  __shared__ float xs[KC * NVT];
-  __shared__ float ws[KC * 32];
+    float* __restrict__ y, int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs, int mt_per_wg) {
+  extern __shared__ float xs[];  // [CinR][NVT], CinR = Cin rounded up to a whole chunk (rows >= Cin are zero)
+  constexpr int NG = NVT / 32, P = 256 / NVT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
@@ -47,225 +47,323 @@ __global__ __launch_bounds__(256) void convt_k2s2_fwd_mfma_kernel(
   const int n = blockIdx.z;
   const float* xn = x + (int64_t)n * xbs;
   float* yn = y + (int64_t)n * ybs;
-  const int nchunks = (Cin + KC - 1) / KC;
-  const int mtiles = (Cout + 3) / 4;
-  // blockIdx.y owns CTF_MTG consecutive m-tiles (16 output channels): more workgroups in flight,
-  // and concurrent workgroups write different output planes
-  const int mt_begin = blockIdx.y * CTF_MTG, mt_end = min(mtiles, mt_begin + CTF_MTG);
+  constexpr int KC = 8;  // k-pairs per weight chunk
+  const int Cin2 = (Cin + 2 * KC - 1) / (2 * KC) * (2 * KC);
   const int OH = 2 * H, OW = 2 * W;
   const int64_t OS = (int64_t)S * 8;
-
-  // output coordinates of this lane's two voxels
-  int64_t obase[2];
-  bool vok[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int v = v0 + (wave * 2 + g) * 32 + l32;
-    vok[g] = v < S;
-    const int vv = vok[g] ? v : 0;
-    const int ix = vv % W, iy = (vv / W) % H, iz = vv / (W * H);
-    obase[g] = ((int64_t)(2 * iz + half) * OH + 2 * iy) * OW + 2 * ix;  // a = half
+  {
+    const int sv = tid % NVT, part = tid / NVT;
+    const bool vin = v0 + sv < S;
+    const float* xp = xn + (vin ? v0 + sv : 0);
+#pragma unroll 16
+    for (int c = part; c < Cin2; c += P) {
+      const bool ok = vin && c < Cin;
+      const float val = xp[ok ? (int64_t)c * S : 0];  // unconditional load from a clamped address
+      xs[c * NVT + sv] = ok ? val : 0.f;
+    }
   }
-
-  for (int mt = mt_begin; mt < mt_end; ++mt) {
-    const int o0 = mt * 4;
-    f32x16 acc[2];
+  __syncthreads();
+  const int mtiles = (Cout + 3) / 4;
+  const int mt_begin = blockIdx.y * mt_per_wg, mt_end = min(mtiles, mt_begin + mt_per_wg);
+  const int wrow = Cout * 8;  // weight offsets fit 32 bits (host: convt_fits_i32)
+  // output offsets of this lane's voxels (a = half)
+  int64_t obase[NG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g) {
+    const int v = min(v0 + g * 32 + l32, S - 1);
+    const int ix = v % W, iy = (v / W) % H, iz = v / (W * H);
+    obase[g] = ((int64_t)(2 * iz + half) * OH + 2 * iy) * OW + 2 * ix;
+  }
+  // weights: KC k-pairs per chunk in registers; the next chunk (possibly of the next m-tile) is in
+  // flight during the MFMAs of the current one
+  float a_cur[KC], a_nxt[KC];
+  // raw loads from clamped addresses; the zero mask is applied when the chunk becomes current
+  // (a select right after the load would make the wave wait for it before the MFMAs)
+  auto wload = [&](float* a, int mt, int k0) {
+    const int col = min(mt * 32 + l32, Cout * 8 - 1);  // always in bounds: no select, no branch
+#pragma unroll
+    for (int j = 0; j < KC; ++j) a[j] = w[min(k0 + 2 * j + half, Cin - 1) * wrow + col];
+  };
+  auto wmask = [&](float* dst, const float* src, int mt, int k0) {
+    const bool ook = mt * 4 + (l32 >> 3) < Cout;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) dst[j] = (ook && k0 + 2 * j + half < Cin) ? src[j] : 0.f;
+  };
+  const float* xb = xs + half * NVT + l32;
+  int mt = mt_begin + wave;
+  if (mt < mt_end) {
+    wload(a_nxt, mt, 0);
+    wmask(a_cur, a_nxt, mt, 0);
+  }
+  while (mt < mt_end) {
+    const int o0 = mt * 4;
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int c0 = ch * KC;
-      const int kc = min(KC, Cin - c0);
-      __syncthreads();
-      if (nchunks > 1 || mt == mt_begin) {
-        const int v = v0 + tid;
-        const bool vin = v < S;
-        const float* xp = xn + (int64_t)c0 * S + (vin ? v : 0);
-        // unconditional loads (clamped), all KC rows written (rows >= kc are zero)
-#pragma unroll 16
-        for (int c = 0; c < KC; ++c) {
-          const bool ok = vin && c < kc;
-          const float val = xp[ok ? (int64_t)c * S : 0];
-          xs[c * NVT + tid] = ok ? val : 0.f;
+    for (int k0 = 0; k0 < Cin2; k0 += 2 * KC) {
+      const bool last = k0 + 2 * KC >= Cin2;
+      const int nmt = last ? mt + 4 : mt, nk0 = last ? 0 : k0 + 2 * KC;
+      if (nmt < mt_end) wload(a_nxt, nmt, nk0);
+      // branch-free chunk: the LDS reads of step j+1 are issued before the MFMAs of step j
+      float bq[2][NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bq[0][g] = xb[k0 * NVT + g * 32];
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        if (j + 1 < KC) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) bq[(j + 1) & 1][g] = xb[(k0 + 2 * j + 2) * NVT + g * 32];
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks each read to just before its MFMA
 #pragma unroll
-      for (int j = 0; j < KC * 32 / 256; ++j) {
-        const int i = tid + 256 * j;
-        const int c = i >> 5, m = i & 31;
-        const int o = o0 + (m >> 3);
-        const bool ok = c < kc && o < Cout;
-        const float val = w[ok ? ((int64_t)(c0 + c) * Cout + o) * 8 + (m & 7) : 0];
-        ws[i] = ok ? val : 0.f;
+        for (int g = 0; g < NG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bq[j & 1][g], acc[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
-      const float* wb = ws + half * 32 + l32;
-      const float* xb = xs + half * NVT + wave * 64 + l32;
-      const int kce = (kc + 7) & ~7;  // rows up to KC are zero-filled
-#pragma unroll 1
-      for (int k = 0; k < kce; k += 8) {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk += 2) {
-          const float a = wb[(k + kk) * 32];
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[(k + kk) * NVT + g * 32], acc[g], 0, 0, 0);
-        }
-      }
+      wmask(a_cur, a_nxt, nmt, nk0);
     }
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      if (!vok[g]) continue;
+    for (int q = 0; q < 4; ++q) {  // q = output channel inside the tile (r >> 2)
+      const int o = o0 + q;
+      if (o >= Cout) continue;
+      const float bv = bias ? bias[o] : 0.f;
+      float* yo = yn + (int64_t)o * OS;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {  // q = output channel inside the tile (r >> 2)
-        const int o = o0 + q;
-        if (o >= Cout) continue;
-        const float bv = bias ? bias[o] : 0.f;
-        float* yo = yn + (int64_t)o * OS + obase[g];
+      for (int g = 0; g < NG; ++g) {
+        if (v0 + g * 32 + l32 >= S) continue;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          *reinterpret_cast<float2*>(yo + (int64_t)b * OW) =
+          *reinterpret_cast<float2*>(yo + obase[g] + (int64_t)b * OW) =
               make_float2(acc[g][q * 4 + b * 2] + bv, acc[g][q * 4 + b * 2 + 1] + bv);
       }
     }
+    mt += 4;
   }
 }
 
-// ---- data gradient: workgroup = 256 input voxels x 64 input channels (2 m-tiles, so dY is read
-// once for Cin <= 64); K is walked 4 output channels (32 k) at a time.  dY is de-interleaved
-// while staging: dys[(o,t)][v], the k-pair is (c=0, c=1) of one (o,a,b).
+// ---- data gradient: workgroup = NVT input voxels x 32*MT input channels; K is walked 4 output
+// channels (32 k) at a time.  dY is de-interleaved while staging (dys[(o,t)][v]; the k-pair is
+// (c=0, c=1) of one (o,a,b)); the next slab's global loads are in flight while the current one is
+// multiplied.  Waves tile [MT m-tiles] x [NVT/32 n-tiles] as WM x WN.
+template <int NVT, int MT>
 __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
     int Cout, int D, int H, int W, int64_t xbs, int64_t ybs) {
-  constexpr int NVT = 256, KO = 4, KK = KO * 8;
+  constexpr int KO = 4, KK = KO * 8;
+  constexpr int P = 256 / NVT, ROWS = 16 / P;        // float2 rows staged per thread
+  constexpr int CT = 32 * MT, WSS = CT + 1, WPT = CT * KK / 256;
+  constexpr int WN = (NVT / 32 < 4) ? NVT / 32 : 4, WM = 4 / WN;
+  constexpr int NGW = NVT / 32 / WN, MTW = MT / WM;
+  static_assert(MT % WM == 0 && NGW >= 1, "wave tiling");
   __shared__ float dys[KK * NVT];
-  __shared__ float ws[KK * 65];
+  __shared__ float ws[KK * WSS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_n = wave % WN, wave_m = wave / WN;
   const int half = lane >> 5, l32 = lane & 31;
   const int S = D * H * W;
   const int v0 = blockIdx.x * NVT;
-  const int c0 = blockIdx.y * 64;
+  const int c0 = blockIdx.y * CT;
   const int n = blockIdx.z;
   const float* dyn = dy + (int64_t)n * ybs;
   const int OH = 2 * H, OW = 2 * W;
   const int64_t OS = (int64_t)S * 8;
-  // this thread's staging voxel
-  const int sv = v0 + tid;
+  // this thread's staging voxel and rows
+  const int svl = tid % NVT, part = tid / NVT;
+  const int sv = v0 + svl;
   const bool sok = sv < S;
   const int svv = sok ? sv : 0;
   const int64_t sbase = ((int64_t)(2 * (svv / (W * H))) * OH + 2 * ((svv / W) % H)) * OW + 2 * (svv % W);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MTW][NGW];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NGW; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.f;
 
-  for (int o0 = 0; o0 < Cout; o0 += KO) {
-    __syncthreads();
+  float2 pf[ROWS];
+  float wpf[WPT];
+  auto fetch = [&](int o0) {
 #pragma unroll
-    for (int o = 0; o < KO; ++o)
+    for (int j = 0; j < ROWS; ++j) {
+      const int idx = part + P * j, o = o0 + (idx >> 2), ab = idx & 3;
+      const bool ok = sok && o < Cout;
+      pf[j] = *reinterpret_cast<const float2*>(
+          dyn + (ok ? (int64_t)o * OS + sbase + (int64_t)(ab >> 1) * OH * OW + (int64_t)(ab & 1) * OW : 0));
+    }
 #pragma unroll
-      for (int ab = 0; ab < 4; ++ab) {
-        float2 val = make_float2(0.f, 0.f);
-        if (sok && o0 + o < Cout)
-          val = *reinterpret_cast<const float2*>(dyn + (int64_t)(o0 + o) * OS + sbase +
-                                                 (int64_t)(ab >> 1) * OH * OW + (int64_t)(ab & 1) * OW);
-        dys[(o * 8 + ab * 2) * NVT + tid] = val.x;
-        dys[(o * 8 + ab * 2 + 1) * NVT + tid] = val.y;
-      }
-    // weights of this k-slab, transposed to ws[k][ci] (row stride 65: conflict-free both ways)
-    for (int i = tid; i < 64 * KK; i += 256) {
+    for (int j = 0; j < WPT; ++j) {
+      const int i = tid + 256 * j;
       const int k = i & (KK - 1), c = i >> 5;  // KK == 32
       const int o = o0 + (k >> 3);
-      ws[k * 65 + c] = (c0 + c < Cin && o < Cout) ? w[((int64_t)(c0 + c) * Cout + o) * 8 + (k & 7)] : 0.f;
+      const bool ok = c0 + c < Cin && o < Cout;
+      wpf[j] = w[ok ? ((int64_t)(c0 + c) * Cout + o) * 8 + (k & 7) : 0];
     }
+  };
+  auto commit = [&](int o0) {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      const int idx = part + P * j, o = o0 + (idx >> 2);
+      const bool ok = sok && o < Cout;
+      dys[(idx * 2) * NVT + svl] = ok ? pf[j].x : 0.f;
+      dys[(idx * 2 + 1) * NVT + svl] = ok ? pf[j].y : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int i = tid + 256 * j;
+      const int k = i & (KK - 1), c = i >> 5;
+      const bool ok = c0 + c < Cin && o0 + (k >> 3) < Cout;
+      ws[k * WSS + c] = ok ? wpf[j] : 0.f;  // transposed: row stride WSS (odd) is conflict-free both ways
+    }
+  };
+
+  fetch(0);
+  for (int o0 = 0; o0 < Cout; o0 += KO) {
+    __syncthreads();  // previous slab fully consumed
+    commit(o0);
     __syncthreads();
-    const float* wb = ws + half * 65 + l32;
-    const float* db = dys + half * NVT + wave * 64 + l32;
-#pragma unroll 4
-    for (int k = 0; k < KK; k += 2) {
-      const float a0 = wb[k * 65], a1 = wb[k * 65 + 32];
-      const float b0 = db[k * NVT], b1 = db[k * NVT + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    if (o0 + KO < Cout) fetch(o0 + KO);  // in flight during the MFMAs below
+    const float* wb = ws + half * WSS + wave_m * MTW * 32 + l32;
+    const float* db = dys + half * NVT + wave_n * NGW * 32 + l32;
+    // software-pipelined over the 16 k-pairs: the LDS reads of pair s+1 are issued before the MFMAs of
+    // pair s (sched_barrier: hipcc otherwise sinks every read to just before its MFMA and waits on it)
+    float a[2][MTW], b[2][NGW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) a[0][m] = wb[m * 32];
+#pragma unroll
+    for (int g = 0; g < NGW; ++g) b[0][g] = db[g * 32];
+#pragma unroll
+    for (int s = 0; s < KK / 2; ++s) {
+      if (s + 1 < KK / 2) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) a[(s + 1) & 1][m] = wb[(2 * s + 2) * WSS + m * 32];
+#pragma unroll
+        for (int g = 0; g < NGW; ++g) b[(s + 1) & 1][g] = db[(2 * s + 2) * NVT + g * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int g = 0; g < NGW; ++g)
+          acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][m], b[s & 1][g], acc[m][g], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* dxn = dx + (int64_t)n * xbs;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int v = v0 + (wave * 2 + g) * 32 + l32;
+  for (int g = 0; g < NGW; ++g) {
+    const int v = v0 + (wave_n * NGW + g) * 32 + l32;
     if (v >= S) continue;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = c0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int c = c0 + (wave_m * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (c < Cin) dxn[(int64_t)c * S + v] = acc[m][g][r];
       }
   }
 }
 
-// ---- weight gradient: workgroup = 64 input channels (2 m-tiles) x 16 output channels (wave w:
-// o-group w, N-tile = 4 o x 8 t), persistent over 64-voxel tiles of its split; partial
-// dW -> slab[split][Cin][Cout][8] (coalesced: the lane index IS (o,t)), fixed-order reduce.
+// ---- weight gradient: workgroup = 32*MT input channels x 16 output channels (wave w: 4 o x 8 t
+// = one N-tile), persistent over the 64-voxel tiles of its split with the next tile's loads in
+// flight during the MFMAs.  Partial dW -> slab[split][Cin][Cout][8] (coalesced: the lane index IS
+// (o,t)), fixed-order reduce.  The bias gradient falls out of the dY values already in registers:
+// per-thread partial sums per output channel, reduced at the end -> bslab[split][Cout] (double).
+template <int MT>
 __global__ __launch_bounds__(256) void convt_k2s2_bwd_weight_mfma_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
-    int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs, int nsplit) {
-  constexpr int NV = 64;
-  __shared__ float xs[64 * (NV + 1)];
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab,
+    double* __restrict__ bslab, int N, int Cin, int Cout, int D, int H, int W, int64_t xbs, int64_t ybs,
+    int nsplit) {
+  constexpr int NV = 64, CT = 32 * MT, XR = CT / 4;
+  __shared__ float xs[CT * (NV + 1)];
   __shared__ float dys[128 * (NV + 1)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
-  const int split = blockIdx.x, o0 = blockIdx.y * 16, c0 = blockIdx.z * 64;
+  const int split = blockIdx.x, o0 = blockIdx.y * 16, c0 = blockIdx.z * CT;
   const int S = D * H * W;
   const int OH = 2 * H, OW = 2 * W;
   const int64_t OS = (int64_t)S * 8;
   const int64_t total = (int64_t)N * S;
   const int64_t ntiles = (total + NV - 1) / NV;
+  const bool want_bias = bslab != nullptr && blockIdx.z == 0;
 
-  f32x16 acc[2];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  float bsum[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
 
-  const int sv = tid & 63, sq = tid >> 6;  // staging: voxel, quarter
-  for (int64_t tile = split; tile < ntiles; tile += nsplit) {
+  const int sv = tid & 63, sq = wave;  // staging: voxel, quarter (rows sq, sq+4, ...; ab == sq for dY)
+  float xpf[XR];
+  float2 dpf[16];
+  bool tok = false;
+  auto fetch = [&](int64_t tile) {
     const int64_t g = tile * NV + sv;
-    const bool ok = g < total;
-    const int64_t nn = ok ? g / S : 0;
-    const int v = ok ? (int)(g - nn * S) : 0;
-    __syncthreads();
-#pragma unroll 4
-    for (int c = sq; c < 64; c += 4)
-      xs[c * (NV + 1) + sv] = (ok && c0 + c < Cin) ? x[nn * xbs + (int64_t)(c0 + c) * S + v] : 0.f;
-    const int64_t sbase = nn * ybs + ((int64_t)(2 * (v / (W * H))) * OH + 2 * ((v / W) % H)) * OW + 2 * (v % W);
-#pragma unroll 4
-    for (int i = sq; i < 64; i += 4) {  // i = o_local*4 + ab
-      const int o = o0 + (i >> 2), ab = i & 3;
-      float2 val = make_float2(0.f, 0.f);
-      if (ok && o < Cout)
-        val = *reinterpret_cast<const float2*>(dy + sbase + (int64_t)o * OS + (int64_t)(ab >> 1) * OH * OW +
-                                               (int64_t)(ab & 1) * OW);
-      dys[((i >> 2) * 8 + ab * 2) * (NV + 1) + sv] = val.x;
-      dys[((i >> 2) * 8 + ab * 2 + 1) * (NV + 1) + sv] = val.y;
+    tok = g < total;
+    const int64_t nn = tok ? g / S : 0;
+    const int v = tok ? (int)(g - nn * S) : 0;
+    const float* xp = x + nn * xbs + v;
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int c = c0 + sq + 4 * j;
+      xpf[j] = xp[(tok && c < Cin) ? (int64_t)c * S : 0];
     }
+    const float* dp = dy + nn * ybs + ((int64_t)(2 * (v / (W * H)) + (sq >> 1)) * OH + 2 * ((v / W) % H) + (sq & 1)) * OW +
+                      2 * (v % W);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int o = o0 + j;
+      dpf[j] = *reinterpret_cast<const float2*>(dp + ((tok && o < Cout) ? (int64_t)o * OS : 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int c = sq + 4 * j;
+      xs[c * (NV + 1) + sv] = (tok && c0 + c < Cin) ? xpf[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool ok = tok && o0 + j < Cout;
+      const float vx = ok ? dpf[j].x : 0.f, vy = ok ? dpf[j].y : 0.f;
+      dys[(j * 8 + sq * 2) * (NV + 1) + sv] = vx;
+      dys[(j * 8 + sq * 2 + 1) * (NV + 1) + sv] = vy;
+      bsum[j] += vx + vy;
+    }
+  };
+
+  if (split < ntiles) fetch(split);
+  for (int64_t tile = split; tile < ntiles; tile += nsplit) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + nsplit < ntiles) fetch(tile + nsplit);
     const float* xb = xs + l32 * (NV + 1) + half;
     const float* db = dys + (wave * 32 + l32) * (NV + 1) + half;
-#pragma unroll 8
-    for (int k = 0; k < NV; k += 2) {
-      const float b = db[k];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[k], b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[32 * (NV + 1) + k], b, acc[1], 0, 0, 0);
+    float a[2][MT], b[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[0][m] = xb[m * 32 * (NV + 1)];
+    b[0] = db[0];
+#pragma unroll
+    for (int s = 0; s < NV / 2; ++s) {
+      if (s + 1 < NV / 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[(s + 1) & 1][m] = xb[m * 32 * (NV + 1) + 2 * s + 2];
+        b[(s + 1) & 1] = db[2 * s + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // reads of pair s+1 in flight during the MFMAs of pair s
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][m], b[s & 1], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // D[i = ci][j = (o,t)]
@@ -273,23 +371,44 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_weight_mfma_kernel(
   if (o < Cout) {
     float* sl = slab + (int64_t)split * Cin * Cout * 8;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = c0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (c < Cin) sl[((int64_t)c * Cout + o) * 8 + (l32 & 7)] = acc[m][r];
       }
   }
+  if (want_bias) {
+    __syncthreads();
+    float* red = dys;  // [16 o][4 waves]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float s = wave_sum(bsum[j]);
+      if (lane == 0) red[j * 4 + wave] = s;
+    }
+    __syncthreads();
+    if (tid < 16 && o0 + tid < Cout)
+      bslab[(int64_t)split * Cout + o0 + tid] =
+          ((double)red[tid * 4] + (double)red[tid * 4 + 1]) + ((double)red[tid * 4 + 2] + (double)red[tid * 4 + 3]);
+  }
 }
 
-__global__ void convt_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                         int64_t total, int nsplit) {
+// dW = sum over splits (fixed order, double); dbias likewise from the per-split bias partials
+__global__ void convt_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t total,
+                                         int nsplit, const double* __restrict__ bslab, float* __restrict__ dbias,
+                                         int Cout) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     double v = 0.0;
     for (int s = 0; s < nsplit; ++s) v += slab[(int64_t)s * total + i];
     out[i] = (float)v;
   }
+  if (dbias && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+      double v = 0.0;
+      for (int s = 0; s < nsplit; ++s) v += bslab[(int64_t)s * Cout + o];
+      dbias[o] = (float)v;
+    }
 }
 
 // ----------------------------------------------------- generic direct kernels
@@ -425,10 +544,11 @@ static bool is_k2s2(const m355_conv3d_desc* d) {
 static int convt_out(int in, const m355_conv3d_desc* d) {
   return (in - 1) * d->stride - 2 * d->pad + d->k + d->out_pad;
 }
+static int convt_bww_mt(const m355_conv3d_desc* d) { return d->Cin > 64 ? 4 : 2; }
 static int convt_nsplit(const m355_conv3d_desc* d) {
-  const int64_t tiles = ceil_div(d->Cin, 64) * ceil_div(d->Cout, 16);
+  const int64_t tiles = ceil_div(d->Cin, 32 * convt_bww_mt(d)) * ceil_div(d->Cout, 16);
   const int64_t nsteps = ceil_div((int64_t)d->N * d->D * d->H * d->W, 64);
-  int64_t ns = std::max<int64_t>(1, 768 / tiles);
+  int64_t ns = std::max<int64_t>(1, 512 / tiles);  // persistent: 2 workgroups per CU, one round
   ns = std::min<int64_t>(ns, nsteps);
   return (int)ns;
 }
@@ -460,7 +580,17 @@ static size_t convt_slab_bytes(const m355_conv3d_desc* d) {
 }
 static size_t convt_dbias_bytes(const m355_conv3d_desc* d) {
   const int64_t OS = (int64_t)convt_out(d->D, d) * convt_out(d->H, d) * convt_out(d->W, d);
-  return (size_t)round_up((int64_t)d->Cout * ceil_div(OS, 32768) * 8, 256);
+  const int64_t generic = (int64_t)d->Cout * ceil_div(OS, 32768) * 8;                    // launch_dbias partials
+  const int64_t fused = is_k2s2(d) ? (int64_t)convt_nsplit(d) * d->Cout * 8 : 0;        // bslab[split][Cout]
+  return (size_t)round_up(std::max(generic, fused), 256);
+}
+
+// forward tile: the largest voxel tile whose [Cin][NVT] x slab fits 64 KB of LDS (0: none does)
+static int convt_fwd_nvt(const m355_conv3d_desc* d) {
+  const int64_t cin2 = round_up(d->Cin, 16);  // whole weight chunks (KC = 8 k-pairs)
+  for (int nvt : {128, 64, 32})  // 256 needs > 256 registers: one workgroup per CU, no overlap
+    if (cin2 * nvt * 4 <= 65536) return nvt;
+  return 0;
 }
 
 extern "C" size_t m355_conv_transpose3d_workspace(const m355_conv3d_desc* d) {
@@ -479,11 +609,25 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
   M355_REQUIRE(OD > 0 && OH > 0 && OW > 0, M355_EINVALID_ARG, "conv_transpose3d_fwd: empty output");
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0 && convt_fits_i32(d)) {
+  const int nvt = convt_fwd_nvt(d);
+  if (is_k2s2(d) && nvt && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
-    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(ceil_div(d->Cout, 4), CTF_MTG), (unsigned)d->N);
-    hipLaunchKernelGGL(convt_k2s2_fwd_mfma_kernel, grid, dim3(256), 0, st, x, w, bias, y, d->Cin,
-                       d->Cout, d->D, d->H, d->W, xbs, ybs);
+    const int64_t vox_tiles = ceil_div(S, nvt) * d->N;
+    const int mtiles = (int)ceil_div(d->Cout, 4);
+    // x is re-read once per m-tile group: split M only as far as needed to fill the chip
+    const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, vox_tiles), ceil_div(mtiles, 4)));
+    const int mt_per_wg = (int)round_up(ceil_div(mtiles, groups), 4);
+    dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)ceil_div(mtiles, mt_per_wg), (unsigned)d->N);
+    const size_t lds = (size_t)round_up(d->Cin, 16) * nvt * 4;
+#define M355_CONVT_FWD(NVT)                                                                                   \
+  hipLaunchKernelGGL(convt_k2s2_fwd_mfma_kernel<NVT>, grid, dim3(256), lds, st, x, w, bias, y, d->Cin, d->Cout, \
+                     d->D, d->H, d->W, xbs, ybs, mt_per_wg)
+    switch (nvt) {
+      case 128: M355_CONVT_FWD(128); break;
+      case 64: M355_CONVT_FWD(64); break;
+      default: M355_CONVT_FWD(32); break;
+    }
+#undef M355_CONVT_FWD
     return check_launch("convt_k2s2_fwd");
   }
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
@@ -505,9 +649,20 @@ extern "C" int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const f
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
-    dim3 grid((unsigned)ceil_div(S, 256), (unsigned)ceil_div(d->Cin, 64), (unsigned)d->N);
-    hipLaunchKernelGGL(convt_k2s2_bwd_data_mfma_kernel, grid, dim3(256), 0, st, dy, w, dx, d->Cin,
-                       d->Cout, d->D, d->H, d->W, xbs, ybs);
+    const int mt = d->Cin > 64 ? 4 : 2;  // all input channels of a standard level in one pass over dY
+    const int64_t cblocks = ceil_div(d->Cin, 32 * mt);
+    int nvt = 256;
+    while (nvt > 64 && ceil_div(S, nvt) * cblocks * d->N < 512) nvt >>= 1;
+    dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)cblocks, (unsigned)d->N);
+#define M355_CONVT_BWD(NVT, MT)                                                                                \
+  hipLaunchKernelGGL((convt_k2s2_bwd_data_mfma_kernel<NVT, MT>), grid, dim3(256), 0, st, dy, w, dx, d->Cin,    \
+                     d->Cout, d->D, d->H, d->W, xbs, ybs)
+    if (mt == 2) {
+      if (nvt == 256) M355_CONVT_BWD(256, 2); else if (nvt == 128) M355_CONVT_BWD(128, 2); else M355_CONVT_BWD(64, 2);
+    } else {
+      if (nvt == 256) M355_CONVT_BWD(256, 4); else if (nvt == 128) M355_CONVT_BWD(128, 4); else M355_CONVT_BWD(64, 4);
+    }
+#undef M355_CONVT_BWD
     return check_launch("convt_k2s2_bwd_data");
   }
   const int64_t total = (int64_t)d->N * d->Cin * d->D * d->H * d->W;
@@ -534,12 +689,24 @@ extern "C" int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const
                  "conv_transpose3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                  need);
     float* slab = (float*)workspace;
-    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(d->Cout, 16), (unsigned)ceil_div(d->Cin, 64));
-    hipLaunchKernelGGL(convt_k2s2_bwd_weight_mfma_kernel, grid, dim3(256), 0, st, x, dy, slab, d->N,
-                       d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, nsplit);
+    double* bslab = nullptr;
+    if (dbias) {
+      M355_REQUIRE(workspace_bytes >= need + convt_dbias_bytes(d), M355_EWORKSPACE,
+                   "conv_transpose3d_bwd_weight: workspace too small for the bias gradient");
+      bslab = (double*)((char*)workspace + need);
+    }
+    const int mt = convt_bww_mt(d);
+    dim3 grid((unsigned)nsplit, (unsigned)ceil_div(d->Cout, 16), (unsigned)ceil_div(d->Cin, 32 * mt));
+    if (mt == 2)
+      hipLaunchKernelGGL(convt_k2s2_bwd_weight_mfma_kernel<2>, grid, dim3(256), 0, st, x, dy, slab, bslab, d->N,
+                         d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, nsplit);
+    else
+      hipLaunchKernelGGL(convt_k2s2_bwd_weight_mfma_kernel<4>, grid, dim3(256), 0, st, x, dy, slab, bslab, d->N,
+                         d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, nsplit);
     const int64_t total = (int64_t)d->Cin * d->Cout * 8;
     hipLaunchKernelGGL(convt_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1024)),
-                       dim3(256), 0, st, slab, dw, total, nsplit);
+                       dim3(256), 0, st, slab, dw, total, nsplit, bslab, dbias, d->Cout);
+    return check_launch("conv_transpose3d_bwd_weight");
   } else {
     const int k3 = d->k * d->k * d->k;
     const int64_t nblk = (int64_t)d->Cin * d->Cout * k3;
