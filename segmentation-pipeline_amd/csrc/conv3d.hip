@@ -110,20 +110,21 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   const int64_t HW = (int64_t)H * W;
   const int DHW = (int)(HW * D);
 
-  // chunk-invariant gather offsets of this thread's elements (-1: zero padding, -2: past the tile)
-  int goff[XPER];
+  // chunk-invariant gather offsets of this thread's elements, in bytes; zero padding and elements
+  // past the tile get an offset no buffer descriptor covers, so the hardware returns 0 for them
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[XPER];
 #pragma unroll
   for (int i = 0; i < XPER; ++i) {
     const int e = tid + 256 * i;
-    int off = -2;
+    unsigned off = OOB;
     if (e < XE) {
       const int c = e / CS, r = e - c * CS;
       const int zz = r / PS, r2 = r - zz * PS;
       const int yy = r2 / RS, xx = r2 - yy * RS;
       const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-      off = (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                ? c * DHW + gz * (int)HW + gy * W + gx
-                : -1;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        off = (unsigned)(c * DHW + gz * (int)HW + gy * W + gx) * 4u;
     }
     goff[i] = off;
   }
@@ -134,71 +135,86 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
-  // Loads are UNCONDITIONAL (the select is on the address, clamped to element 0 of the chunk,
-  // never on the value): a `cond ? load : 0` makes hipcc branch around each load and wait
-  // vmcnt(0) at every join, which serialises the prefetch.  Zero padding is applied when the
-  // registers are committed to LDS, after the MFMA loop.
+  // Prefetch of the next chunk into registers.  x comes through a raw buffer descriptor that
+  // covers exactly the channels of the chunk that exist (base at channel c0, num_records =
+  // min(CC, Cin - c0) channels): padding, tile overhang and channels past Cin are out of range and
+  // read as 0, so there are no validity masks, no branches, and the commit is plain LDS writes.
+  // The prefetch is cut into per-step items issued inside the MFMA loop (see below).
   float xr[XPER];
   f32x4 wr[WPER];
-  auto fetch = [&](int ch) {
+  __amdgpu_buffer_rsrc_t rx;
+  const float* wsrc = wp;
+  auto chunk_setup = [&](int ch, bool live) {  // !live: zero-sized descriptor, every load returns 0
     const int c0 = ch * CC;
-    const float* xc = xn + (int64_t)c0 * DHW;
-    const bool full = (c0 + CC <= Cin);
-#pragma unroll
-    for (int i = 0; i < XPER; ++i) {
-      bool ok = goff[i] >= 0;
-      if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
-      xr[i] = xc[ok ? goff[i] : 0];
-    }
-    const float* wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
-#pragma unroll
-    for (int j = 0; j < WPER; ++j) {
-      const int idx = tid + 256 * j;
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (int64_t)c0 * DHW), 0,
+                                           live ? min(CC, Cin - c0) * DHW * 4 : 0, 0x00020000);
+    wsrc = wp + (int64_t)c0 * 27 * cout_pad + o0;
+  };
+  auto fetch_item = [&](int s) {  // s is a compile-time constant wherever this is called
+    if (s < XPER) xr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[s], 0, 0));
+    if (s < WPER) {
+      const int idx = tid + 256 * s;
       const int idc = idx < WE4 ? idx : WE4 - 1;  // clamp: keeps the array fully scalarised
-      wr[j] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
+      wr[s] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
     }
   };
-  auto commit = [&](int buf, int ch) {
-    const int c0 = ch * CC;
-    const bool full = (c0 + CC <= Cin);
+  auto commit = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < XPER; ++i) {
-      bool ok = goff[i] >= 0;
-      if (!full) ok = ok && (c0 + (tid + 256 * i) / CS < Cin);
-      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = ok ? xr[i] : 0.f;
-    }
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = xr[i];
 #pragma unroll
     for (int j = 0; j < WPER; ++j)
       if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
   };
+  constexpr int NSTEP = (CC / 2) * 27;
+  static_assert(XPER <= NSTEP && WPER <= NSTEP, "one prefetch item per MFMA step");
 
   if (ch_begin < ch_end) {
-    fetch(ch_begin);
-    commit(0, ch_begin);
+    chunk_setup(ch_begin, true);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) fetch_item(s);
+    commit(0);
   }
   __syncthreads();
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const int cur = (ch - ch_begin) & 1;
     const bool more = ch + 1 < ch_end;
-    if (more) fetch(ch + 1);  // in flight during the MFMA loop below
+    chunk_setup(more ? ch + 1 : ch, more);  // unconditional, so the loop body has no branch
     const float* xb = xs[cur] + half * CS + wave * PS + ly * RS + lx;
     const float* wb = ws[cur] + half * (27 * 32) + l32;
-    // ---- MFMA over K = CC * 27 ----
+    // ---- MFMA over K = CC * 27, software-pipelined over the (channel pair, tap) steps: the LDS
+    // reads of step s+1 and one item of the next chunk's prefetch are issued before the MFMAs of
+    // step s.  The sched_barriers pin that order; left alone, hipcc sinks LDS reads to just before
+    // their MFMA (waiting lgkmcnt(0) on them) and hoists the whole prefetch in front of the loop,
+    // which with one wave per SIMD leaves the matrix core idle meanwhile.
+    float av[2], bv[2][NTW];
+    auto lds_step = [&](int s, int slot) {  // s is a compile-time constant after unrolling
+      const int cp = s / 27, tap = s % 27;
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      av[slot] = wb[(2 * cp * 27 + tap) * 32];
 #pragma unroll
-    for (int cp = 0; cp < CC / 2; ++cp) {
+      for (int g = 0; g < NTW; ++g) bv[slot][g] = xb[2 * cp * CS + dz * PS + (g * GY + dy) * RS + dx];
+    };
+    lds_step(0, 0);
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        const float a = wb[(2 * cp * 27 + tap) * 32];
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + 1 < NSTEP) lds_step(s + 1, (s + 1) & 1);
+      fetch_item(s);
 #pragma unroll
-        for (int g = 0; g < NTW; ++g) {
-          const float b = xb[2 * cp * CS + dz * PS + (g * GY + dy) * RS + dx];
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
-        }
+      for (int g = 0; g < NTW; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][g], acc[g], 0, 0, 0);
+      // issue order inside the step: each MFMA is followed by up to two of the LDS reads of step
+      // s+1, then the prefetch loads -- they go out while the matrix core is busy
+#pragma unroll
+      for (int g = 0; g < NTW; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
       }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) commit(cur ^ 1, ch + 1);
+    if (more) commit(cur ^ 1);
     __syncthreads();
   }
 
@@ -804,6 +820,206 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
   }
 }
 
+// ---- bwd-weight, second generation (used whenever W % 4 == 0 and a sample fits 2 GiB) ----
+// Same tiling and MFMA mapping as conv3_mfma_bww_kernel.  What changed is everything AROUND the
+// MFMAs: with one wave per SIMD nothing else covers the matrix core while a wave issues the
+// prefetch of the next tile (~1000 VALU/VMEM instructions) and commits it to LDS (~1000 more),
+// which cost ~20 % of the kernel.  Here
+//  * the prefetch uses raw buffer loads: out-of-volume halo elements and channels past Cin/Cout
+//    get an out-of-range offset and the hardware returns 0, so there are no validity masks and the
+//    commit is a plain sequence of LDS writes;
+//  * the row loop is fully unrolled and the prefetch is cut into one slice per row, so its
+//    instructions are issued in the shadow of that row's MFMAs (the sched_barrier at the end of
+//    each row keeps the slices from being hoisted back into one block).  The prefetch is
+//    unconditional (the last iteration re-fetches its own tile): a branch would split the row into
+//    basic blocks and undo the interleaving.
+template <int GX>
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
+    int64_t xbs, int64_t ybs) {
+  using T = BwTile<GX>;
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS,
+                CSW = T::CSW, DSW = T::DSW, NV = T::NV;
+  static_assert(NV == 256, "one dy voxel per thread");
+  __shared__ float xs[32 * CSW];
+  __shared__ float ds[32 * DSW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ctile = blockIdx.x, otile = blockIdx.y, split = blockIdx.z;
+  const int c0 = ctile * 32, o0 = otile * 32;
+  const int iHW = H * W, iDHW = D * H * W;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-wave tap bases into the x halo tile; everything else in an LDS read address is an immediate
+  const float* xt[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(wave * 7 + t, 26);
+    xt[t] = xs + l32 * CSW + half + (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3);
+  }
+  const float* db = ds + l32 * DSW + half;
+
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+  const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
+
+  constexpr int RPC = (TZ + 2) * (TY + 2);   // rows per channel
+  constexpr int ROWS = 32 * RPC;
+  constexpr int Q = TX / 4;                  // float4 per interior row
+  constexpr int NI = ROWS * Q, IPER = NI / 256;
+  constexpr int NH = ROWS * 2, HPER = NH / 256;
+  static_assert(NI % 256 == 0 && NH % 256 == 0, "every thread owns whole prefetch items");
+  constexpr int NR = TZ * TY;                // MFMA rows per tile == prefetch slices
+  constexpr unsigned OOB = 0x80000000u;      // >= num_records of any sample we accept: load returns 0
+  f32x4 xi[IPER];
+  float xh[HPER];
+  float dr[32];
+
+  // tile-invariant descriptors (see conv3_mfma_bww_kernel)
+  int relI[IPER], ldsI[IPER], relH[HPER], ldsH[HPER];
+  unsigned codeI[IPER], codeH[HPER];
+#pragma unroll
+  for (int k = 0; k < IPER; ++k) {
+    const int m = tid + 256 * k;
+    const int q = m % Q, row = m / Q;
+    const int c = row / RPC, rem = row - c * RPC;
+    const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+    relI[k] = c * iDHW + zz * iHW + yy * W + 4 * q;
+    ldsI[k] = c * CSW + zz * PS + yy * RS + 1 + 4 * q;
+    codeI[k] = (1u << zz) | (1u << (8 + yy)) | (1u << (20 + q));
+  }
+#pragma unroll
+  for (int j = 0; j < HPER; ++j) {
+    const int h = tid + 256 * j;
+    const int side = h & 1, row = h >> 1;
+    const int c = row / RPC, rem = row - c * RPC;
+    const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
+    relH[j] = c * iDHW + zz * iHW + yy * W + (side ? TX : -1);
+    ldsH[j] = c * CSW + zz * PS + yy * RS + (side ? TX + 1 : 0);
+    codeH[j] = (1u << zz) | (1u << (8 + yy)) | (1u << (20 + side));
+  }
+
+  // per-tile uniform state of the prefetch
+  __amdgpu_buffer_rsrc_t rx, rd;
+  unsigned inI = 0u, inH = 0u;  // valid halo rows | interior float4s (resp. halo sides)
+  int base = 0, dsp = 0;
+  bool vok = false;
+  auto tile_setup = [&](int tile, bool live) {  // !live: zero-sized descriptors, no memory traffic
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles;
+    const int tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    // channels past Cin / Cout are past num_records: zero-filled by the hardware as well
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs), 0, live ? Cin * iDHW * 4 : 0, 0x00020000);
+    rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs), 0, live ? Cout * iDHW * 4 : 0, 0x00020000);
+    unsigned zy = 0u;
+    for (int zz = 0; zz < TZ + 2; ++zz)
+      if (z0 + zz - 1 >= 0 && z0 + zz - 1 < D) zy |= 1u << zz;
+    for (int yy = 0; yy < TY + 2; ++yy)
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) zy |= 1u << (8 + yy);
+    unsigned qm = 0u;
+    for (int q = 0; q < Q; ++q)
+      if (x0 + 4 * q < W) qm |= 1u << (20 + q);  // W % 4 == 0: a float4 is in or out as a whole
+    inI = zy | qm;
+    inH = zy | (x0 - 1 >= 0 ? (1u << 20) : 0u) | (x0 + TX < W ? (1u << 21) : 0u);
+    base = c0 * iDHW + (z0 - 1) * iHW + (y0 - 1) * W + x0;
+    const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+    vok = gz < D && gy < H && gx < W;
+    dsp = o0 * iDHW + gz * iHW + gy * W + gx;
+  };
+  // slice r of the prefetch (r is a compile-time constant wherever this is called)
+  auto fetch_slice = [&](int r) {
+#pragma unroll
+    for (int k = 0; k < IPER; ++k)
+      if (k % NR == r) {
+        const bool ok = (codeI[k] & ~inI) == 0u;
+        xi[k] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(base + relI[k]) * 4u : OOB, 0, 0));
+      }
+#pragma unroll
+    for (int j = 0; j < HPER; ++j)
+      if (j % NR == r) {
+        const bool ok = (codeH[j] & ~inH) == 0u;
+        xh[j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(base + relH[j]) * 4u : OOB, 0, 0));
+      }
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j % NR == r)
+        dr[j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rd, vok ? (unsigned)(dsp + j * iDHW) * 4u : OOB, 0, 0));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < IPER; ++k) {
+      float* p = xs + ldsI[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p[e] = xi[k][e];
+    }
+#pragma unroll
+    for (int j = 0; j < HPER; ++j) xs[ldsH[j]] = xh[j];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = dr[j];
+  };
+
+  if (split < ntiles) {
+    tile_setup(split, true);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) fetch_slice(r);
+    commit();
+  }
+  __syncthreads();
+
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    tile_setup(more ? tile + nsplit : tile, more);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      fetch_slice(r);
+      const int ro = (r / TY) * PS + (r % TY) * RS;  // immediate
+#pragma unroll
+      for (int xp = 0; xp < TX / 2; ++xp) {
+        const float a = db[r * TX + 2 * xp];
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xt[t][ro + 2 * xp], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave is done reading this tile
+    if (more) commit();
+    __syncthreads();
+  }
+
+  // partial dW -> slab[split][Cout][Cin][27]
+  float* sl = slab + (int64_t)split * Cout * Cin * 27;
+  const int c = c0 + l32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave * 7 + t;
+    if (tap < 27 && c < Cin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
+      }
+    }
+  }
+}
+
 // ------------------------------------------- bwd-weight, tiny channel count on one side
 // dW[o,c,tap] when Cin <= 4 (first conv) or Cout <= 4 (out conv).  The generic kernel would
 // pad the narrow side to 32 MFMA rows/cols (8-10x waste).  Here the narrow channel AND the
@@ -1273,29 +1489,57 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   p.nchunks = p.kin_pad / cc;
   p.tz_tiles = (int)ceil_div(D, 4);
   p.tx_tiles = (int)ceil_div(W, p.gx);
-  // Prefer the largest voxel tile (most reuse of the staged weights); fill the
-  // chip with split-K over input-channel chunks when the layer is small.
+  // Pick (voxel-tile height NTW, split-K) by a cost model instead of "fill the chip once":
+  // workgroups of one launch do equal work, so the time is rounds x (workgroups sharing a CU) x
+  // time of one workgroup, and a launch that needs 1.1 rounds costs as much as one that needs 2.
+  //   slots     NTW <= 4: 66.8 KB LDS -> two workgroups per CU (512); NTW = 8: one (256)
+  //   one chunk 54 x NTW MFMAs of 64 cycles per wave at ~2.04 GHz; + ~2 chunks of fill/epilogue
+  //   split-K   ks x out bytes written + read again by the reduce kernel (~4 TB/s) + a launch
   const int64_t out_bytes = (int64_t)N * mout * D * H * W * 4;
-  const int target = env_int("M355_CONV_TARGET_WG", 512);
   const int force_ntw = env_int("M355_CONV_NTW", 0);
   const int force_ks = env_int("M355_CONV_KSPLIT", 0);
-  // NTW=4 (2 workgroups per CU) measured 3-9% faster than NTW=8 on levels 0-2
   const int cands[4] = {4, 8, 2, 1};
   int chosen = 1, chosen_ks = 1;
-  for (int i = 0; i < 4; ++i) {
+  double best = 1e30;
+  for (int i = 0; i < 4 && compute == M355_COMPUTE_BF16; ++i) {
+    // bf16 operand mode (HBM/LDS-bound kernel): fill the chip once, largest tile first
+    const int ntw = cands[i];
+    if (force_ntw && ntw != force_ntw) continue;
+    const int ty = ntw * gy;
+    if (ty > H && ntw > 1 && !force_ntw) continue;
+    const int64_t nwg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+    int64_t ks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(512, nwg), std::min<int64_t>(p.nchunks, 8)));
+    while (ks > 1 && ks * out_bytes > (128ll << 20)) --ks;
+    while (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) --ks;
+    chosen = ntw;
+    chosen_ks = (int)ks;
+    if (nwg * ks * 4 >= 512 * 3) break;
+  }
+  for (int i = 0; i < 4 && compute != M355_COMPUTE_BF16; ++i) {
     const int ntw = cands[i];
     if (force_ntw && ntw != force_ntw) continue;
     const int ty = ntw * gy;
     if (ty > H && ntw > 1 && !force_ntw) continue;  // do not overhang H by a whole factor
-    const int64_t nwg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
-    int64_t ks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(target, nwg),
-                                                       std::min<int64_t>(p.nchunks, 8)));
-    while (ks > 1 && ks * out_bytes > (128ll << 20)) --ks;
-    // keep every split non-empty
-    while (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) --ks;
-    chosen = ntw;
-    chosen_ks = (int)ks;
-    if (nwg * ks * 4 >= (int64_t)target * 3) break;
+    const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+    const int per_cu = ntw <= 4 ? 2 : 1;
+    const double chunk_us = 54.0 * ntw * 64.0 / 2040.0;
+    for (int ks = 1; ks <= std::min(p.nchunks, 8); ++ks) {
+      if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;  // an empty split
+      if (ks > 1 && ks * out_bytes > (128ll << 20)) break;
+      const int64_t nwg = base_wg * ks;
+      const double rounds = (double)ceil_div(nwg, 256 * per_cu);
+      // a lone workgroup on a CU has nothing to cover its barriers and LDS commits: measured ~0.8 of
+      // the paired rate for NTW <= 4 (u0.c0 pinned to one per CU: 111 vs 126 TFLOP/s), ~0.93 for NTW = 8
+      const bool lone = per_cu == 1 || nwg <= 256;
+      const double share = lone ? 1.0 / (per_cu == 1 ? 0.93 : 0.8) : (double)per_cu;
+      double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + 2.0) * chunk_us;
+      if (ks > 1) cost += (2.0 * ks + 1.0) * (double)out_bytes / 4.0e6 + 4.0;
+      if (cost < best * 0.98) {  // candidates come in order of preference: switch only for a real gain
+        best = cost;
+        chosen = ntw;
+        chosen_ks = ks;
+      }
+    }
   }
   if (force_ks) {
     chosen_ks = std::min(force_ks, p.nchunks);
@@ -1455,7 +1699,28 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
   p.ctiles = (int)ceil_div(Cin, 32);
   const int64_t ntiles = (int64_t)N * p.tz_tiles * p.ty_tiles * p.tx_tiles;
   const int64_t pairs = (int64_t)p.otiles * p.ctiles;
-  int64_t nsplit = std::max<int64_t>(1, 256 / pairs);
+  // One workgroup per CU; workgroups have equal work, so time ~ rounds x (tiles per split + fixed
+  // cost of a workgroup: pipeline fill + the 110 KB slab write, ~half a tile).  Pick the split that
+  // minimises it (a power of two up to the tile count) instead of just filling 256 CUs once.
+  int64_t nsplit = 1;
+  {
+    int64_t cand[24];
+    int nc = 0;
+    for (int64_t ns = 1; ns < ntiles; ns *= 2) cand[nc++] = ns;
+    for (int r = 1; r <= 8; ++r) cand[nc++] = std::max<int64_t>(1, 256 * r / pairs);  // exactly r rounds
+    cand[nc++] = std::max<int64_t>(1, ntiles);
+    std::sort(cand, cand + nc);
+    double best = 1e30;
+    for (int i = 0; i < nc; ++i) {
+      const int64_t ns = std::min<int64_t>(cand[i], std::max<int64_t>(1, ntiles));
+      const double rounds = (double)ceil_div(pairs * ns, 256);
+      const double cost = rounds * ((double)ceil_div(ntiles, ns) + 0.5);
+      if (cost < best * 0.97) {  // prefer fewer splits (less slab traffic) unless clearly better
+        best = cost;
+        nsplit = ns;
+      }
+    }
+  }
   if (Cin <= 4 || Cout <= 4)  // tap-on-lane kernel: small LDS footprint, ~3 workgroups per CU
     nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
   nsplit = std::min<int64_t>(nsplit, ntiles);
@@ -1656,7 +1921,18 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     M355_REQUIRE((int64_t)d->Cin * d->D * d->H * d->W < (1ll << 31) &&
                      (int64_t)d->Cout * d->D * d->H * d->W < (1ll << 31),
                  M355_EUNSUPPORTED, "conv3d_bwd_weight: tensor exceeds 2^31 elements per sample");
-    if (p.gx == 32)
+    // second-generation kernel: float4 rows, and a sample must fit the 32-bit byte offsets of a
+    // buffer descriptor (the hardware zero-fills what lies past it)
+    const int64_t spatial = (int64_t)d->D * d->H * d->W;
+    const bool gen2 = vec && ((uintptr_t)dy & 3) == 0 && (int64_t)d->Cin * spatial < (1ll << 29) &&
+                      (int64_t)d->Cout * spatial < (1ll << 29) && env_int("M355_BWW_GEN", 2) == 2;
+#define M355_BWW2_LAUNCH(GXV)                                                                     \
+  hipLaunchKernelGGL((conv3_mfma_bww2_kernel<GXV>), grid, dim3(256), 0, st, x, dy, slab, d->N,    \
+                     d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,       \
+                     p.nsplit, xbs, ybs);
+    if (gen2) {
+      if (p.gx == 32) { M355_BWW2_LAUNCH(32) } else if (p.gx == 16) { M355_BWW2_LAUNCH(16) } else { M355_BWW2_LAUNCH(8) }
+    } else if (p.gx == 32)
       M355_BWW_LAUNCH(32)
     else if (p.gx == 16)
       M355_BWW_LAUNCH(16)

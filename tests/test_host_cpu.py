@@ -151,3 +151,40 @@ def test_components_are_picklable_by_reference_for_torchcontext():
     for cls in (ModularUNet, Block3d, NestedResUNet, HybridLogisticDiceLoss, BlurConv3d):
         assert dill.loads(dill.dumps(cls)) is cls
         assert inspect.getsourcefile(cls)
+
+
+def test_reference_format_checkpoint_roundtrip(golden, tmp_path):
+    """Checkpoint interchange in the reference's on-disk format (utils/torch_context.py:113-126,
+    196-213): a dict with `component_definitions` = [{name, constructor, params, state_dict}], written
+    with torch.save(pickle_module=dill).  The file here is written by this test (the constructor
+    pickled by reference is ours, the weights are the reference-generated golden state_dict with the
+    reference's key names) and re-initialised exactly as TorchContext._init_component does."""
+    g = golden("unet_res_blur.npz")
+    params = dict(in_channels=2, out_channels=2, filters=[8, 8, 16], depth=3, block_params={'residual': True},
+                  downsample_class=BlurConv3d, downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1},
+                  upsample_class=BlurConvTranspose3d,
+                  upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0})
+    definitions = [
+        dict(name="model", constructor=ModularUNet, params=params, state_dict=g.state_dict("m.sd.")),
+        dict(name="criterion", constructor=HybridLogisticDiceLoss, params={}),
+        dict(name="optimizer", constructor=torch.optim.SGD,
+             params=dict(params="self.model.parameters()", lr=0.001, momentum=0.95)),
+    ]
+    path = tmp_path / "checkpoint.pt"
+    torch.save(dict(name="ctx", component_definitions=definitions, creation_time="t", variables=None,
+                    file_paths=[], metadata={}, config={}), path, pickle_module=dill)
+    ckpt = torch.load(path, pickle_module=dill, weights_only=False)  # our own file, see docstring
+    built = {}
+    for d in ckpt["component_definitions"]:
+        p = {k: (built["model"].parameters() if v == "self.model.parameters()" else v) for k, v in d["params"].items()}
+        comp = d["constructor"](**p)
+        if "state_dict" in d:
+            comp.load_state_dict(d["state_dict"])  # strict: key names and shapes are the reference's
+        built[d["name"]] = comp
+    assert type(built["model"]) is ModularUNet and type(built["criterion"]) is HybridLogisticDiceLoss
+    sd = built["model"].state_dict()
+    ref = g.state_dict("m.sd.")
+    assert list(sd) == list(ref)
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+    assert len(built["optimizer"].param_groups[0]["params"]) == len(list(built["model"].parameters()))
