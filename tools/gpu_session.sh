@@ -31,6 +31,7 @@ for s in $STEPS; do
     archprof) run archprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/archprof -- python tools/arch_bench.py
           find $OUT/archprof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/arch_kernel_stats.csv
           head -n 16 $OUT/arch_kernel_stats.csv 2>/dev/null ;;
+    pmc) run pmc 900 bash tools/pmc_collect.sh ;;
     prof) run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-infer
           find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/kernel_stats.csv
           head -n 40 $OUT/kernel_stats.csv 2>/dev/null ;;
