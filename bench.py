@@ -206,22 +206,23 @@ def main():
         infer = {"value": world * args.batch * args.steps / ti, "unit": "patches/s", "ms_per_step": ti / args.steps * 1e3}
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: conv3_mfma_fwd_kernel<8,32> (fp32 MFMA implicit GEMM),
+        # ---- roofline of the dominant kernel: conv3_mfma_fwd_p_kernel<4,32> (fp32 MFMA implicit GEMM),
         # all launches of that variant in the timed region (forward convs and data gradients) ----
         # the kernel variant (NTW, GX) that accumulates the most time is the dominant kernel
         per_plan = {}
         for (tag, f, e0, e1, plan) in prof:
-            if plan is not None and plan[0] == 1 and plan[3] == 1:
-                per_plan.setdefault((plan[1], plan[2]), []).append((f, e0.elapsed_time(e1)))
+            if plan is not None and plan[0] in (1, 3) and plan[3] == 1:
+                per_plan.setdefault((plan[0], plan[1], plan[2]), []).append((f, e0.elapsed_time(e1)))
         dom = max(per_plan, key=lambda p: sum(ms for _, ms in per_plan[p])) if per_plan else None
         sel = per_plan.get(dom, [])
         roofline = None
         if sel:
+            kname = "conv3_mfma_fwd_p_kernel" if dom[0] == 3 else "conv3_mfma_fwd_kernel"  # 3: persistent variant
             tot_f, tot_ms = sum(f for f, _ in sel), sum(ms for _, ms in sel)
             ach = tot_f / (tot_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(f"conv3_mfma_fwd_kernel<{dom[0]}, {dom[1]}>"),
-                        "kernel": f"conv3_mfma_fwd_kernel<{dom[0]},{dom[1]}>", "launches": len(sel),
+                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(f"{kname}<{dom[1]}, {dom[2]}>"),
+                        "kernel": f"{kname}<{dom[1]},{dom[2]}>", "launches": len(sel),
                         "avg_launch_ms": tot_ms / len(sel), "avg_gflop_per_launch": tot_f / len(sel) / 1e9}
         by_tag = {}
         for tag, f, e0, e1, plan in prof:

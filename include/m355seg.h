@@ -82,8 +82,9 @@ int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
- * which: 0 = forward, 1 = data gradient.  out[0] = 1 if the MFMA implicit-GEMM path is
- * used (0 = generic direct kernel), out[1] = voxel groups per wave (NTW), out[2] = lanes
+ * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA
+ * implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel (workgroups walk
+ * several tiles), 2 z-Toeplitz small-Cout kernel; out[1] = voxel groups per wave (NTW), out[2] = lanes
  * along x per group (GX), out[3] = split-K factor.  Pure host function. */
 int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4);
 

@@ -258,6 +258,212 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   }
 }
 
+// ---- persistent variant of conv3_mfma_fwd_kernel ----
+// A workgroup of the kernel above lives for nchunks/ksplit chunks and pays ~2.5 chunks of fixed
+// cost around them (measured: 8-chunk layers reach 112 TFLOP/s, 48-chunk layers 140): the first
+// chunk's load latency + commit, the output stores, the launch of the next workgroup.  Here the grid
+// is one residency (2 workgroups per CU) and every workgroup walks items it, it + G, ...
+// (item = output tile x 32-channel tile x sample x split, same order as the grid above).  The
+// (item, chunk) sequence is flattened: during the last chunk of an item the FIRST chunk of the next
+// item is prefetched, so the MFMA stream only stops for the output stores.
+template <int NTW, int GX>
+__global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
+    int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles,
+    int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride) {
+  using T = FwdTile<NTW, GX>;
+  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
+                CS = T::CS, CC = T::CC;
+  constexpr int XE = CC * CS;
+  constexpr int XPER = (XE + 255) / 256;
+  constexpr int WE4 = CC * 27 * 8;
+  constexpr int WPER = (WE4 + 255) / 256;
+  constexpr int NSTEP = (CC / 2) * 27;
+  static_assert(XPER <= NSTEP && WPER <= NSTEP, "one prefetch item per MFMA step");
+  static_assert(TZ + 2 <= 8 && TY + 2 <= 64 && TX + 2 <= 64, "halo coordinates fit the code fields");
+  __shared__ float xs[2][XE];
+  __shared__ __attribute__((aligned(16))) float ws[2][CC * 27 * 32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const int ly = l32 / GX, lx = l32 % GX;
+  const int64_t HW = (int64_t)H * W;
+  const int DHW = (int)(HW * D);
+  const int iHW = (int)HW;
+
+  const int sp_tiles = tz_tiles * ty_tiles * tx_tiles;
+  const int total = sp_tiles * otiles * nbatch * ksplit;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+
+  struct Item {
+    int z0, y0, x0, o0, n, ks, ch_begin, ch_end;
+  };
+  auto decode = [&](int it) {
+    Item q;
+    int sp = it % sp_tiles, r = it / sp_tiles;
+    const int txt = sp % tx_tiles;
+    sp /= tx_tiles;
+    q.x0 = txt * TX;
+    q.y0 = (sp % ty_tiles) * TY;
+    q.z0 = (sp / ty_tiles) * TZ;
+    q.o0 = (r % otiles) * 32;
+    r /= otiles;
+    q.ks = r % ksplit;
+    q.n = r / ksplit;
+    q.ch_begin = q.ks * cps;
+    q.ch_end = min(nchunks, q.ch_begin + cps);
+    return q;
+  };
+
+  // tile-invariant part of this thread's gather elements: offset from the halo origin and the halo
+  // coordinates packed as zz | yy << 8 | xx << 16; elements past the tile never validate
+  int rel[XPER];
+  unsigned code[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    const int c = e / CS, r = e - c * CS;
+    const int zz = r / PS, r2 = r - zz * PS;
+    const int yy = r2 / RS, xx = r2 - yy * RS;
+    rel[i] = c * DHW + zz * iHW + yy * W + xx;
+    code[i] = e < XE ? ((unsigned)zz | ((unsigned)yy << 8) | ((unsigned)xx << 16)) : 0x00FFFFFFu;
+  }
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[XPER];
+  auto compute_goff = [&](const Item& q) {
+    const int base = (q.z0 - 1) * iHW + (q.y0 - 1) * W + (q.x0 - 1);
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+      const unsigned cd = code[i];
+      // 0xFF fields (elements past the tile) are out of range for any volume this kernel accepts
+      const bool ok = (unsigned)(q.z0 - 1 + (int)(cd & 0xFFu)) < (unsigned)D &&
+                      (unsigned)(q.y0 - 1 + (int)((cd >> 8) & 0xFFu)) < (unsigned)H &&
+                      (unsigned)(q.x0 - 1 + (int)(cd >> 16)) < (unsigned)W;
+      goff[i] = ok ? (unsigned)(base + rel[i]) * 4u : OOB;
+    }
+  };
+
+  float xr[XPER];
+  f32x4 wr[WPER];
+  __amdgpu_buffer_rsrc_t rx;
+  const float* wsrc = wp;
+  auto chunk_setup = [&](const Item& q, int ch, bool live) {  // !live: zero-sized descriptor
+    const int c0 = ch * CC;
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)q.n * xbs + (int64_t)c0 * DHW), 0,
+                                           live ? min(CC, Cin - c0) * DHW * 4 : 0, 0x00020000);
+    wsrc = wp + (int64_t)c0 * 27 * cout_pad + q.o0;
+  };
+  auto fetch_item = [&](int s) {
+    if (s < XPER) xr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[s], 0, 0));
+    if (s < WPER) {
+      const int idx = tid + 256 * s;
+      const int idc = idx < WE4 ? idx : WE4 - 1;
+      wr[s] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XE) xs[buf][tid + 256 * i] = xr[i];
+#pragma unroll
+    for (int j = 0; j < WPER; ++j)
+      if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
+  };
+
+  int it = blockIdx.x;
+  if (it >= total) return;
+  Item cur = decode(it);
+  compute_goff(cur);
+  chunk_setup(cur, cur.ch_begin, true);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) fetch_item(s);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+
+  f32x16 acc[NTW];
+  while (true) {
+#pragma unroll
+    for (int g = 0; g < NTW; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    Item nxt = cur;
+    for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
+      if (ch + 1 < cur.ch_end) {
+        chunk_setup(cur, ch + 1, true);
+      } else {  // last chunk of this item: prefetch the first chunk of the next one
+        const bool live = it + (int)gridDim.x < total;
+        nxt = decode(live ? it + (int)gridDim.x : it);
+        compute_goff(nxt);
+        chunk_setup(nxt, nxt.ch_begin, live);
+      }
+      const float* xb = xs[buf] + half * CS + wave * PS + ly * RS + lx;
+      const float* wb = ws[buf] + half * (27 * 32) + l32;
+      float av[2], bv[2][NTW];
+      auto lds_step = [&](int s, int slot) {
+        const int cp = s / 27, tap = s % 27;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        av[slot] = wb[(2 * cp * 27 + tap) * 32];
+#pragma unroll
+        for (int g = 0; g < NTW; ++g) bv[slot][g] = xb[2 * cp * CS + dz * PS + (g * GY + dy) * RS + dx];
+      };
+      lds_step(0, 0);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + 1 < NSTEP) lds_step(s + 1, (s + 1) & 1);
+        fetch_item(s);
+#pragma unroll
+        for (int g = 0; g < NTW; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NTW; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      commit(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    // ---- output tile of `cur`: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*half
+    const int z = cur.z0 + wave;
+    const int xg = cur.x0 + lx;
+    if (z < D && xg < W) {
+      float* dst = ksplit == 1 ? y + (int64_t)cur.n * ybs
+                               : slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * D * HW;
+      const float* an = (ksplit == 1 && add) ? add + (int64_t)cur.n * ybs : nullptr;
+      const bool fuse = ksplit == 1;
+#pragma unroll
+      for (int g = 0; g < NTW; ++g) {
+        const int yg = cur.y0 + g * GY + ly;
+        if (yg >= H) continue;
+        const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = cur.o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < Cout) {
+            const int64_t idx = (int64_t)o * D * HW + sp;
+            float v = acc[g][r];
+            if (fuse && bias) v += bias[o];
+            if (an) v += an[idx];
+            dst[idx] = v;
+          }
+        }
+      }
+    }
+    it += (int)gridDim.x;
+    if (it >= total) break;
+    cur = nxt;
+  }
+}
+
 // ---------------------------------------------------------------- bf16 compute mode
 // Same implicit GEMM with operands rounded to bf16 (RNE) and v_mfma_f32_32x32x16_bf16 (fp32
 // accumulate, 16x the fp32-MFMA rate).  The K-step of 16 is 16 input channels at ONE tap:
@@ -1004,8 +1210,10 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
     __syncthreads();
   }
 
-  // partial dW -> slab[split][Cout][Cin][27]
-  float* sl = slab + (int64_t)split * Cout * Cin * 27;
+  // partial dW -> slab[split][27][Cout][Cin]: the lane index is the input channel, so every store
+  // writes 32 consecutive floats (the [o][c][27] order of dW would scatter each lane to its own
+  // cache line: 28k line requests per workgroup instead of ~900)
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
   const int c = c0 + l32;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
@@ -1014,10 +1222,38 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
+        if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
       }
     }
   }
+}
+
+// dW[o][c][27] = sum over splits of slab[split][27][o][c] (fixed order): one block per (o, 32 input
+// channels); coalesced reads along c, transposed through LDS, one contiguous 864-float write.
+__global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                            int Cin, int Cout, int nsplit) {
+  __shared__ float tr[32 * 27 + 32];
+  const int o = blockIdx.x, c0 = blockIdx.y * 32;
+  const int64_t plane = (int64_t)Cout * Cin, split_stride = 27 * plane;
+  const int cw = min(32, Cin - c0);
+  for (int e = threadIdx.x; e < 27 * 32; e += 256) {
+    const int tap = e >> 5, cl = e & 31;
+    float v = 0.f;
+    if (cl < cw) {
+      const float* p = slab + (int64_t)tap * plane + (int64_t)o * Cin + c0 + cl;
+      int s = 0;
+      for (; s + 4 <= nsplit; s += 4) {  // 4 independent loads in flight, summed in split order
+        const float t0 = p[(int64_t)s * split_stride], t1 = p[(int64_t)(s + 1) * split_stride],
+                    t2 = p[(int64_t)(s + 2) * split_stride], t3 = p[(int64_t)(s + 3) * split_stride];
+        v += t0; v += t1; v += t2; v += t3;
+      }
+      for (; s < nsplit; ++s) v += p[(int64_t)s * split_stride];
+    }
+    tr[cl * 27 + tap] = v;
+  }
+  __syncthreads();
+  float* dst = out + ((int64_t)o * Cin + c0) * 27;
+  for (int e = threadIdx.x; e < cw * 27; e += 256) dst[e] = tr[e];
 }
 
 // ------------------------------------------- bwd-weight, tiny channel count on one side
@@ -1470,6 +1706,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_bwd_weight_kernel(
 // ------------------------------------------------------------------ planning
 struct FwdPlan {
   bool mfma;
+  bool persistent;  // more items than resident workgroups: conv3_mfma_fwd_p_kernel
   int gx, ntw;
   int tz_tiles, ty_tiles, tx_tiles;
   int otiles, kin_pad, mout_pad, nchunks, ksplit;
@@ -1493,7 +1730,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   // workgroups of one launch do equal work, so the time is rounds x (workgroups sharing a CU) x
   // time of one workgroup, and a launch that needs 1.1 rounds costs as much as one that needs 2.
   //   slots     NTW <= 4: 66.8 KB LDS -> two workgroups per CU (512); NTW = 8: one (256)
-  //   one chunk 54 x NTW MFMAs of 64 cycles per wave at ~2.04 GHz; + ~2 chunks of fill/epilogue
+  //   one chunk 54 x NTW MFMAs of 64 cycles per wave at ~2.04 GHz; + fill/epilogue (see `fixed`)
   //   split-K   ks x out bytes written + read again by the reduce kernel (~4 TB/s) + a launch
   const int64_t out_bytes = (int64_t)N * mout * D * H * W * 4;
   const int force_ntw = env_int("M355_CONV_NTW", 0);
@@ -1522,7 +1759,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
     if (ty > H && ntw > 1 && !force_ntw) continue;  // do not overhang H by a whole factor
     const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
     const int per_cu = ntw <= 4 ? 2 : 1;
-    const double chunk_us = 54.0 * ntw * 64.0 / 2040.0;
+    // narrow tiles re-read the weights from LDS more often per MFMA ((1 + NTW) / NTW reads each)
+    const double chunk_us = 54.0 * ntw * 64.0 / 2040.0 / (ntw >= 4 ? 1.0 : ntw == 2 ? 0.96 : 0.8);
     for (int ks = 1; ks <= std::min(p.nchunks, 8); ++ks) {
       if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;  // an empty split
       if (ks > 1 && ks * out_bytes > (128ll << 20)) break;
@@ -1532,7 +1770,10 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
       // the paired rate for NTW <= 4 (u0.c0 pinned to one per CU: 111 vs 126 TFLOP/s), ~0.93 for NTW = 8
       const bool lone = per_cu == 1 || nwg <= 256;
       const double share = lone ? 1.0 / (per_cu == 1 ? 0.93 : 0.8) : (double)per_cu;
-      double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + 2.0) * chunk_us;
+      // fixed cost of an item: ~2 chunks for a one-shot workgroup, ~0.5 when the persistent kernel
+      // (more items than resident workgroups) prefetches across the item boundary
+      const double fixed = nwg > 256 * per_cu ? 0.5 : 2.0;
+      double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + fixed) * chunk_us;
       if (ks > 1) cost += (2.0 * ks + 1.0) * (double)out_bytes / 4.0e6 + 4.0;
       if (cost < best * 0.98) {  // candidates come in order of preference: switch only for a real gain
         best = cost;
@@ -1550,6 +1791,13 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   p.ty_tiles = (int)ceil_div(H, p.ntw * gy);
   p.ksplit = chosen_ks;
   const int ksplit = chosen_ks;
+  {
+    // resident workgroups (LDS + registers: 2 per CU up to NTW = 4); the override exists for the tests
+    const int64_t slots = env_int("M355_CONV_SLOTS", p.ntw <= 4 ? 512 : 256);
+    const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
+    p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
+                   env_int("M355_CONV_PERSISTENT", 1);
+  }
   p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (compute == M355_COMPUTE_BF16 ? 2 : 4), 256);
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
@@ -1580,6 +1828,13 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
   dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  if (p.persistent) {
+    const int64_t slots = env_int("M355_CONV_SLOTS", NTW <= 4 ? 512 : 256);
+    hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
+                       add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
+                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride);
+    return;
+  }
   hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
                      y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
                      p.ksplit, xbs, ybs, slab_stride);
@@ -1799,7 +2054,7 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  out4[0] = 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  out4[0] = p.persistent ? 3 : 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 
@@ -1938,10 +2193,14 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
       M355_BWW_LAUNCH(16)
     else
       M355_BWW_LAUNCH(8)
-    const int64_t total = (int64_t)d->Cout * d->Cin * 27;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total,
-                       p.nsplit);
+    if (gen2) {
+      hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)p.ctiles), dim3(256), 0, st, slab, dw,
+                         d->Cin, d->Cout, p.nsplit);
+    } else {
+      const int64_t total = (int64_t)d->Cout * d->Cin * 27;
+      const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total, p.nsplit);
+    }
     }
   } else {
     const int k3 = d->k * d->k * d->k;

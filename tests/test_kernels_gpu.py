@@ -71,6 +71,23 @@ def test_conv3d_generic_direct(hip, oracle, case):
     close(db_h, db_o, 3e-5, 1e-4)
 
 
+@pytest.mark.parametrize("env", [{"M355_CONV_SLOTS": "7"}, {"M355_CONV_SLOTS": "5", "M355_CONV_KSPLIT": "2"},
+                                 {"M355_CONV_SLOTS": "3", "M355_CONV_NTW": "8"}])
+def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, monkeypatch):
+    """The persistent forward kernel (workgroups walk several output tiles, prefetching across the
+    tile boundary) on ragged volumes, N = 2, residual add, split-K and the one-per-CU NTW = 8 tile:
+    a tiny residency forces every workgroup through many items."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for (N, ci, co, D, H, W) in [(2, 12, 40, 9, 10, 36), (1, 5, 33, 6, 21, 16), (1, 8, 8, 12, 9, 8)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+        add = rnd(N, co, D, H, W, seed=4)
+        close(hip.conv3d_fwd(x, w, b, add), oracle.conv3d_fwd(x, w, b, add), 2e-5, 2e-5, "persistent fwd")
+        dy = rnd(N, co, D, H, W, seed=5)
+        close(hip.conv3d_bwd_data(dy, w, x.shape), oracle.conv3d_bwd_data(dy, w, x.shape), 2e-5, 2e-5,
+              "persistent bwd_data")
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
