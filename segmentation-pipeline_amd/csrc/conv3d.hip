@@ -65,6 +65,52 @@ struct FwdTile {
   static constexpr int NROWS = CC * (TZ + 2) * (TY + 2);
 };
 
+// Output tile of one wave: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// The bias / residual values of all 16 rows are loaded as one batch (one wait) and the row offsets
+// k*DHW are uniform, so the 16*NTW stores go out back to back.  (Written the obvious way --
+// `if (o < Cout) { v = acc; if (bias) v += bias[o]; if (add) v += add[idx]; y[idx] = v; }` per
+// element -- hipcc emits a branch, a load and a vmcnt(0) per element: ~10 us per tile with the
+// matrix core idle.)
+template <int NTW, int GY>
+__device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float* __restrict__ dst,
+                                                const float* __restrict__ addp, const float* __restrict__ bias,
+                                                int o0, int Cout, int z, int y0, int xg, int ly, int half,
+                                                int D, int H, int W) {
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  const int ob = o0 + 4 * half;  // this lane's first output channel; row r is channel ob + (r&3) + 8*(r>>2)
+  float bb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bb[r] = 0.f;
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[r] = bias[min(ob + (r & 3) + 8 * (r >> 2), Cout - 1)];
+  }
+#pragma unroll
+  for (int g = 0; g < NTW; ++g) {
+    const int yg = y0 + g * GY + ly;
+    if (yg >= H) continue;
+    const int64_t base = (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
+    if (addp) {
+      float aa[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        aa[r] = addp[base + (ob + k < Cout ? (int64_t)k * DHW : 0)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += aa[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2);
+      if (ob + k < Cout) dst[base + (int64_t)k * DHW] = v[r];
+    }
+  }
+}
+
 // One workgroup per CU by design (128 accumulator + prefetch registers -> 1 wave per SIMD):
 // the next chunk's input halo tile and weights are fetched into registers BEFORE the MFMA loop
 // of the current chunk and written to the other LDS buffer after it, so global-memory latency
@@ -218,44 +264,16 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // ---- epilogue ----
   const int z = z0 + wave;
   const int xg = x0 + lx;
   if (z >= D || xg >= W) return;
-  if (ksplit == 1) {
-    float* yn = y + (int64_t)n * ybs;
-    const float* an = add ? add + (int64_t)n * ybs : nullptr;
-#pragma unroll
-    for (int g = 0; g < NTW; ++g) {
-      const int yg = y0 + g * GY + ly;
-      if (yg >= H) continue;
-      const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) {
-          const int64_t idx = (int64_t)o * D * HW + sp;
-          float v = acc[g][r];
-          if (bias) v += bias[o];
-          if (an) v += an[idx];
-          yn[idx] = v;
-        }
-      }
-    }
-  } else {
-    float* sn = slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW;
-#pragma unroll
-    for (int g = 0; g < NTW; ++g) {
-      const int yg = y0 + g * GY + ly;
-      if (yg >= H) continue;
-      const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sn[(int64_t)o * D * HW + sp] = acc[g][r];
-      }
-    }
-  }
+  if (ksplit == 1)
+    store_conv_tile<NTW, GY>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z,
+                             y0, xg, ly, half, D, H, W);
+  else
+    store_conv_tile<NTW, GY>(acc, slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW, nullptr, nullptr,
+                             o0, Cout, z, y0, xg, ly, half, D, H, W);
 }
 
 // ---- persistent variant of conv3_mfma_fwd_kernel ----
@@ -432,31 +450,16 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
       buf ^= 1;
     }
 
-    // ---- output tile of `cur`: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*half
+    // ---- output tile of `cur` ----
     const int z = cur.z0 + wave;
     const int xg = cur.x0 + lx;
     if (z < D && xg < W) {
-      float* dst = ksplit == 1 ? y + (int64_t)cur.n * ybs
-                               : slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * D * HW;
-      const float* an = (ksplit == 1 && add) ? add + (int64_t)cur.n * ybs : nullptr;
-      const bool fuse = ksplit == 1;
-#pragma unroll
-      for (int g = 0; g < NTW; ++g) {
-        const int yg = cur.y0 + g * GY + ly;
-        if (yg >= H) continue;
-        const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = cur.o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (o < Cout) {
-            const int64_t idx = (int64_t)o * D * HW + sp;
-            float v = acc[g][r];
-            if (fuse && bias) v += bias[o];
-            if (an) v += an[idx];
-            dst[idx] = v;
-          }
-        }
-      }
+      if (ksplit == 1)
+        store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
+                                 cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W);
+      else
+        store_conv_tile<NTW, GY>(acc, slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * D * HW, nullptr,
+                                 nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W);
     }
     it += (int)gridDim.x;
     if (it >= total) break;
