@@ -81,6 +81,19 @@ int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
                     const float* bias, const float* add, float* y,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward with the statistics of the following normalisation fused into the epilogue
+ * (Block3d: conv -> norm, models/components.py:51-53): besides y the kernel writes, per sample n,
+ * slot p and output channel o, the (sum, sum of squares) of the y values one wave stored:
+ *   stat_partials[((n * P + p) * Cout + o) * 2 + {0,1}],   P = m355_conv3d_stats_slots(desc)
+ * (every slot of every channel is written; slots of waves that lie outside the volume hold zeros).
+ * m355_norm_stats_from_partials() turns them into mean / rstd without reading y again.
+ * P == 0 means this descriptor has no fused statistics (not 3x3x3 s1 p1, Cout <= 4, bf16 operand
+ * mode, or a split-K plan): call m355_conv3d_fwd + m355_norm_stats instead. */
+int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d);
+int m355_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, const float* w,
+                          const float* bias, const float* add, float* y, float* stat_partials,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
  * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA
  * implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel (workgroups walk
@@ -151,6 +164,12 @@ size_t m355_norm_workspace(const m355_norm_desc* d);
 int m355_norm_stats(const m355_norm_desc* d, const float* x, float* mean, float* rstd,
                     float* running_mean, float* running_var, float momentum,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* The same statistics from the partials of m355_conv3d_fwd_stats (x is not read).  `slots` = P of
+ * the producing conv; desc->C must be that conv's Cout and desc->S its output voxel count.
+ * Workspace: m355_norm_workspace(desc) bytes.  Fixed summation order (double), bit-reproducible. */
+int m355_norm_stats_from_partials(const m355_norm_desc* d, const float* stat_partials, int64_t slots,
+                                  float* mean, float* rstd, float* running_mean, float* running_var,
+                                  float momentum, void* workspace, size_t workspace_bytes, void* stream);
 /* BN eval mode: derive mean/rstd from the running statistics. */
 int m355_norm_stats_from_running(const m355_norm_desc* d, const float* running_mean,
                                  const float* running_var, float* mean, float* rstd,

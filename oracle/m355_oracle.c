@@ -362,6 +362,59 @@ int m355o_norm_stats(const m355_norm_desc* d, const float* x, float* mean, float
   return 0;
 }
 
+/* Fused conv + statistics (Block3d conv -> norm, reference models/components.py:51-53): the oracle
+ * keeps ONE partial slot per (sample, channel) -- the exact (sum, sum of squares) of y in double,
+ * rounded to float -- which is all the contract promises about the partials. */
+int64_t m355o_conv3d_stats_slots(const m355_conv3d_desc* d) {
+  return (d && d->k == 3 && d->stride == 1 && d->pad == 1) ? 1 : 0;
+}
+int m355o_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, const float* w, const float* bias,
+                           const float* add, float* y, float* part, void* ws, size_t wsb, void* stream) {
+  const int rc = m355o_conv3d_fwd(d, x, w, bias, add, y, ws, wsb, stream);
+  if (rc) return rc;
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * S);
+  for (int n = 0; n < d->N; ++n)
+    for (int o = 0; o < d->Cout; ++o) {
+      const float* p = y + n * ybs + (int64_t)o * S;
+      double a = 0.0, b = 0.0;
+      for (int64_t i = 0; i < S; ++i) { a += p[i]; b += (double)p[i] * p[i]; }
+      part[((int64_t)n * d->Cout + o) * 2 + 0] = (float)a;
+      part[((int64_t)n * d->Cout + o) * 2 + 1] = (float)b;
+    }
+  return 0;
+}
+int m355o_norm_stats_from_partials(const m355_norm_desc* d, const float* part, int64_t slots, float* mean,
+                                   float* rstd, float* running_mean, float* running_var, float momentum,
+                                   void* ws, size_t wsb, void* stream) {
+  (void)stream; (void)ws; (void)wsb;
+  const int64_t ns = m355o_norm_num_stats(d);
+  double* s1 = (double*)calloc((size_t)ns, sizeof(double));
+  double* s2 = (double*)calloc((size_t)ns, sizeof(double));
+  for (int n = 0; n < d->N; ++n)
+    for (int64_t q = 0; q < slots; ++q)
+      for (int c = 0; c < d->C; ++c) {
+        const float* v = part + (((int64_t)n * slots + q) * d->C + c) * 2;
+        const int64_t s = stat_of(d, n, c);
+        s1[s] += v[0]; s2[s] += v[1];
+      }
+  const double count = d->groups == 0 ? (double)d->N * d->S : (double)(d->C / d->groups) * d->S;
+  for (int64_t s = 0; s < ns; ++s) {
+    const double m = s1[s] / count;
+    double var = s2[s] / count - m * m;
+    if (var < 0) var = 0;
+    mean[s] = (float)m;
+    rstd[s] = (float)(1.0 / sqrt(var + (double)d->eps));
+    if (running_mean) running_mean[s] = (1.f - momentum) * running_mean[s] + momentum * (float)m;
+    if (running_var) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      running_var[s] = (1.f - momentum) * running_var[s] + momentum * (float)unb;
+    }
+  }
+  free(s1); free(s2);
+  return 0;
+}
+
 int m355o_norm_stats_from_running(const m355_norm_desc* d, const float* rm, const float* rv,
                                   float* mean, float* rstd, void* stream) {
   (void)stream;

@@ -46,6 +46,8 @@ SIGNATURES = {
     "m355_last_error": (C.c_char_p, []),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
     "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_stats_slots": (_i64, [_CD]),
+    "m355_conv3d_fwd_stats": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_plan": (C.c_int, [_CD, _i32, C.POINTER(C.c_int32)]),
     "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
     "m355_conv3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     "m355_norm_num_stats": (_i64, [_ND]),
     "m355_norm_workspace": (_sz, [_ND]),
     "m355_norm_stats": (C.c_int, [_ND, _P, _P, _P, _P, _P, _f32, _P, _sz, _P]),
+    "m355_norm_stats_from_partials": (C.c_int, [_ND, _P, _i64, _P, _P, _P, _P, _f32, _P, _sz, _P]),
     "m355_norm_stats_from_running": (C.c_int, [_ND, _P, _P, _P, _P, _P]),
     "m355_norm_act_fwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P]),
     "m355_norm_act_bwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _sz, _P]),

@@ -75,7 +75,12 @@ template <int NTW, int GY>
 __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float* __restrict__ dst,
                                                 const float* __restrict__ addp, const float* __restrict__ bias,
                                                 int o0, int Cout, int z, int y0, int xg, int ly, int half,
-                                                int D, int H, int W) {
+                                                int D, int H, int W, bool lane_ok, float* __restrict__ stat) {
+  // lane_ok: this lane's (z, x) column lies inside the volume.  Every lane stays active to the end
+  // (the statistics below are reduced with cross-lane shuffles).
+  // stat (may be null): (sum, sum of squares) of the values this WAVE stores, per output channel ->
+  // stat[o*2 + {0,1}]; the normalisation that follows the conv sums these partials instead of
+  // reading y again (m355_conv3d_fwd_stats / m355_norm_stats_from_partials).
   const int64_t HW = (int64_t)H * W, DHW = HW * D;
   const int ob = o0 + 4 * half;  // this lane's first output channel; row r is channel ob + (r&3) + 8*(r>>2)
   float bb[16];
@@ -85,11 +90,14 @@ __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) bb[r] = bias[min(ob + (r & 3) + 8 * (r >> 2), Cout - 1)];
   }
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
 #pragma unroll
   for (int g = 0; g < NTW; ++g) {
     const int yg = y0 + g * GY + ly;
-    if (yg >= H) continue;
-    const int64_t base = (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg;
+    const bool ok = lane_ok && yg < H;
+    const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
@@ -98,16 +106,51 @@ __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float*
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = (r & 3) + 8 * (r >> 2);
-        aa[r] = addp[base + (ob + k < Cout ? (int64_t)k * DHW : 0)];
+        aa[r] = addp[(ok && ob + k < Cout) ? base + (int64_t)k * DHW : 0];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] += aa[r];
     }
+    if (stat) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ok ? v[r] : 0.f;
+        s1[r] += t;
+        s2[r] = fmaf(t, t, s2[r]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        if (ob + k < Cout) dst[base + (int64_t)k * DHW] = v[r];
+      }
+    }
+  }
+  if (stat) {
+    // reduce-scatter over the 32 lanes of each half (xor < 32 stays inside the half): 32 values
+    // (16 rows x {sum, sumsq}) are summed over 32 lanes with 16+8+4+2+1 shuffles; lane l ends up
+    // holding value index l & 31 = q*16 + r.  Fixed order -> bit-reproducible.
+    float a[32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int k = (r & 3) + 8 * (r >> 2);
-      if (ob + k < Cout) dst[base + (int64_t)k * DHW] = v[r];
+      a[r] = s1[r];
+      a[16 + r] = s2[r];
     }
+    const int l32 = threadIdx.x & 31;
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+      const bool up = (l32 & h) != 0;
+#pragma unroll
+      for (int i = 0; i < h; ++i) {
+        const float send = up ? a[i] : a[i + h];
+        const float keep = up ? a[i + h] : a[i];
+        a[i] = keep + __shfl_xor(send, h, 64);
+      }
+    }
+    const int r = l32 & 15, q = l32 >> 4;
+    const int o = ob + (r & 3) + 8 * (r >> 2);
+    if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
   }
 }
 
@@ -120,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
-    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride) {
+    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride, float* __restrict__ stat) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS = T::CS, CC = T::CC;
@@ -267,13 +310,16 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   // ---- epilogue ----
   const int z = z0 + wave;
   const int xg = x0 + lx;
-  if (z >= D || xg >= W) return;
-  if (ksplit == 1)
+  const bool lane_ok = z < D && xg < W;
+  if (ksplit == 1) {
+    // statistics slot of this wave: stat[n][spatial tile * 4 + wave][Cout][2]
+    float* st = stat ? stat + (((int64_t)n * gridDim.x + blockIdx.x) * 4 + wave) * Cout * 2 : nullptr;
     store_conv_tile<NTW, GY>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z,
-                             y0, xg, ly, half, D, H, W);
-  else
+                             y0, xg, ly, half, D, H, W, lane_ok, st);
+  } else {
     store_conv_tile<NTW, GY>(acc, slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW, nullptr, nullptr,
-                             o0, Cout, z, y0, xg, ly, half, D, H, W);
+                             o0, Cout, z, y0, xg, ly, half, D, H, W, lane_ok, nullptr);
+  }
 }
 
 // ---- persistent variant of conv3_mfma_fwd_kernel ----
@@ -289,7 +335,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles,
-    int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride) {
+    int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride,
+    float* __restrict__ stat) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS = T::CS, CC = T::CC;
@@ -318,11 +365,12 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
   const int cps = (nchunks + ksplit - 1) / ksplit;
 
   struct Item {
-    int z0, y0, x0, o0, n, ks, ch_begin, ch_end;
+    int z0, y0, x0, o0, n, ks, ch_begin, ch_end, sp;
   };
   auto decode = [&](int it) {
     Item q;
     int sp = it % sp_tiles, r = it / sp_tiles;
+    q.sp = sp;
     const int txt = sp % tx_tiles;
     sp /= tx_tiles;
     q.x0 = txt * TX;
@@ -451,15 +499,18 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     }
 
     // ---- output tile of `cur` ----
-    const int z = cur.z0 + wave;
-    const int xg = cur.x0 + lx;
-    if (z < D && xg < W) {
-      if (ksplit == 1)
+    {
+      const int z = cur.z0 + wave;
+      const int xg = cur.x0 + lx;
+      const bool lane_ok = z < D && xg < W;
+      if (ksplit == 1) {
+        float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * 4 + wave) * Cout * 2 : nullptr;
         store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
-                                 cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W);
-      else
+                                 cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, st);
+      } else {
         store_conv_tile<NTW, GY>(acc, slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * D * HW, nullptr,
-                                 nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W);
+                                 nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, nullptr);
+      }
     }
     it += (int)gridDim.x;
     if (it >= total) break;
@@ -1827,7 +1878,7 @@ static bool small_bww(const m355_conv3d_desc* d) {
 template <int NTW, int GX>
 static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
-                       int H, int W, int64_t xbs, int64_t ybs, hipStream_t st) {
+                       int H, int W, int64_t xbs, int64_t ybs, hipStream_t st, float* stat = nullptr) {
   dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
@@ -1835,12 +1886,12 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
     const int64_t slots = env_int("M355_CONV_SLOTS", NTW <= 4 ? 512 : 256);
     hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
                        add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride);
+                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat);
     return;
   }
   hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
                      y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
-                     p.ksplit, xbs, ybs, slab_stride);
+                     p.ksplit, xbs, ybs, slab_stride, stat);
 }
 
 // Runs the MFMA implicit GEMM: out[n, m, v] = bias + add + sum_{kc,tap} wp * in[n, kc, v+tap]
@@ -1859,8 +1910,10 @@ static void launch_bf16(const FwdPlan& p, const float* x, const __bf16* wp, cons
 static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
                          const float* bias, const float* add, float* out, int N, int kin,
                          int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
-                         size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32) {
+                         size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32, float* stat = nullptr) {
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
+  M355_REQUIRE(!stat || (compute == M355_COMPUTE_F32 && p.ksplit == 1), M355_EINVALID_ARG,
+               "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
   if (compute == M355_COMPUTE_BF16) {
     M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                  "conv3d(bf16): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
@@ -1913,7 +1966,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
 #define M355_FWD_CASE(NTW, GX)                                                              \
   if (p.ntw == NTW && p.gx == GX) {                                                         \
     launch_fwd<NTW, GX>(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, \
-                        st);                                                                \
+                        st, stat);                                                          \
   } else
   M355_FWD_CASE(8, 32)
   M355_FWD_CASE(4, 32)
@@ -2010,10 +2063,23 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
   return M355_OK;
 }
 
-extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
-                               const float* bias, const float* add, float* y, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+// Per (sample, output channel): how many (sum, sum of squares) partials the forward kernel writes
+// when statistics are fused (4 waves x spatial tiles); 0 = this descriptor has no fused statistics
+// (not 3x3x3 s1 p1, small-Cout kernel, bf16 operand mode, or a split-K plan).
+static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
+  if (!is_k3s1p1(d) || small_cout_fwd(d) || d->compute != M355_COMPUTE_F32) return 0;
+  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
+  if (p.ksplit != 1) return 0;
+  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
+}
+extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }
+
+static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const float* w, const float* bias,
+                           const float* add, float* y, float* stat, void* workspace, size_t workspace_bytes,
+                           void* stream) {
   if (int rc = validate_conv(d, "conv3d_fwd")) return rc;
+  M355_REQUIRE(!stat || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
+               "conv3d_fwd_stats: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
   M355_REQUIRE(x && w && y, M355_EINVALID_ARG, "conv3d_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
@@ -2040,7 +2106,7 @@ extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const 
   }
   if (is_k3s1p1(d)) {
     return run_mfma_conv(x, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
-                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute);
+                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute, stat);
   }
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
   const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
@@ -2048,6 +2114,19 @@ extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const 
                      d->N, d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k, d->stride, d->pad,
                      xbs, ybs);
   return check_launch("conv3d_direct_fwd");
+}
+
+extern "C" int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
+                               const float* bias, const float* add, float* y, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return conv3d_fwd_impl(d, x, w, bias, add, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int m355_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, const float* w,
+                                     const float* bias, const float* add, float* y, float* stat_partials,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  M355_REQUIRE(stat_partials, M355_EINVALID_ARG, "conv3d_fwd_stats: null statistics buffer");
+  return conv3d_fwd_impl(d, x, w, bias, add, y, stat_partials, workspace, workspace_bytes, stream);
 }
 
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {

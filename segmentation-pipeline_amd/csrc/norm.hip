@@ -116,6 +116,39 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const double* __restr
   }
 }
 
+// statistics from the conv epilogue partials part[n][slot][C][2] (float), stage 1: block (b, s) sums a
+// contiguous share of the (sample, slot, channel-in-group) items of statistic s in a fixed order
+// (double) -> partial[(s*nblk + b)*2 + {0,1}]; norm_finalize_kernel then combines the nblk partials.
+__global__ __launch_bounds__(256) void norm_from_partials_kernel(
+    const float* __restrict__ part, double* __restrict__ partial, int groups, int N, int C, int64_t slots,
+    int nblk) {
+  __shared__ double scratch[4];
+  const int64_t s = blockIdx.y;
+  const int b = blockIdx.x;
+  // GN: s = n*groups + g -> sample n, channels [g*cg, (g+1)*cg); BN: s = channel, all samples
+  const int cg = groups == 0 ? 1 : C / groups;
+  const int c_begin = groups == 0 ? (int)s : (int)(s % groups) * cg;
+  const int64_t n_begin = groups == 0 ? 0 : s / groups, runs = groups == 0 ? N : 1;
+  const int64_t per_n = slots * cg, items = runs * per_n;
+  const int64_t share = (items + nblk - 1) / nblk;
+  const int64_t begin = (int64_t)b * share, end = min(items, begin + share);
+  double t1 = 0.0, t2 = 0.0;
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+    const int64_t run = i / per_n, j = i - run * per_n;
+    const int64_t slot = j / cg;
+    const int c = c_begin + (int)(j - slot * cg);
+    const float2 v = *reinterpret_cast<const float2*>(part + (((n_begin + run) * slots + slot) * C + c) * 2);
+    t1 += (double)v.x;
+    t2 += (double)v.y;
+  }
+  t1 = block_sum<double, 256>(t1, scratch);
+  t2 = block_sum<double, 256>(t2, scratch);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)s * nblk + b) * 2 + 0] = t1;
+    partial[((int64_t)s * nblk + b) * 2 + 1] = t2;
+  }
+}
+
 __global__ void norm_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
                                          float* __restrict__ mean, float* __restrict__ rstd,
                                          float eps, int C) {
@@ -383,6 +416,31 @@ extern "C" int m355_norm_stats(const m355_norm_desc* d, const float* x, float* m
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, mean,
                      rstd, running_mean, running_var, momentum, d->eps, g.nstats, g.nblk, g.count);
   return check_launch("norm_stats");
+}
+
+extern "C" int m355_norm_stats_from_partials(const m355_norm_desc* d, const float* stat_partials, int64_t slots,
+                                             float* mean, float* rstd, float* running_mean,
+                                             float* running_var, float momentum, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  if (int rc = validate_norm(d, "norm_stats_from_partials")) return rc;
+  M355_REQUIRE(stat_partials && mean && rstd && workspace && slots > 0, M355_EINVALID_ARG,
+               "norm_stats_from_partials: null pointer / no slots");
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE,
+               "norm_stats_from_partials: workspace too small");
+  M355_REQUIRE(d->groups == 0 || (!running_mean && !running_var), M355_EINVALID_ARG,
+               "norm_stats_from_partials: running statistics are only defined for batch norm");
+  const NormGeom g = geom(d);
+  M355_REQUIRE(g.nstats <= 65535, M355_EUNSUPPORTED, "norm_stats_from_partials: too many statistics");
+  hipStream_t st = (hipStream_t)stream;
+  // blocks per statistic: ~2048 partial items each, never more than the workspace of norm_stats holds
+  const int64_t items = (d->groups == 0 ? (int64_t)d->N : 1) * slots * (d->groups == 0 ? 1 : d->C / d->groups);
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(g.nblk, ceil_div(items, 2048)));
+  double* partial = (double*)workspace;
+  hipLaunchKernelGGL(norm_from_partials_kernel, dim3((unsigned)nblk, (unsigned)g.nstats), dim3(256), 0, st,
+                     stat_partials, partial, d->groups, d->N, d->C, slots, nblk);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, mean, rstd,
+                     running_mean, running_var, momentum, d->eps, g.nstats, nblk, g.count);
+  return check_launch("norm_stats_from_partials");
 }
 
 extern "C" int m355_norm_stats_from_running(const m355_norm_desc* d, const float* running_mean,

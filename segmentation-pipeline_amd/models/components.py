@@ -190,14 +190,14 @@ def _check_conv_module(m):
     _uniform_int(m.padding, "padding")
 
 
-def run_conv(m, x, add=None, out=None):
+def run_conv(m, x, add=None, out=None, stats=None):
     """Execute an nn.Conv3d-like parameter container with the HIP conv kernels."""
     if hasattr(m, "effective"):
         weight, bias = m.effective()
     else:
         weight, bias = m.weight, m.bias
     return ops.conv3d(x, weight, bias, add=add, stride=_uniform_int(m.stride, "stride"),
-                      padding=_uniform_int(m.padding, "padding"), out=out)
+                      padding=_uniform_int(m.padding, "padding"), out=out, stats=stats)
 
 
 def _act_code(m):
@@ -219,8 +219,17 @@ def _check_norm_module(m):
         "(supported: BatchNorm3d, GroupNorm, InstanceNorm3d)")
 
 
-def run_norm_act(norm, act, x, add=None, out=None):
-    """normalization + activation (+ residual add) through the fused HIP passes."""
+def wants_batch_stats(norm):
+    """True when the normalisation computes statistics from its input (so the producing conv should
+    emit the partial sums): GroupNorm / InstanceNorm always, BatchNorm3d in training mode."""
+    if isinstance(norm, (nn.GroupNorm, nn.InstanceNorm3d)):
+        return True
+    return isinstance(norm, nn.BatchNorm3d) and (norm.training or norm.running_mean is None)
+
+
+def run_norm_act(norm, act, x, add=None, out=None, stats=None):
+    """normalization + activation (+ residual add) through the fused HIP passes.  `stats`: partial
+    sums emitted by the conv that produced `x` (saves the statistics pass over x)."""
     code, slope = _act_code(act)
     if norm is None:
         # activation only: identity statistics
@@ -230,12 +239,12 @@ def run_norm_act(norm, act, x, add=None, out=None):
                           running_var=torch.ones(Cc, device=x.device), out=out)
         return ops.norm_act(x, None, None, cfg, add=add)
     if isinstance(norm, nn.GroupNorm):
-        cfg = ops.NormCfg(groups=norm.num_groups, eps=norm.eps, act=code, slope=slope, out=out)
+        cfg = ops.NormCfg(groups=norm.num_groups, eps=norm.eps, act=code, slope=slope, out=out, stats=stats)
         return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
     if isinstance(norm, nn.InstanceNorm3d):
         if norm.track_running_stats:
             raise NotImplementedError("InstanceNorm3d(track_running_stats=True) has no HIP kernel")
-        cfg = ops.NormCfg(groups=x.shape[1], eps=norm.eps, act=code, slope=slope, out=out)
+        cfg = ops.NormCfg(groups=x.shape[1], eps=norm.eps, act=code, slope=slope, out=out, stats=stats)
         return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
     # BatchNorm3d: batch statistics in training mode (and whenever no running stats exist)
     training = norm.training or norm.running_mean is None
@@ -246,7 +255,8 @@ def run_norm_act(norm, act, x, add=None, out=None):
             momentum = 1.0 / float(norm.num_batches_tracked)
     cfg = ops.NormCfg(groups=0, eps=norm.eps, act=code, slope=slope, training=training,
                       momentum=0.0 if momentum is None else momentum,
-                      running_mean=norm.running_mean, running_var=norm.running_var, out=out)
+                      running_mean=norm.running_mean, running_var=norm.running_var, out=out,
+                      stats=stats if training else None)
     return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
 
 
@@ -322,8 +332,10 @@ class Block3d(nn.Module):
             if norm is None and act is None:
                 h = run_conv(conv, h, add=add, out=slot)
             else:
-                h = run_conv(conv, h)
-                h = run_norm_act(norm, act, h, add=add, out=slot)
+                # the conv epilogue emits the partial sums of the normalisation that follows
+                stats = {} if wants_batch_stats(norm) else None
+                h = run_conv(conv, h, stats=stats)
+                h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats)
         if self._num_convs == 0 and res is not None:
             h = ops.add(res, h)
 

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .components import run_conv, run_norm_act
+from .components import run_conv, run_norm_act, wants_batch_stats
 from .modular_unet import _run_hypothesis
 
 
@@ -40,8 +40,10 @@ class NestedResUNet(nn.Module):
         def forward(self, x, out: Optional[ops.OutSlot] = None):
             res = run_conv(self.res_conv, x) if self.residual else None
             drop = self.dropout is not None and self.training and self.dropout.p > 0.0
-            h = run_norm_act(self.bn1, self.activation1, run_conv(self.conv1, x))
-            h = run_norm_act(self.bn2, self.activation2, run_conv(self.conv2, h), add=res,
+            s1 = {} if wants_batch_stats(self.bn1) else None
+            h = run_norm_act(self.bn1, self.activation1, run_conv(self.conv1, x, stats=s1), stats=s1)
+            s2 = {} if wants_batch_stats(self.bn2) else None
+            h = run_norm_act(self.bn2, self.activation2, run_conv(self.conv2, h, stats=s2), stats=s2, add=res,
                              out=None if drop else out)
             if drop:
                 p = self.dropout.p

@@ -137,6 +137,7 @@ class _ConvMeta:
     catbuf: Optional[torch.Tensor] = None
     out: Optional[OutSlot] = None
     tag: str = "conv3d"
+    stats: Optional[dict] = None   # filled with {"partials", "slots"} when the statistics are fused
 
 
 def _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad=0, compute=0):
@@ -177,8 +178,16 @@ class _Conv3dFn(torch.autograd.Function):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(L.m355_conv3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(ws),
-                                ws.numel(), _stream()), "conv3d_fwd")
+        slots = L.m355_conv3d_stats_slots(C.byref(d)) if meta.stats is not None else 0
+        if slots > 0:
+            # statistics of the following normalisation fused into the conv epilogue (per-wave partials)
+            part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x.device)
+            check(L.m355_conv3d_fwd_stats(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(part), _p(ws),
+                                          ws.numel(), _stream()), "conv3d_fwd_stats")
+            meta.stats["partials"], meta.stats["slots"] = part, slots
+        else:
+            check(L.m355_conv3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(ws),
+                                    ws.numel(), _stream()), "conv3d_fwd")
         if prof is not None:
             e1.record()
             flops = 2.0 * k ** 3 * Cin * Cout * N * oshape[2] * oshape[3] * oshape[4]
@@ -238,16 +247,19 @@ class _Conv3dFn(torch.autograd.Function):
         return (dw if need_w else None, db if need_b else None, dadd, None, *dparts)
 
 
-def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[OutSlot] = None):
+def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[OutSlot] = None,
+           stats: Optional[dict] = None):
     """nn.Conv3d forward (cubic kernel).  `x` is a tensor or a `Concat`; `add` is fused
-    into the epilogue (y = conv(x) + bias + add)."""
+    into the epilogue (y = conv(x) + bias + add).  `stats`: an empty dict asks the kernel to also
+    emit the partial sums the following normalisation needs (filled in when the kernel variant
+    supports it; pass it on as `NormCfg.stats`)."""
     k = weight.shape[2]
     if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
         raise NotImplementedError("only cubic kernels are supported")
     if isinstance(x, Concat):
-        meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out)
+        meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats)
         return _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
-    meta = _ConvMeta(k, stride, padding, out=out)
+    meta = _ConvMeta(k, stride, padding, out=out, stats=stats)
     return _Conv3dFn.apply(weight, bias, add, meta, x)
 
 
@@ -315,6 +327,7 @@ class NormCfg:
     running_mean: Optional[torch.Tensor] = None
     running_var: Optional[torch.Tensor] = None
     out: Optional[OutSlot] = None
+    stats: Optional[dict] = None   # partial sums from the producing conv (ops.conv3d(..., stats=...))
 
 
 class _NormActFn(torch.autograd.Function):
@@ -337,7 +350,18 @@ class _NormActFn(torch.autograd.Function):
         mean = torch.empty(ns, dtype=torch.float32, device=x.device)
         rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
         use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
-        if use_batch:
+        fused = cfg.stats.get("partials") if cfg.stats else None
+        if fused is not None and tuple(fused.shape) != (N, cfg.stats["slots"], Cc, 2):
+            raise _lib.M355Error(f"norm_act: statistics partials {tuple(fused.shape)} do not belong to this tensor")
+        if use_batch and fused is not None:
+            upd = cfg.groups == 0 and cfg.training
+            ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+            check(L.m355_norm_stats_from_partials(C.byref(d), _p(fused), int(cfg.stats["slots"]), _p(mean), _p(rstd),
+                                                  _p(cfg.running_mean) if upd else None,
+                                                  _p(cfg.running_var) if upd else None,
+                                                  float(cfg.momentum), _p(ws), ws.numel(), _stream()),
+                  "norm_stats_from_partials")
+        elif use_batch:
             ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
             upd = cfg.groups == 0 and cfg.training
             check(L.m355_norm_stats(C.byref(d), _p(x), _p(mean), _p(rstd),

@@ -85,6 +85,31 @@ class RawOps:
                                         self._stream()), "conv3d_fwd")
         return y
 
+    def conv3d_fwd_stats(self, x, w, bias=None, groups=0, eps=1e-5):
+        """fused conv + statistics: returns (y, mean, rstd) of the normalisation that follows the conv, or
+        None when this backend has no fused statistics for the shape"""
+        x, w = self.to(x), self.to(w)
+        bias = self.to(bias) if bias is not None else None
+        N, Cin, D, H, W = x.shape
+        Cout = w.shape[0]
+        d = self.conv_desc(x.shape, Cout, 3, 1, 1)
+        slots = self.fn("conv3d_stats_slots")(C.byref(d))
+        if slots <= 0:
+            return None
+        y = self.empty(N, Cout, D, H, W)
+        part = self.empty(N, slots, Cout, 2)
+        ws = self._ws("conv3d_fwd_workspace", d)
+        self._chk(self.fn("conv3d_fwd_stats")(C.byref(d), _p(x), _p(w), _p(bias), None, _p(y), _p(part), _p(ws),
+                                              ws.numel(), self._stream()), "conv3d_fwd_stats")
+        nd = NormDesc(N, Cout, D * H * W, groups, 0, eps, 0.01, 0, 0, 0)
+        ns = self.fn("norm_num_stats")(C.byref(nd))
+        mean, rstd = self.empty(ns), self.empty(ns)
+        nws = self._ws("norm_workspace", nd)
+        self._chk(self.fn("norm_stats_from_partials")(C.byref(nd), _p(part), slots, _p(mean), _p(rstd), None, None,
+                                                      0.1, _p(nws), nws.numel(), self._stream()),
+                  "norm_stats_from_partials")
+        return y, mean, rstd
+
     def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1, compute=0):
         dy, w = self.to(dy), self.to(w)
         d = self.conv_desc(x_shape, w.shape[0], w.shape[2], stride, pad, compute=compute)

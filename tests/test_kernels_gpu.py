@@ -88,6 +88,29 @@ def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, monkeypatch):
               "persistent bwd_data")
 
 
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}])
+def test_conv3d_fused_statistics(hip, oracle, env, monkeypatch):
+    """m355_conv3d_fwd_stats + m355_norm_stats_from_partials == statistics of the conv output (GroupNorm and
+    BatchNorm geometry, ragged volumes with overhanging tiles, N = 2, one-shot and persistent kernels)."""
+    monkeypatch.setenv("M355_CONV_KSPLIT", "1")  # split-K plans (what these small volumes would get) have no fusion
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for (N, ci, co, D, H, W, groups) in [(2, 8, 16, 9, 10, 36, 4), (1, 5, 40, 6, 21, 16, 8), (2, 8, 24, 12, 9, 8, 0),
+                                        (1, 16, 32, 16, 16, 32, 8)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+        got = hip.conv3d_fwd_stats(x, w, b, groups)
+        assert got is not None, "the fp32 3x3x3 MFMA path has fused statistics for these shapes"
+        y, mean, rstd = got
+        yo, mo, ro = oracle.conv3d_fwd_stats(x, w, b, groups)
+        close(y, yo, 2e-5, 2e-5, "y")
+        close(mean, mo, 1e-5, 1e-5, "mean")
+        close(rstd, ro, 1e-5, 1e-5, "rstd")
+        # and against the unfused statistics pass over the same y
+        m2, r2 = hip.norm_stats(y, groups)[:2]
+        close(mean, m2, 1e-5, 1e-6, "mean vs norm_stats")
+        close(rstd, r2, 1e-5, 1e-6, "rstd vs norm_stats")
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
