@@ -1768,10 +1768,25 @@ struct FwdPlan {
 };
 
 // Plan for a 3x3x3/s1/p1 conv with K-channels `kin` and M-channels `mout`.
+// Lanes along x per 32-voxel group: the widest of {32, 16, 8} unless a narrower one wastes noticeably
+// fewer padded voxels (W = 24: 16 -> 2 tiles = 32 columns, 8 -> 3 tiles = 24 columns).
+static int pick_gx(int W) {
+  int best = 8;
+  int64_t best_pad = round_up(W, 8);
+  for (int gx : {16, 32}) {
+    const int64_t pad = round_up(W, gx);
+    if (W >= gx && pad * 100 <= best_pad * 108) {  // prefer the wider tile unless it pads > 8 % more
+      best = gx;
+      best_pad = std::min(best_pad, pad);
+    }
+  }
+  return best;
+}
+
 static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32) {
   FwdPlan p{};
   p.mfma = true;
-  p.gx = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+  p.gx = pick_gx(W);
   const int gy = 32 / p.gx;
   const int cc = compute == M355_COMPUTE_BF16 ? 16 : 4;  // input channels per LDS chunk
   p.kin_pad = (int)round_up(kin, cc);
@@ -1857,8 +1872,11 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   return p;
 }
 
+// The MFMA kernels: 3x3x3, stride 1, padding 1, and a volume whose 4-channel slab fits the 32-bit byte
+// offsets of a buffer descriptor (< 2^27 voxels, i.e. below 512^3); anything else takes the generic
+// direct kernels (64-bit indexing).
 static bool is_k3s1p1(const m355_conv3d_desc* d) {
-  return d->k == 3 && d->stride == 1 && d->pad == 1;
+  return d->k == 3 && d->stride == 1 && d->pad == 1 && (int64_t)d->D * d->H * d->W < (1ll << 27);
 }
 
 static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
@@ -2001,7 +2019,7 @@ struct BwwPlan {
 
 static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
   BwwPlan p{};
-  p.gx = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+  p.gx = pick_gx(W);
   const int tz = p.gx == 8 ? 4 : 2, ty = p.gx == 32 ? 4 : 8;
   p.tz_tiles = (int)ceil_div(D, tz);
   p.ty_tiles = (int)ceil_div(H, ty);
