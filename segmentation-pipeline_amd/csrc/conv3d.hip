@@ -1,7 +1,8 @@
 // conv3d for gfx950: fp32 implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32,
 // k-ordered fma chain) for the 3x3x3 / stride 1 / pad 1 convolutions that carry
-// ~97 % of the U-Net FLOPs, plus generic direct kernels for every other
-// kernel-size / stride / padding the reference reaches (BlurConv3d k=4 s=2).
+// ~97 % of the U-Net FLOPs, plus generic direct kernels for any other
+// kernel-size / stride / padding (the reference's BlurConv3d, k=4 s=2, reaches the
+// 3x3x3 kernels through a space-to-depth rearrangement, models/components.py).
 //
 // Reference ops replaced: nn.Conv3d in Block3d (models/components.py:36,42,51),
 // out conv (models/modular_unet.py:83,99), F.conv3d in BlurConv3d
@@ -154,10 +155,11 @@ __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float*
   }
 }
 
-// One workgroup per CU by design (128 accumulator + prefetch registers -> 1 wave per SIMD):
-// the next chunk's input halo tile and weights are fetched into registers BEFORE the MFMA loop
-// of the current chunk and written to the other LDS buffer after it, so global-memory latency
-// hides under ~14k cycles of MFMA work; one barrier per chunk.
+// One output tile per workgroup (used when a launch has no more tiles than resident workgroups;
+// otherwise conv3_mfma_fwd_p_kernel below).  Two workgroups per CU up to NTW = 4, one for NTW = 8,
+// i.e. one or two waves per SIMD: the next chunk's input halo tile and weights travel
+// global -> registers -> the other LDS buffer while the current chunk is multiplied, with the
+// prefetch instructions interleaved into the MFMA stream; one barrier per chunk (~14k MFMA cycles).
 template <int NTW, int GX>
 __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
