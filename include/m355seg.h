@@ -262,6 +262,21 @@ int m355_space_to_depth2(const float* x, float* y, int32_t N, int32_t C, int32_t
 int m355_depth_to_space2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                          int64_t x_batch_stride, int64_t y_batch_stride, void* stream);
 
+/* Weight transform of BlurConv3d / BlurConvTranspose3d (reference models/components.py:112-119,
+ * 145-152) for 3x3x3 filters: optional per-filter standardisation (unbiased std, eps 1e-5), the
+ * depthwise 2x2x2 box blur with padding 1 (scale[b] = value of the module's `kernel` buffer for
+ * dim-1 channel b) giving a 4x4x4 filter, and its rearrangement into the sparse 3x3x3 filter of the
+ * space-to-depth formulation, in one pass.  w: [A][B][27] (the module's weight: A = Cout, B = Cin for
+ * the strided conv; A = Cin, B = Cout for the transposed conv).
+ *   transposed == 0:  wexp [A][8B][27]   (conv3d weight over the space-to-depth input)
+ *   transposed == 1:  wexp [8B][A][27]   (conv3d weight producing the 8 output parities)
+ * mean_std: [A][2] saved statistics (written by fwd, read by bwd; may be NULL when standardize == 0).
+ * bwd: dw = d(loss)/d(w) from dwexp. */
+int m355_blur_weight_fwd(const float* w, const float* scale, float* wexp, float* mean_std, int32_t A, int32_t B,
+                         int32_t standardize, int32_t transposed, void* stream);
+int m355_blur_weight_bwd(const float* dwexp, const float* w, const float* scale, const float* mean_std, float* dw,
+                         int32_t A, int32_t B, int32_t standardize, int32_t transposed, void* stream);
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio
  * 0.18.45 GridSampler / GridAggregator(overlap_mode='average').  These entry

@@ -756,6 +756,84 @@ int m355o_space_to_depth2(const float* x, float* y, int32_t N, int32_t C, int32_
 int m355o_depth_to_space2(const float* x, float* y, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                           int64_t xbs, int64_t ybs, void* stream) { (void)stream; return s2d_o(x, y, N, C, D, H, W, xbs, ybs, 0); }
 
+/* Blur-convolution weight transform (reference models/components.py:112-119, 145-152; see
+ * include/m355seg.h): standardise (unbiased std, eps 1e-5) -> depthwise 2x2x2 box blur with padding 1 ->
+ * gather into the sparse 3x3x3 filter of the space-to-depth formulation.  All in double. */
+static int blur_d(int par, int tap, int transposed) { return transposed ? 3 - 2 * tap + par : 2 * tap - 1 + par; }
+static int64_t blur_o(int a, int b, int p, int t, int A, int B, int transposed) {
+  return transposed ? (((int64_t)b * 8 + p) * A + a) * 27 + t : (((int64_t)a * B + b) * 8 + p) * 27 + t;
+}
+int m355o_blur_weight_fwd(const float* w, const float* scale, float* wexp, float* mean_std, int32_t A, int32_t B,
+                          int32_t standardize, int32_t transposed, void* stream) {
+  (void)stream;
+  const int n = B * 27;
+  for (int a = 0; a < A; ++a) {
+    const float* wa = w + (int64_t)a * n;
+    double m = 0.0, inv = 1.0;
+    if (standardize) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < n; ++i) { s1 += wa[i]; }
+      m = s1 / n;
+      for (int i = 0; i < n; ++i) { s2 += (wa[i] - m) * (wa[i] - m); }
+      const double sd = n > 1 ? sqrt(s2 / (n - 1)) : 0.0;
+      inv = 1.0 / (sd + 1e-5);
+      mean_std[a * 2 + 0] = (float)m;
+      mean_std[a * 2 + 1] = (float)sd;
+    }
+    for (int b = 0; b < B; ++b)
+      for (int p = 0; p < 8; ++p)
+        for (int t = 0; t < 27; ++t) {
+          const int dz = blur_d(p >> 2, t / 9, transposed), dy = blur_d((p >> 1) & 1, (t / 3) % 3, transposed),
+                    dx = blur_d(p & 1, t % 3, transposed);
+          double v = 0.0;
+          if (dz >= 0 && dz <= 3 && dy >= 0 && dy <= 3 && dx >= 0 && dx <= 3) {
+            for (int q = 0; q < 8; ++q) {
+              const int z = dz + (q >> 2) - 1, y = dy + ((q >> 1) & 1) - 1, x = dx + (q & 1) - 1;
+              if (z >= 0 && z <= 2 && y >= 0 && y <= 2 && x >= 0 && x <= 2)
+                v += ((double)wa[b * 27 + (z * 3 + y) * 3 + x] - m) * inv;
+            }
+            v *= scale[b];
+          }
+          wexp[blur_o(a, b, p, t, A, B, transposed)] = (float)v;
+        }
+  }
+  return 0;
+}
+int m355o_blur_weight_bwd(const float* dwexp, const float* w, const float* scale, const float* mean_std, float* dw,
+                          int32_t A, int32_t B, int32_t standardize, int32_t transposed, void* stream) {
+  (void)stream;
+  const int n = B * 27;
+  double* g = (double*)malloc(sizeof(double) * (size_t)n);
+  for (int a = 0; a < A; ++a) {
+    const float* wa = w + (int64_t)a * n;
+    for (int i = 0; i < n; ++i) g[i] = 0.0;
+    /* adjoint of the gather + blur: every valid (p, t) sends its gradient to the 8 filter taps it summed */
+    for (int b = 0; b < B; ++b)
+      for (int p = 0; p < 8; ++p)
+        for (int t = 0; t < 27; ++t) {
+          const int dz = blur_d(p >> 2, t / 9, transposed), dy = blur_d((p >> 1) & 1, (t / 3) % 3, transposed),
+                    dx = blur_d(p & 1, t % 3, transposed);
+          if (dz < 0 || dz > 3 || dy < 0 || dy > 3 || dx < 0 || dx > 3) continue;
+          const double go = (double)dwexp[blur_o(a, b, p, t, A, B, transposed)] * scale[b];
+          for (int q = 0; q < 8; ++q) {
+            const int z = dz + (q >> 2) - 1, y = dy + ((q >> 1) & 1) - 1, x = dx + (q & 1) - 1;
+            if (z >= 0 && z <= 2 && y >= 0 && y <= 2 && x >= 0 && x <= 2) g[b * 27 + (z * 3 + y) * 3 + x] += go;
+          }
+        }
+    if (!standardize) {
+      for (int i = 0; i < n; ++i) dw[(int64_t)a * n + i] = (float)g[i];
+      continue;
+    }
+    const double m = mean_std[a * 2 + 0], sd = mean_std[a * 2 + 1], se = sd + 1e-5;
+    double sg = 0.0, sgw = 0.0;
+    for (int i = 0; i < n; ++i) { sg += g[i]; sgw += g[i] * (wa[i] - m); }
+    const double c1 = sg / n, c2 = (n > 1 && sd > 0.0) ? sgw / (se * se * (n - 1) * sd) : 0.0;
+    for (int i = 0; i < n; ++i) dw[(int64_t)a * n + i] = (float)((g[i] - c1) / se - (wa[i] - m) * c2);
+  }
+  free(g);
+  return 0;
+}
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict: prediction.py:132-143.  The arithmetic lives in torchio 0.18.45
  * (GridSampler / GridAggregator overlap_mode='average'), absent from the reference tree:

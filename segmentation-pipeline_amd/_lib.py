@@ -78,6 +78,8 @@ SIGNATURES = {
     "m355_add": (C.c_int, [_P, _P, _P, _i64, _P]),
     "m355_space_to_depth2": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_depth_to_space2": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_blur_weight_fwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i32, _i32, _P]),
+    "m355_blur_weight_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_finalize": (C.c_int, [_P, _P, _P, _i32, _i64, _P]),

@@ -11,7 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm355seg.so")
-SOURCES = ["abi.cpp", "conv3d.hip", "norm.hip", "elementwise.hip", "convt.hip", "loss_patch_eval.hip"]
+SOURCES = ["abi.cpp", "conv3d.hip", "norm.hip", "elementwise.hip", "convt.hip", "loss_patch_eval.hip",
+           "blur_weights.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "m355seg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -70,4 +70,8 @@ static inline int env_int(const char* name, int dflt) {
 
 static inline int64_t dense_or(int64_t stride, int64_t dense) { return stride ? stride : dense; }
 
+// Compute units of the current device (256 on MI355X); the tile planners size their grids in rounds
+// over the CUs.  Falls back to 256 when no device is visible (workspace queries on a build host).
+int num_cus();
+
 }  // namespace m355

@@ -1809,6 +1809,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   const int cands[4] = {4, 8, 2, 1};
   int chosen = 1, chosen_ks = 1;
   double best = 1e30;
+  const int cus = num_cus();
   for (int i = 0; i < 4 && compute == M355_COMPUTE_BF16; ++i) {
     // bf16 operand mode (HBM/LDS-bound kernel): fill the chip once, largest tile first
     const int ntw = cands[i];
@@ -1836,14 +1837,14 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
       if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;  // an empty split
       if (ks > 1 && ks * out_bytes > (128ll << 20)) break;
       const int64_t nwg = base_wg * ks;
-      const double rounds = (double)ceil_div(nwg, 256 * per_cu);
+      const double rounds = (double)ceil_div(nwg, (int64_t)cus * per_cu);
       // a lone workgroup on a CU has nothing to cover its barriers and LDS commits: measured ~0.8 of
       // the paired rate for NTW <= 4 (u0.c0 pinned to one per CU: 111 vs 126 TFLOP/s), ~0.93 for NTW = 8
-      const bool lone = per_cu == 1 || nwg <= 256;
+      const bool lone = per_cu == 1 || nwg <= cus;
       const double share = lone ? 1.0 / (per_cu == 1 ? 0.93 : 0.8) : (double)per_cu;
       // fixed cost of an item: ~2 chunks for a one-shot workgroup, ~0.5 when the persistent kernel
       // (more items than resident workgroups) prefetches across the item boundary
-      const double fixed = nwg > 256 * per_cu ? 0.5 : 2.0;
+      const double fixed = nwg > (int64_t)cus * per_cu ? 0.5 : 2.0;
       double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + fixed) * chunk_us;
       if (ks > 1) cost += (2.0 * ks + 1.0) * (double)out_bytes / 4.0e6 + 4.0;
       if (cost < best * 0.98) {  // candidates come in order of preference: switch only for a real gain
@@ -1864,7 +1865,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   const int ksplit = chosen_ks;
   {
     // resident workgroups (LDS + registers: 2 per CU up to NTW = 4); the override exists for the tests
-    const int64_t slots = env_int("M355_CONV_SLOTS", p.ntw <= 4 ? 512 : 256);
+    const int64_t slots = env_int("M355_CONV_SLOTS", (p.ntw <= 4 ? 2 : 1) * num_cus());
     const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
                    env_int("M355_CONV_PERSISTENT", 1);
@@ -1903,7 +1904,7 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
   if (p.persistent) {
-    const int64_t slots = env_int("M355_CONV_SLOTS", NTW <= 4 ? 512 : 256);
+    const int64_t slots = env_int("M355_CONV_SLOTS", (NTW <= 4 ? 2 : 1) * num_cus());
     hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
                        add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
                        p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat);
@@ -2034,17 +2035,18 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
   // cost of a workgroup: pipeline fill + the 110 KB slab write, ~half a tile).  Pick the split that
   // minimises it (a power of two up to the tile count) instead of just filling 256 CUs once.
   int64_t nsplit = 1;
+  const int cus = num_cus();
   {
     int64_t cand[24];
     int nc = 0;
     for (int64_t ns = 1; ns < ntiles; ns *= 2) cand[nc++] = ns;
-    for (int r = 1; r <= 8; ++r) cand[nc++] = std::max<int64_t>(1, 256 * r / pairs);  // exactly r rounds
+    for (int r = 1; r <= 8; ++r) cand[nc++] = std::max<int64_t>(1, (int64_t)cus * r / pairs);  // exactly r rounds
     cand[nc++] = std::max<int64_t>(1, ntiles);
     std::sort(cand, cand + nc);
     double best = 1e30;
     for (int i = 0; i < nc; ++i) {
       const int64_t ns = std::min<int64_t>(cand[i], std::max<int64_t>(1, ntiles));
-      const double rounds = (double)ceil_div(pairs * ns, 256);
+      const double rounds = (double)ceil_div(pairs * ns, cus);
       const double cost = rounds * ((double)ceil_div(ntiles, ns) + 0.5);
       if (cost < best * 0.97) {  // prefer fewer splits (less slab traffic) unless clearly better
         best = cost;

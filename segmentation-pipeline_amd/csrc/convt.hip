@@ -548,7 +548,7 @@ static int convt_bww_mt(const m355_conv3d_desc* d) { return d->Cin > 64 ? 4 : 2;
 static int convt_nsplit(const m355_conv3d_desc* d) {
   const int64_t tiles = ceil_div(d->Cin, 32 * convt_bww_mt(d)) * ceil_div(d->Cout, 16);
   const int64_t nsteps = ceil_div((int64_t)d->N * d->D * d->H * d->W, 64);
-  int64_t ns = std::max<int64_t>(1, 512 / tiles);  // persistent: 2 workgroups per CU, one round
+  int64_t ns = std::max<int64_t>(1, 2 * num_cus() / tiles);  // persistent: 2 workgroups per CU, one round
   ns = std::min<int64_t>(ns, nsteps);
   return (int)ns;
 }

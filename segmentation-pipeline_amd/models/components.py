@@ -66,6 +66,15 @@ def _box_blur(weight, kernel):
     return acc * scale
 
 
+def _blur_scale(kernel, weight):
+    """per dim-1-channel value of the Blur modules' all-equal 2x2x2 `kernel` buffer"""
+    if kernel.shape[0] != weight.shape[1]:
+        # the reference only works when the grouped conv is valid (in == out channels)
+        raise RuntimeError(
+            f"Blur convolution needs kernel rows ({kernel.shape[0]}) == weight.shape[1] ({weight.shape[1]})")
+    return kernel.reshape(kernel.shape[0], -1)[:, 0].contiguous()
+
+
 # A stride-2 conv with a 4x4x4 kernel and padding 1 is a stride-1 3x3x3 conv over the space-to-depth
 # input: along one axis, input index 2Z + d - 1 has parity (d-1)&1 and half-resolution offset
 # floor((d-1)/2) in {-1, 0, 0, +1} for d = 0..3, i.e. tap t = offset + 1 of a 3-tap kernel.
@@ -136,13 +145,12 @@ class BlurConv3d(nn.Conv3d):
         return _box_blur(w, self.kernel), None  # bias never used (:119)
 
     def forward(self, x):
-        w4, _ = self.effective()
         stride, pad = _uniform_int(self.stride, "stride"), _uniform_int(self.padding, "padding")
-        even = all(s % 2 == 0 for s in x.shape[2:])
-        if _is_blur_geometry(w4, stride, pad) and even and isinstance(x, torch.Tensor):
-            # stride-1 3x3x3 conv over the space-to-depth input (MFMA path)
-            co, ci = w4.shape[:2]
-            wexp = _expand_4x4x4(w4, _S2D_TAP).reshape(co, ci * 8, 3, 3, 3)
+        even = isinstance(x, torch.Tensor) and all(s % 2 == 0 for s in x.shape[2:])
+        if _uniform_int(self.kernel_size, "kernel_size") == 3 and stride == 2 and pad == 1 and even:
+            # effective 4x4x4 / stride 2 / padding 1 = a stride-1 3x3x3 conv over the space-to-depth input
+            # (MFMA path); standardisation + box blur + rearrangement of the filter in one HIP kernel
+            wexp = ops.blur_weight(self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization)
             return ops.conv3d(ops.space_to_depth2(x), wexp, None, stride=1, padding=1)
         return run_conv(self, x)
 
@@ -160,17 +168,18 @@ class BlurConvTranspose3d(nn.ConvTranspose3d):
         self.kwargs = kwargs
 
     def forward(self, x, output_size=None, out=None):
+        if (_uniform_int(self.kernel_size, "kernel_size") == 3 and _uniform_int(self.stride, "stride") == 2
+                and _uniform_int(self.padding, "padding") == 1
+                and _uniform_int(self.output_padding, "output_padding") == 0):
+            # effective 4x4x4 / stride 2 / padding 1: a 3x3x3 conv producing the 8 output parities, then
+            # depth-to-space (MFMA path); filter transform in one HIP kernel
+            wexp = ops.blur_weight(self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization,
+                                   transposed=True)
+            return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1), out=out)
         w = self.weight
         if self.weight_standardization:
             w = _standardize(w)
         w = _box_blur(w, self.kernel)
-        if _is_blur_geometry(w, _uniform_int(self.stride, "stride"), _uniform_int(self.padding, "padding"),
-                             _uniform_int(self.output_padding, "output_padding")):
-            # 3x3x3 conv producing the 8 output parities, then depth-to-space (MFMA path)
-            ci, co = w.shape[:2]
-            wexp = _expand_4x4x4(w, _D2S_TAP)                       # [ci, co, 8, 27]
-            wexp = wexp.permute(1, 2, 0, 3).reshape(co * 8, ci, 3, 3, 3)
-            return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1), out=out)
         return ops.conv_transpose3d(
             x, w, None, stride=_uniform_int(self.stride, "stride"),
             padding=_uniform_int(self.padding, "padding"),

@@ -655,6 +655,45 @@ def depth_to_space2(x, out: Optional[OutSlot] = None):
     return _S2DFn.apply(x, False, out)
 
 
+class _BlurWeightFn(torch.autograd.Function):
+    """Blur-convolution weight transform (reference models/components.py:112-119, 145-152) ->
+    sparse 3x3x3 filter of the space-to-depth formulation; see m355_blur_weight_fwd."""
+
+    @staticmethod
+    def forward(ctx, w, scale, standardize, transposed):
+        L = _lib.lib()
+        _require(w, scale)
+        w, scale = w.contiguous(), scale.contiguous()
+        A, B = w.shape[0], w.shape[1]
+        shape = (8 * B, A, 3, 3, 3) if transposed else (A, 8 * B, 3, 3, 3)
+        wexp = torch.empty(shape, dtype=w.dtype, device=w.device)
+        ms = torch.empty((A, 2), dtype=torch.float32, device=w.device) if standardize else None
+        check(L.m355_blur_weight_fwd(_p(w), _p(scale), _p(wexp), _p(ms), A, B, int(standardize), int(transposed),
+                                     _stream()), "blur_weight_fwd")
+        ctx.flags = (A, B, int(standardize), int(transposed))
+        ctx.save_for_backward(w, scale, ms)
+        return wexp
+
+    @staticmethod
+    def backward(ctx, dwexp):
+        L = _lib.lib()
+        w, scale, ms = ctx.saved_tensors
+        A, B, standardize, transposed = ctx.flags
+        dw = torch.empty_like(w)
+        check(L.m355_blur_weight_bwd(_p(dwexp.contiguous()), _p(w), _p(scale), _p(ms), _p(dw), A, B, standardize,
+                                     transposed, _stream()), "blur_weight_bwd")
+        return dw, None, None, None
+
+
+def blur_weight(w, scale, standardize=False, transposed=False):
+    """[A, B, 3, 3, 3] module weight -> conv3d weight of the space-to-depth form of the Blur convs:
+    [A, 8B, 3, 3, 3] (strided conv) or [8B, A, 3, 3, 3] (transposed conv).  `scale`: [B] values of the
+    module's `kernel` buffer."""
+    if tuple(w.shape[2:]) != (3, 3, 3) or scale.numel() != w.shape[1]:
+        raise _lib.M355Error(f"blur_weight: needs a 3x3x3 filter and one scale per dim-1 channel, got {tuple(w.shape)}")
+    return _BlurWeightFn.apply(w, scale, bool(standardize), bool(transposed))
+
+
 # --------------------------------------------------- sliding window / evaluation
 def patch_gather(volume, locations, patch_size):
     """volume [C,V0,V1,V2], locations int32 [P,3] (i0,j0,k0) -> patches [P,C,*patch_size]"""

@@ -247,6 +247,23 @@ class RawOps:
                   "depth_to_space2")
         return y
 
+    def blur_weight_fwd(self, w, scale, standardize, transposed):
+        w, scale = self.to(w), self.to(scale)
+        A, B = w.shape[:2]
+        wexp = self.empty(8 * B, A, 3, 3, 3) if transposed else self.empty(A, 8 * B, 3, 3, 3)
+        ms = self.empty(A, 2)
+        self._chk(self.fn("blur_weight_fwd")(_p(w), _p(scale), _p(wexp), _p(ms), A, B, int(standardize),
+                                             int(transposed), self._stream()), "blur_weight_fwd")
+        return wexp, ms
+
+    def blur_weight_bwd(self, dwexp, w, scale, ms, standardize, transposed):
+        dwexp, w, scale, ms = map(self.to, (dwexp, w, scale, ms))
+        A, B = w.shape[:2]
+        dw = torch.empty_like(w)
+        self._chk(self.fn("blur_weight_bwd")(_p(dwexp), _p(w), _p(scale), _p(ms), _p(dw), A, B, int(standardize),
+                                             int(transposed), self._stream()), "blur_weight_bwd")
+        return dw
+
     def softmax_fwd(self, x, inner=1, diag_bias=0.0):
         x = self.to(x)
         N, Ct = x.shape[:2]

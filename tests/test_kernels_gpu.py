@@ -215,6 +215,22 @@ def test_space_to_depth_roundtrip(hip, oracle):
         hip.space_to_depth(rnd(1, 1, 3, 4, 4, seed=2))
 
 
+@pytest.mark.parametrize("standardize", [False, True])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_blur_weight_transform(hip, oracle, standardize, transposed):
+    for A, B in [(5, 6), (40, 40), (3, 130)]:
+        w = rnd(A, B, 3, 3, 3, seed=1) * 0.3 + 0.05
+        scale = torch.full((B,), 0.37) + rnd(B, seed=3) * 0.01
+        eo, mso = oracle.blur_weight_fwd(w, scale, standardize, transposed)
+        eh, msh = hip.blur_weight_fwd(w, scale, standardize, transposed)
+        close(eh, eo, 1e-5, 1e-6, "wexp")
+        if standardize:
+            close(msh, mso, 1e-5, 1e-7, "mean/std")
+        g = rnd(*eo.shape, seed=2)
+        close(hip.blur_weight_bwd(g, w, scale, mso, standardize, transposed),
+              oracle.blur_weight_bwd(g, w, scale, mso, standardize, transposed), 2e-5, 1e-6, "dw")
+
+
 def test_blur_convs_mfma_path_matches_direct_kernels():
     """BlurConv3d / BlurConvTranspose3d route through s2d + 3x3x3 MFMA conv; compare values and all
     gradients with the generic direct stride-2 kernels on the same effective filter, and check that

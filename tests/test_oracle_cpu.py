@@ -155,6 +155,32 @@ def test_c_space_to_depth_and_blur_identities(oracle):
     close(got, F.conv_transpose3d(xd, wt, stride=2, padding=1).float(), 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("standardize", [False, True])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_c_blur_weight_transform_matches_torch_composition(oracle, standardize, transposed):
+    """m355o_blur_weight_{fwd,bwd} == standardise -> box blur -> gather written with torch ops (the
+    composition the goldens generated from the reference's BlurConv3d / BlurConvTranspose3d pin,
+    models/components.py:112-119,145-152), forward and autograd backward."""
+    from segmentation_pipeline_amd.models.components import (_D2S_TAP, _S2D_TAP, _box_blur, _expand_4x4x4,
+                                                             _standardize)
+    A, B = 5, 6
+    w = (rnd(A, B, 3, 3, 3, seed=1) * 0.3 + 0.05).double().requires_grad_()
+    kernel = torch.full((B, 1, 2, 2, 2), 1.0 / 64 if not transposed else 1.0 / B, dtype=torch.double)
+    wn = _standardize(w) if standardize else w
+    w4 = _box_blur(wn, kernel)
+    if transposed:
+        ref = _expand_4x4x4(w4, _D2S_TAP).permute(1, 2, 0, 3).reshape(B * 8, A, 3, 3, 3)
+    else:
+        ref = _expand_4x4x4(w4, _S2D_TAP).reshape(A, B * 8, 3, 3, 3)
+    scale = kernel.reshape(B, -1)[:, 0].float()
+    got, ms = oracle.blur_weight_fwd(w.detach().float(), scale, standardize, transposed)
+    close(got, ref.float(), 1e-5, 1e-6)
+    g = rnd(*ref.shape, seed=2)
+    ref.backward(g.double())
+    dw = oracle.blur_weight_bwd(g, w.detach().float(), scale, ms, standardize, transposed)
+    close(dw, w.grad.float(), 2e-5, 1e-6)
+
+
 def test_c_patches_and_confusion(oracle):
     vol = rnd(2, 9, 8, 7, seed=1)
     locs = R.grid_locations((9, 8, 7), (4, 4, 4), (1, 1, 1))
