@@ -239,8 +239,8 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate (conv fwd + data grad), f32 elsewhere",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet(4,3,[32,64,128,256,320],5,"
-                                   f"GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
+            "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet({cin},{cout},"
+                                   f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
                        "global_batch": world * args.batch, "params": sum(p.numel() for p in model.parameters()),
                        "parallelism": f"patch-parallel dp{world}" if world > 1 else "single GPU",
                        "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95)"},
