@@ -2,7 +2,7 @@
 """Randomised parity sweep of the 3x3x3 conv family (forward / data gradient / weight gradient, fused
 statistics) against the C oracle: random N, channels, ragged volumes, and random planner overrides so
 that every kernel variant (one-shot / persistent, every NTW and lane-group width, split-K, both
-bwd-weight generations) sees odd shapes.   usage: python tools/fuzz_conv.py [cases] [seed]"""
+bwd-weight generations) sees odd shapes.   usage: python tools/fuzz_conv.py [--convt] [cases] [seed]"""
 import os
 import random
 import sys
@@ -23,7 +23,35 @@ def err(a, b):
     return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
 
 
+def fuzz_convt(cases, rng):
+    """ConvTranspose3d k=2 s=2 (the MFMA GEMM kernels: every voxel-tile / channel-tile variant, fused bias
+    gradient) on random channel counts and ragged volumes."""
+    hip, oracle = RawOps("hip"), RawOps("oracle")
+    worst = 0.0
+    for i in range(cases):
+        N = rng.choice([1, 1, 2])
+        ci = rng.choice([1, 3, 4, 8, 17, 32, 40, 64, 65, 96, 130, 200, 330])
+        co = rng.choice([1, 2, 4, 5, 16, 31, 32, 64, 70, 130])
+        D, H, W = rng.randint(1, 9), rng.randint(1, 12), rng.randint(1, 20)
+        x, w, b = rnd(N, ci, D, H, W, seed=3 * i), rnd(ci, co, 2, 2, 2, seed=3 * i + 1) * 0.2, rnd(co, seed=3 * i + 2)
+        dy = rnd(N, co, 2 * D, 2 * H, 2 * W, seed=5 * i)
+        e = [err(hip.convt_fwd(x, w, b), oracle.convt_fwd(x, w, b)),
+             err(hip.convt_bwd_data(dy, w, x.shape), oracle.convt_bwd_data(dy, w, x.shape))]
+        dwh, dbh = hip.convt_bwd_weight(x, dy, 2)
+        dwo, dbo = oracle.convt_bwd_weight(x, dy, 2)
+        e += [err(dwh, dwo), err(dbh, dbo)]
+        worst = max(worst, max(e))
+        if max(e) > 5e-5:
+            print(f"MISMATCH convT case {i}: N={N} Cin={ci} Cout={co} DHW={D}x{H}x{W}", ["%.2e" % v for v in e], flush=True)
+            sys.exit(1)
+    print(f"convT fuzz ok: {cases} cases, worst relative error {worst:.2e}")
+
+
 def main():
+    if "--convt" in sys.argv:
+        sys.argv.remove("--convt")
+        return fuzz_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 80,
+                          random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     hip, oracle = RawOps("hip"), RawOps("oracle")
