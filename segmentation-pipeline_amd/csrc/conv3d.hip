@@ -1321,7 +1321,9 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
 //  swap=0 (Cin small):  P = dy (wide = Cout), Q = x,  dW[o=i][c=s][tap]
 //  swap=1 (Cout small): P = x (wide = Cin),  Q = dy read at v - off(tap) = v + off(26-tap),
 //                       dW[o=s][c=i][tap]
-// 16 accumulators -> several workgroups per CU hide the (synchronous) staging.
+// 16 accumulators and 46 KB of LDS -> three workgroups per CU; the next tile is prefetched into
+// registers through buffer descriptors (out-of-volume halo and channels past CP / CQ read as 0)
+// while the current one is multiplied.
 template <int GX>
 __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ slab, int N,
@@ -1329,8 +1331,11 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
     int64_t pbs, int64_t qbs, int swap, int Cin, int Cout) {
   using T = BwTile<GX>;
   constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, HV = T::HV,
-                DSW = T::DSW, NV = T::NV;
+                DSW = T::DSW;
+  static_assert(T::NV == 256, "one wide-tile voxel per thread");
   constexpr int QS = HV + 1;
+  constexpr int QE = 4 * HV, QPER = (QE + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
   __shared__ float ps[32 * DSW];
   __shared__ float qs[4 * QS];
 
@@ -1355,7 +1360,24 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
   const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
   const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
   const int ntiles = N * tiles_per_n;
-  for (int tile = split; tile < ntiles; tile += nsplit) {
+
+  // tile-invariant description of this thread's narrow-halo elements: offset from the halo origin,
+  // LDS slot, halo coordinates (zz | yy << 8 | xx << 16; 0xFFFFFF past the tile: never valid)
+  int qrel[QPER], qlds[QPER];
+  unsigned qcode[QPER];
+#pragma unroll
+  for (int k = 0; k < QPER; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / HV, r = e - c * HV;
+    const int zz = r / PS, r2 = r - zz * PS;
+    const int yy = r2 / RS, xx = r2 - yy * RS;
+    qrel[k] = c * iDHW + zz * iHW + yy * W + xx;
+    qlds[k] = e < QE ? c * QS + r : -1;
+    qcode[k] = e < QE ? ((unsigned)zz | ((unsigned)yy << 8) | ((unsigned)xx << 16)) : 0x00FFFFFFu;
+  }
+
+  float pr[32], qr[QPER];
+  auto fetch = [&](int tile, bool live) {  // !live: zero-sized descriptors, no memory traffic
     int t = tile;
     const int n = t / tiles_per_n;
     t -= n * tiles_per_n;
@@ -1364,38 +1386,50 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
     const int tyt = t % ty_tiles;
     const int tzt = t / ty_tiles;
     const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
-    const float* Pn = P + (int64_t)n * pbs;
-    const float* Qn = Q + (int64_t)n * qbs;
-    __syncthreads();
-    {  // wide tile: 32 channels x 256 voxels, one voxel per thread
-      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-      const bool vok = gz < D && gy < H && gx < W;
-      const int sp = vok ? gz * iHW + gy * W + gx : 0;
-#pragma unroll 8
-      for (int j = 0; j < 32; ++j) {
-        const bool ok = vok && p0 + j < CP;
-        const float v = Pn[ok ? (p0 + j) * iDHW + sp : 0];
-        ps[j * DSW + tid] = ok ? v : 0.f;
-      }
+    const __amdgpu_buffer_rsrc_t rp =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(P + (int64_t)n * pbs), 0, live ? CP * iDHW * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (int64_t)n * qbs), 0, live ? CQ * iDHW * 4 : 0, 0x00020000);
+    const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+    const bool vok = gz < D && gy < H && gx < W;
+    const int sp = p0 * iDHW + gz * iHW + gy * W + gx;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      pr[j] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rp, vok ? (unsigned)(sp + j * iDHW) * 4u : OOB, 0, 0));
+    const int qbase = (z0 - 1) * iHW + (y0 - 1) * W + (x0 - 1);
+#pragma unroll
+    for (int k = 0; k < QPER; ++k) {
+      const unsigned cd = qcode[k];
+      const bool ok = (unsigned)(z0 - 1 + (int)(cd & 0xFFu)) < (unsigned)D &&
+                      (unsigned)(y0 - 1 + (int)((cd >> 8) & 0xFFu)) < (unsigned)H &&
+                      (unsigned)(x0 - 1 + (int)(cd >> 16)) < (unsigned)W;
+      qr[k] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rq, ok ? (unsigned)(qbase + qrel[k]) * 4u : OOB, 0, 0));
     }
-    // narrow halo tile: 4 channels x (TZ+2)(TY+2)(TX+2)
-    for (int e = tid; e < 4 * HV; e += 256) {
-      const int c = e / HV, r = e - c * HV;
-      const int zz = r / PS, r2 = r - zz * PS;
-      const int yy = r2 / RS, xx = r2 - yy * RS;
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-      const bool ok = c < CQ && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const float v = Qn[ok ? c * iDHW + gz * iHW + gy * W + gx : 0];
-      qs[c * QS + r] = ok ? v : 0.f;
-    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ps[j * DSW + tid] = pr[j];
+#pragma unroll
+    for (int k = 0; k < QPER; ++k)
+      if (qlds[k] >= 0) qs[qlds[k]] = qr[k];
+  };
+
+  if (split < ntiles) fetch(split, true);
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    __syncthreads();  // every wave is done reading the previous tile
+    commit();
     __syncthreads();
+    const bool more = tile + nsplit < ntiles;
+    fetch(more ? tile + nsplit : tile, more);  // in flight during the MFMAs below
     for (int z = 0; z < TZ; ++z)
       for (int yy = 0; yy < TY; ++yy) {
-        const float* pr = pb + (z * TY + yy) * TX;
-        const float* qr = qb + z * PS + yy * RS;
+        const float* prow = pb + (z * TY + yy) * TX;
+        const float* qrow = qb + z * PS + yy * RS;
 #pragma unroll
         for (int xp = 0; xp < TX / 2; ++xp)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[2 * xp], qr[2 * xp], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(prow[2 * xp], qrow[2 * xp], acc, 0, 0, 0);
       }
   }
   float* sl = slab + (int64_t)split * Cout * Cin * 27;
@@ -1893,7 +1927,9 @@ static size_t small_cout_ws(const m355_conv3d_desc* d) {
   return (size_t)round_up((int64_t)round_up(d->Cin, 2) * TZ_K * 32 * 4, 256);
 }
 static bool small_bww(const m355_conv3d_desc* d) {
-  return (d->Cin <= 4 || d->Cout <= 4) && !env_int("M355_NO_SMALL", 0);
+  // tap-on-lane kernel; a sample must fit the 32-bit byte offsets of a buffer descriptor
+  return (d->Cin <= 4 || d->Cout <= 4) && !env_int("M355_NO_SMALL", 0) &&
+         (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 29);
 }
 
 template <int NTW, int GX>
