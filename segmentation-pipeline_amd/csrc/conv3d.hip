@@ -33,9 +33,10 @@ __device__ __forceinline__ int opaque(int v) {
 //           (the data-gradient is a conv of dy with the flipped, transposed filter)
 // Padded rows/cols are zero-filled.
 __global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                               int Cin, int kin_pad, int mout_pad, int transpose) {
+                               int Cin, int kin_pad, int mout_pad, int transpose, int* __restrict__ counter) {
   // logical conv being run: K-channels = kin (padded to kin_pad), M-channels = mout_pad
   const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;  // work queue of the persistent conv kernel
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i % mout_pad);
@@ -328,8 +329,11 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 // A workgroup of the kernel above lives for nchunks/ksplit chunks and pays ~2.5 chunks of fixed
 // cost around them (measured: 8-chunk layers reach 112 TFLOP/s, 48-chunk layers 140): the first
 // chunk's load latency + commit, the output stores, the launch of the next workgroup.  Here the grid
-// is one residency (2 workgroups per CU) and every workgroup walks items it, it + G, ...
-// (item = output tile x 32-channel tile x sample x split, same order as the grid above).  The
+// is one residency (2 workgroups per CU) and every workgroup takes items from a queue (item = output
+// tile x 32-channel tile x sample x split, same order as the grid above; the first G items are the
+// block indices, the rest come from an atomic counter, so a workgroup that starts late -- another
+// kernel, e.g. an RCCL collective, still holding its CU -- simply takes fewer items; every item's
+// result is independent of who computes it, so this stays bit-reproducible).  The
 // (item, chunk) sequence is flattened: during the last chunk of an item the FIRST chunk of the next
 // item is prefetched, so the MFMA stream only stops for the output stores.
 template <int NTW, int GX>
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles,
     int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride,
-    float* __restrict__ stat) {
+    float* __restrict__ stat, int* __restrict__ work_counter) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS = T::CS, CC = T::CC;
@@ -348,7 +352,6 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
   constexpr int WPER = (WE4 + 255) / 256;
   constexpr int NSTEP = (CC / 2) * 27;
   static_assert(XPER <= NSTEP && WPER <= NSTEP, "one prefetch item per MFMA step");
-  static_assert(TZ + 2 <= 8 && TY + 2 <= 64 && TX + 2 <= 64, "halo coordinates fit the code fields");
   __shared__ float xs[2][XE];
   __shared__ __attribute__((aligned(16))) float ws[2][CC * 27 * 32];
 
@@ -387,31 +390,22 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     return q;
   };
 
-  // tile-invariant part of this thread's gather elements: offset from the halo origin and the halo
-  // coordinates packed as zz | yy << 8 | xx << 16; elements past the tile never validate
-  int rel[XPER];
-  unsigned code[XPER];
-#pragma unroll
-  for (int i = 0; i < XPER; ++i) {
-    const int e = tid + 256 * i;
-    const int c = e / CS, r = e - c * CS;
-    const int zz = r / PS, r2 = r - zz * PS;
-    const int yy = r2 / RS, xx = r2 - yy * RS;
-    rel[i] = c * DHW + zz * iHW + yy * W + xx;
-    code[i] = e < XE ? ((unsigned)zz | ((unsigned)yy << 8) | ((unsigned)xx << 16)) : 0x00FFFFFFu;
-  }
+  // gather offsets of this thread's halo elements for item q, in bytes from the chunk's first channel;
+  // zero padding and elements past the tile get an offset no descriptor covers (hardware returns 0).
+  // Recomputed per item from the element index (divisions by compile-time constants) rather than
+  // kept as per-thread tables: 40 registers this kernel does not have.
   constexpr unsigned OOB = 0x80000000u;
   unsigned goff[XPER];
   auto compute_goff = [&](const Item& q) {
-    const int base = (q.z0 - 1) * iHW + (q.y0 - 1) * W + (q.x0 - 1);
 #pragma unroll
     for (int i = 0; i < XPER; ++i) {
-      const unsigned cd = code[i];
-      // 0xFF fields (elements past the tile) are out of range for any volume this kernel accepts
-      const bool ok = (unsigned)(q.z0 - 1 + (int)(cd & 0xFFu)) < (unsigned)D &&
-                      (unsigned)(q.y0 - 1 + (int)((cd >> 8) & 0xFFu)) < (unsigned)H &&
-                      (unsigned)(q.x0 - 1 + (int)(cd >> 16)) < (unsigned)W;
-      goff[i] = ok ? (unsigned)(base + rel[i]) * 4u : OOB;
+      const int e = tid + 256 * i;
+      const int c = e / CS, r = e - c * CS;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = q.z0 + zz - 1, gy = q.y0 + yy - 1, gx = q.x0 + xx - 1;
+      const bool ok = e < XE && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      goff[i] = ok ? (unsigned)(c * DHW + gz * iHW + gy * W + gx) * 4u : OOB;
     }
   };
 
@@ -442,6 +436,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
       if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
   };
 
+  __shared__ int next_item_s;
+  const int G = (int)gridDim.x;
   int it = blockIdx.x;
   if (it >= total) return;
   Item cur = decode(it);
@@ -455,17 +451,27 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
 
   f32x16 acc[NTW];
   while (true) {
+    // thread 0 asks the queue for this workgroup's next item now; the answer is published through
+    // LDS after the first chunk (a barrier later) and consumed at the start of the last chunk
+    int pending = 0;
+    if (tid == 0) pending = G + atomicAdd(work_counter, 1);
+    if (cur.ch_end - cur.ch_begin == 1) {  // single-chunk items: no chunk to hide the round trip behind
+      if (tid == 0) next_item_s = pending;
+      __syncthreads();
+    }
 #pragma unroll
     for (int g = 0; g < NTW; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
     Item nxt = cur;
+    int nit = total;
     for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
       if (ch + 1 < cur.ch_end) {
         chunk_setup(cur, ch + 1, true);
       } else {  // last chunk of this item: prefetch the first chunk of the next one
-        const bool live = it + (int)gridDim.x < total;
-        nxt = decode(live ? it + (int)gridDim.x : it);
+        nit = next_item_s;
+        const bool live = nit < total;
+        nxt = decode(live ? nit : it);
         compute_goff(nxt);
         chunk_setup(nxt, nxt.ch_begin, live);
       }
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = pending;
       commit(buf ^ 1);
       __syncthreads();
       buf ^= 1;
@@ -514,8 +521,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
                                  nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, nullptr);
       }
     }
-    it += (int)gridDim.x;
-    if (it >= total) break;
+    if (nit >= total) break;
+    it = nit;
     cur = nxt;
   }
 }
@@ -1904,7 +1911,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
                    env_int("M355_CONV_PERSISTENT", 1);
   }
-  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (compute == M355_COMPUTE_BF16 ? 2 : 4), 256);
+  // packed weights + 256 B for the work counter of the persistent kernel
+  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (compute == M355_COMPUTE_BF16 ? 2 : 4), 256) + 256;
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
 }
@@ -1935,7 +1943,8 @@ static bool small_bww(const m355_conv3d_desc* d) {
 template <int NTW, int GX>
 static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
-                       int H, int W, int64_t xbs, int64_t ybs, hipStream_t st, float* stat = nullptr) {
+                       int H, int W, int64_t xbs, int64_t ybs, hipStream_t st, float* stat = nullptr,
+                       int* work_counter = nullptr) {
   dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
@@ -1943,7 +1952,7 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
     const int64_t slots = env_int("M355_CONV_SLOTS", (NTW <= 4 ? 2 : 1) * num_cus());
     hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
                        add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat);
+                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter);
     return;
   }
   hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
@@ -2012,18 +2021,19 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
   float* wp = (float*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
+  int* work_counter = (int*)((char*)ws + p.wp_bytes - 256);  // last 256 B of the packed-weight region
   {
     const int64_t total = (int64_t)p.kin_pad * 27 * p.mout_pad;
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
     hipLaunchKernelGGL(pack_w3_kernel, dim3(blocks), dim3(256), 0, st, w, wp, Cout_w, Cin_w,
-                       p.kin_pad, p.mout_pad, transpose ? 1 : 0);
+                       p.kin_pad, p.mout_pad, transpose ? 1 : 0, work_counter);
   }
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
 #define M355_FWD_CASE(NTW, GX)                                                              \
   if (p.ntw == NTW && p.gx == GX) {                                                         \
     launch_fwd<NTW, GX>(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, \
-                        st, stat);                                                          \
+                        st, stat, work_counter);                                            \
   } else
   M355_FWD_CASE(8, 32)
   M355_FWD_CASE(4, 32)
