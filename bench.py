@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1, help="patches per rank per step")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="arithmetic of the 3x3x3 conv fwd / data gradient (default: exact fp32, the BASELINE cfg2 mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -237,7 +237,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate (conv fwd + data grad), f32 elsewhere",
+            "dtype": "f32" if args.precision == "fp32" else f"{args.precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet({cin},{cout},"
                                    f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",

@@ -45,10 +45,12 @@ enum { M355_F32 = 0 };
 /* arithmetic of the 3x3x3 convolutions (tensors in HBM are fp32 either way):
  *   M355_COMPUTE_F32  exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (default)
  *   M355_COMPUTE_BF16 operands rounded to bf16 (round-to-nearest-even) when they are staged,
- *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE cfg3 / cfg5 family).
+ *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE cfg3).
+ *   M355_COMPUTE_F16  the same with IEEE fp16 operands, v_mfma_f32_32x32x16_f16 (BASELINE cfg5:
+ *                     "mixed fp16 with MFMA channel-GEMM path"); values beyond +-65504 become inf.
  * Applies to conv3d fwd, bwd_data and (when W % 32 == 0 and both channel counts > 4) bwd_weight;
  * every other case of the weight gradient runs in exact fp32. */
-enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1 };
+enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1, M355_COMPUTE_F16 = 2 };
 
 /* activation fused into the normalise pass (components.py:26,54-55) */
 enum { M355_ACT_NONE = 0, M355_ACT_RELU = 1, M355_ACT_LEAKY_RELU = 2 };

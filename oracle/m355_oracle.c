@@ -45,7 +45,30 @@ static float bf16r(float f) {
   memcpy(&f, &u, 4);
   return f;
 }
-#define OPND(d, v) ((d)->compute == M355_COMPUTE_BF16 ? (double)bf16r(v) : (double)(v))
+/* round-to-nearest-even to IEEE binary16 and back (subnormals and overflow to inf included) */
+static float f16r(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+  if (a >= 0x7F800000u) return f;                 /* inf / nan */
+  if (a >= 0x477FF000u) {                         /* >= 65520 rounds to inf */
+    const uint32_t inf = sign | 0x7F800000u;
+    float r;
+    memcpy(&r, &inf, 4);
+    return r;
+  }
+  if (a < 0x38800000u) {                          /* below 2^-14: multiples of 2^-24 */
+    const float q = nearbyintf(fabsf(f) * 16777216.0f) / 16777216.0f;
+    return sign ? -q : q;
+  }
+  uint32_t r = a + 0x00000FFFu + ((a >> 13) & 1u); /* keep 10 mantissa bits */
+  r &= 0xFFFFE000u;
+  r |= sign;
+  float out;
+  memcpy(&out, &r, 4);
+  return out;
+}
+#define OPND(d, v) ((d)->compute == M355_COMPUTE_BF16 ? (double)bf16r(v) : (d)->compute == M355_COMPUTE_F16 ? (double)f16r(v) : (double)(v))
 
 /* ------------------------------------------------------------------ conv3d
  * nn.Conv3d: models/components.py:36,42,51; models/modular_unet.py:83,99;

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libm355seg.so")
 
 M355_OK = 0
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 
 
 class ConvDesc(C.Structure):

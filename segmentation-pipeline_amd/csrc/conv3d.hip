@@ -536,11 +536,31 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
 //   ws[tap][half][32 o][8]       A fragment: lane (o, half)
 // At this rate the kernel is bound by staging (global -> cvt -> LDS), not by the MFMA pipe:
 // synchronous staging, two workgroups per CU overlap each other.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit element type is a template parameter: __bf16 (M355_COMPUTE_BF16) or _Float16
+// (M355_COMPUTE_F16, v_mfma_f32_32x32x16_f16); everything else is identical.
+template <typename HT>
+struct H16;
+template <>
+struct H16<__bf16> {
+  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct H16<_Float16> {
+  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
 
 // packed bf16 weights: wpb[(((ch*27 + tap)*2 + half)*mout_pad + m)*8 + j], channel = ch*16 + half*8 + j
-__global__ void pack_w3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout,
-                                    int Cin, int nchunks, int mout_pad, int transpose) {
+template <typename HT>
+__global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
+                                   int Cin, int nchunks, int mout_pad, int transpose) {
   const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -558,24 +578,25 @@ __global__ void pack_w3_bf16_kernel(const float* __restrict__ w, __bf16* __restr
     } else {
       if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
     }
-    wp[i] = (__bf16)v;
+    wp[i] = (HT)v;
   }
 }
 
-template <int NTW, int GX>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
-    const float* __restrict__ x, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+template <int NTW, int GX, typename HT>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_h16_kernel(
+    const float* __restrict__ x, const HT* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
     int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride) {
   using T = FwdTile<NTW, GX>;
+  using hx8 = typename H16<HT>::x8;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
   constexpr int XI = 2 * HV;                   // (half, voxel) staging items of 8 channels
   constexpr int XPER = (XI + 255) / 256;
   constexpr int WI = 27 * 2 * 32;              // 16-byte weight items per chunk
   constexpr int WPER = (WI + 255) / 256;
-  __shared__ __attribute__((aligned(16))) bf16x8 xs[XI];
-  __shared__ __attribute__((aligned(16))) bf16x8 ws[WI];
+  __shared__ __attribute__((aligned(16))) hx8 xs[XI];
+  __shared__ __attribute__((aligned(16))) hx8 ws[WI];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -623,8 +644,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
-  const bf16x8* xb = xs + half * HV + wave * PS + ly * RS + lx;
-  const bf16x8* wb = ws + half * 32 + l32;
+  const hx8* xb = xs + half * HV + wave * PS + ly * RS + lx;
+  const hx8* wb = ws + half * 32 + l32;
   const uint4* wsrc0 = reinterpret_cast<const uint4*>(wp);
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
@@ -658,9 +679,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
       const int e = tid + 256 * i;
       const int cbase = ch * 16 + (e >= HV ? 8 : 0);
       const bool sp_ok = goff[i] >= 0;
-      bf16x8 v;
+      hx8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (__bf16)((sp_ok && cbase + j < Cin) ? xr[i][j] : 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = (HT)((sp_ok && cbase + j < Cin) ? xr[i][j] : 0.f);
       if (e < XI) xs[e] = v;
     }
 #pragma unroll
@@ -670,11 +691,11 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_bf16_kernel(
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const bf16x8 a = wb[tap * 64];
+      const hx8 a = wb[tap * 64];
 #pragma unroll
       for (int g = 0; g < NTW; ++g) {
-        const bf16x8 b = xb[dz * PS + (g * GY + dy) * RS + dx];
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+        const hx8 b = xb[dz * PS + (g * GY + dy) * RS + dx];
+        acc[g] = H16<HT>::mfma(a, b, acc[g]);
       }
     }
   }
@@ -1461,10 +1482,12 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
 //   dys[32 o][128 + 8]            (row stride 17 x 16 B: conflict-free b128 reads)
 //   xs3[3 dx][32 c][16 rows x 32 + 8]   (channel stride 65 x 16 B)
 // Memory-bound at this MFMA rate; the next tile is prefetched into registers during the MFMAs.
-__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_bf16_kernel(
+template <typename HT>
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_h16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
     int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
     int64_t xbs, int64_t ybs) {
+  using hx8 = typename H16<HT>::x8;
   constexpr int TZ = 2, TY = 2, TX = 32, NV = TZ * TY * TX;     // 128
   constexpr int ROWS = (TZ + 2) * (TY + 2);                      // 16 halo rows per channel
   constexpr int DROW = NV + 8;                                   // bf16 elements per dy row
@@ -1472,8 +1495,8 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_bf16_kernel(
   constexpr int XCPY = 32 * XCH;                                 // bf16 elements per shifted copy
   constexpr int XITEMS = 32 * ROWS * 8;                          // (c, row, q) float4 items
   constexpr int XPER = XITEMS / 256;                             // 16
-  __shared__ __attribute__((aligned(16))) __bf16 dys[32 * DROW];
-  __shared__ __attribute__((aligned(16))) __bf16 xs3[3 * XCPY];
+  __shared__ __attribute__((aligned(16))) HT dys[32 * DROW];
+  __shared__ __attribute__((aligned(16))) HT xs3[3 * XCPY];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1555,27 +1578,27 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_bf16_kernel(
       if (q == 7) right = hv;
       const int rowi = (tid >> 3) + 32 * k;
       const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      __bf16* dst = xs3 + c * XCH + rr * TX + 4 * q;
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      HT* dst = xs3 + c * XCH + rr * TX + 4 * q;
+      using bf16x4 = typename H16<HT>::x4;
       bf16x4 m1, m0, p1;
-      m1[0] = (__bf16)left; m1[1] = (__bf16)v[0]; m1[2] = (__bf16)v[1]; m1[3] = (__bf16)v[2];   // x - 1
-      m0[0] = (__bf16)v[0]; m0[1] = (__bf16)v[1]; m0[2] = (__bf16)v[2]; m0[3] = (__bf16)v[3];   // x
-      p1[0] = (__bf16)v[1]; p1[1] = (__bf16)v[2]; p1[2] = (__bf16)v[3]; p1[3] = (__bf16)right;  // x + 1
+      m1[0] = (HT)left; m1[1] = (HT)v[0]; m1[2] = (HT)v[1]; m1[3] = (HT)v[2];   // x - 1
+      m0[0] = (HT)v[0]; m0[1] = (HT)v[1]; m0[2] = (HT)v[2]; m0[3] = (HT)v[3];   // x
+      p1[0] = (HT)v[1]; p1[1] = (HT)v[2]; p1[2] = (HT)v[3]; p1[3] = (HT)right;  // x + 1
       *reinterpret_cast<bf16x4*>(dst) = m1;
       *reinterpret_cast<bf16x4*>(dst + XCPY) = m0;
       *reinterpret_cast<bf16x4*>(dst + 2 * XCPY) = p1;
     }
-    bf16x8 d0, d1;
+    hx8 d0, d1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      d0[u] = (__bf16)(mdy ? dr[0][u] : 0.f);
-      d0[4 + u] = (__bf16)(mdy ? dr[1][u] : 0.f);
-      d1[u] = (__bf16)(mdy ? dr[2][u] : 0.f);
-      d1[4 + u] = (__bf16)(mdy ? dr[3][u] : 0.f);
+      d0[u] = (HT)(mdy ? dr[0][u] : 0.f);
+      d0[4 + u] = (HT)(mdy ? dr[1][u] : 0.f);
+      d1[u] = (HT)(mdy ? dr[2][u] : 0.f);
+      d1[4 + u] = (HT)(mdy ? dr[3][u] : 0.f);
     }
-    __bf16* dd = dys + so * DROW + sseg * 16;
-    *reinterpret_cast<bf16x8*>(dd) = d0;
-    *reinterpret_cast<bf16x8*>(dd + 8) = d1;
+    HT* dd = dys + so * DROW + sseg * 16;
+    *reinterpret_cast<hx8*>(dd) = d0;
+    *reinterpret_cast<hx8*>(dd + 8) = d1;
   };
 
   if (split < ntiles) {
@@ -1583,8 +1606,8 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_bf16_kernel(
     commit();
   }
   __syncthreads();
-  const __bf16* ab = dys + l32 * DROW + 8 * half;
-  const __bf16* bb = xs3 + l32 * XCH + 8 * half;
+  const HT* ab = dys + l32 * DROW + 8 * half;
+  const HT* bb = xs3 + l32 * XCH + 8 * half;
   for (int tile = split; tile < ntiles; tile += nsplit) {
     const bool more = tile + nsplit < ntiles;
     if (more) fetch(tile + nsplit);
@@ -1593,12 +1616,12 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_bf16_kernel(
       const int z = zy / TY, yy = zy % TY;
 #pragma unroll
       for (int xk = 0; xk < 2; ++xk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + zy * TX + 16 * xk);
-        const __bf16* brow = bb + (z * (TY + 2) + yy) * TX + 16 * xk;
+        const hx8 a = *reinterpret_cast<const hx8*>(ab + zy * TX + 16 * xk);
+        const HT* brow = bb + (z * (TY + 2) + yy) * TX + 16 * xk;
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + toff[t]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+          const hx8 b = *reinterpret_cast<const hx8*>(brow + toff[t]);
+          acc[t] = H16<HT>::mfma(a, b, acc[t]);
         }
       }
     }
@@ -1831,7 +1854,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   p.mfma = true;
   p.gx = pick_gx(W);
   const int gy = 32 / p.gx;
-  const int cc = compute == M355_COMPUTE_BF16 ? 16 : 4;  // input channels per LDS chunk
+  const bool h16 = compute != M355_COMPUTE_F32;  // bf16 / fp16 operand modes share one plan
+  const int cc = h16 ? 16 : 4;  // input channels per LDS chunk
   p.kin_pad = (int)round_up(kin, cc);
   p.mout_pad = (int)round_up(mout, 32);
   p.otiles = p.mout_pad / 32;
@@ -1851,8 +1875,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   int chosen = 1, chosen_ks = 1;
   double best = 1e30;
   const int cus = num_cus();
-  for (int i = 0; i < 4 && compute == M355_COMPUTE_BF16; ++i) {
-    // bf16 operand mode (HBM/LDS-bound kernel): fill the chip once, largest tile first
+  for (int i = 0; i < 4 && h16; ++i) {
+    // 16-bit operand modes (HBM/LDS-bound kernel): fill the chip once, largest tile first
     const int ntw = cands[i];
     if (force_ntw && ntw != force_ntw) continue;
     const int ty = ntw * gy;
@@ -1865,7 +1889,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
     chosen_ks = (int)ks;
     if (nwg * ks * 4 >= 512 * 3) break;
   }
-  for (int i = 0; i < 4 && compute != M355_COMPUTE_BF16; ++i) {
+  for (int i = 0; i < 4 && !h16; ++i) {
     const int ntw = cands[i];
     if (force_ntw && ntw != force_ntw) continue;
     const int ty = ntw * gy;
@@ -1912,7 +1936,7 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
                    env_int("M355_CONV_PERSISTENT", 1);
   }
   // packed weights + 256 B for the work counter of the persistent kernel
-  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (compute == M355_COMPUTE_BF16 ? 2 : 4), 256) + 256;
+  p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (h16 ? 2 : 4), 256) + 256;
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
 }
@@ -1961,16 +1985,57 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
 }
 
 // Runs the MFMA implicit GEMM: out[n, m, v] = bias + add + sum_{kc,tap} wp * in[n, kc, v+tap]
-template <int NTW, int GX>
-static void launch_bf16(const FwdPlan& p, const float* x, const __bf16* wp, const float* bias,
+template <int NTW, int GX, typename HT>
+static void launch_h16(const FwdPlan& p, const float* x, const HT* wp, const float* bias,
                         const float* add, float* y, float* slab, int N, int kin, int mout, int D,
                         int H, int W, int64_t xbs, int64_t ybs, hipStream_t st) {
   dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
-  hipLaunchKernelGGL((conv3_mfma_bf16_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add, y,
+  hipLaunchKernelGGL((conv3_mfma_h16_kernel<NTW, GX, HT>), grid, dim3(256), 0, st, x, wp, bias, add, y,
                      slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
                      p.ksplit, xbs, ybs, slab_stride);
+}
+
+// 16-bit operand modes (bf16 / fp16): tensors stay fp32 in HBM, operands are rounded while staged
+template <typename HT>
+static int run_h16_conv(const FwdPlan& p, const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
+                        const float* bias, const float* add, float* out, int N, int kin, int mout, int D, int H,
+                        int W, int64_t in_bs, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st) {
+  M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
+               "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
+  M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
+  M355_REQUIRE((int64_t)std::max(kin, mout) * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
+               "conv3d(16-bit operands): tensor exceeds 2^31 elements per sample");
+  HT* wpb = (HT*)ws;
+  float* slab = (float*)((char*)ws + p.wp_bytes);
+  {
+    const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(pack_w3_h16_kernel<HT>, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w, p.nchunks,
+                       p.mout_pad, transpose ? 1 : 0);
+  }
+  const float* kb = p.ksplit == 1 ? bias : nullptr;
+  const float* ka = p.ksplit == 1 ? add : nullptr;
+#define M355_H16_CASE(NTW, GX)                                                                          \
+  if (p.ntw == NTW && p.gx == GX) {                                                                     \
+    launch_h16<NTW, GX, HT>(p, in, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, st);   \
+  } else
+  M355_H16_CASE(8, 32) M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
+  M355_H16_CASE(8, 16) M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
+  M355_H16_CASE(8, 8) M355_H16_CASE(4, 8) M355_H16_CASE(2, 8) M355_H16_CASE(1, 8) {
+    set_error("conv3d(16-bit operands): no kernel for ntw=%d gx=%d", p.ntw, p.gx);
+    return M355_EUNSUPPORTED;
+  }
+#undef M355_H16_CASE
+  if (p.ksplit > 1) {
+    const int64_t S = (int64_t)D * H * W;
+    const int64_t total = (int64_t)N * mout * S;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out, N, mout, S,
+                       p.ksplit, total, out_bs);
+  }
+  return check_launch("conv3d_mfma_h16");
 }
 
 static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
@@ -1980,42 +2045,12 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
   M355_REQUIRE(!stat || (compute == M355_COMPUTE_F32 && p.ksplit == 1), M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
-  if (compute == M355_COMPUTE_BF16) {
-    M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
-                 "conv3d(bf16): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
-    M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
-    M355_REQUIRE((int64_t)std::max(kin, mout) * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
-                 "conv3d(bf16): tensor exceeds 2^31 elements per sample");
-    __bf16* wpb = (__bf16*)ws;
-    float* slab = (float*)((char*)ws + p.wp_bytes);
-    {
-      const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
-      const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
-      hipLaunchKernelGGL(pack_w3_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w,
-                         p.nchunks, p.mout_pad, transpose ? 1 : 0);
-    }
-    const float* kb = p.ksplit == 1 ? bias : nullptr;
-    const float* ka = p.ksplit == 1 ? add : nullptr;
-#define M355_BF_CASE(NTW, GX)                                                                  \
-  if (p.ntw == NTW && p.gx == GX) {                                                            \
-    launch_bf16<NTW, GX>(p, in, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, st); \
-  } else
-    M355_BF_CASE(8, 32) M355_BF_CASE(4, 32) M355_BF_CASE(2, 32) M355_BF_CASE(1, 32)
-    M355_BF_CASE(8, 16) M355_BF_CASE(4, 16) M355_BF_CASE(2, 16) M355_BF_CASE(1, 16)
-    M355_BF_CASE(8, 8) M355_BF_CASE(4, 8) M355_BF_CASE(2, 8) M355_BF_CASE(1, 8) {
-      set_error("conv3d(bf16): no kernel for ntw=%d gx=%d", p.ntw, p.gx);
-      return M355_EUNSUPPORTED;
-    }
-#undef M355_BF_CASE
-    if (p.ksplit > 1) {
-      const int64_t S = (int64_t)D * H * W;
-      const int64_t total = (int64_t)N * mout * S;
-      const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out, N,
-                         mout, S, p.ksplit, total, out_bs);
-    }
-    return check_launch("conv3d_mfma_bf16");
-  }
+  if (compute == M355_COMPUTE_BF16)
+    return run_h16_conv<__bf16>(p, in, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W, in_bs,
+                                out_bs, ws, ws_bytes, st);
+  if (compute == M355_COMPUTE_F16)
+    return run_h16_conv<_Float16>(p, in, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W, in_bs,
+                                  out_bs, ws, ws_bytes, st);
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
@@ -2126,7 +2161,8 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
                M355_EINVALID_ARG, "%s: non-positive dimension", who);
   M355_REQUIRE(d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->pad >= 0, M355_EINVALID_ARG,
                "%s: bad k/stride/pad (%d/%d/%d)", who, d->k, d->stride, d->pad);
-  M355_REQUIRE(d->compute == M355_COMPUTE_F32 || d->compute == M355_COMPUTE_BF16, M355_EINVALID_ARG,
+  M355_REQUIRE(d->compute == M355_COMPUTE_F32 || d->compute == M355_COMPUTE_BF16 || d->compute == M355_COMPUTE_F16,
+               M355_EINVALID_ARG,
                "%s: unknown compute mode %d", who, d->compute);
   return M355_OK;
 }
@@ -2280,15 +2316,19 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     M355_REQUIRE((int64_t)d->Cin * d->D * d->H * d->W < (1ll << 31) &&
                      (int64_t)d->Cout * d->D * d->H * d->W < (1ll << 31),
                  M355_EUNSUPPORTED, "conv3d_bwd_weight: tensor exceeds 2^31 elements per sample");
-    const bool bf16_ok = d->compute == M355_COMPUTE_BF16 && d->W % 32 == 0 && (xbs % 4 == 0) && (ybs % 4 == 0) &&
+    const bool bf16_ok = d->compute != M355_COMPUTE_F32 && d->W % 32 == 0 && (xbs % 4 == 0) && (ybs % 4 == 0) &&
                          (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !small_bww(d);
     if (bf16_ok) {
       // tile 2x2x32; the slab layout / split count of the fp32 plan are reused
       const int tz2 = (int)ceil_div(d->D, 2), ty2 = (int)ceil_div(d->H, 2), tx2 = d->W / 32;
       const int nsplit = (int)std::min<int64_t>(p.nsplit, (int64_t)d->N * tz2 * ty2 * tx2);
       dim3 gb((unsigned)p.ctiles, (unsigned)p.otiles, (unsigned)nsplit);
-      hipLaunchKernelGGL(conv3_mfma_bww_bf16_kernel, gb, dim3(256), 0, st, x, dy, slab, d->N, d->Cin, d->Cout,
-                         d->D, d->H, d->W, tz2, ty2, tx2, nsplit, xbs, ybs);
+      if (d->compute == M355_COMPUTE_BF16)
+        hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<__bf16>, gb, dim3(256), 0, st, x, dy, slab, d->N, d->Cin,
+                           d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit, xbs, ybs);
+      else
+        hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<_Float16>, gb, dim3(256), 0, st, x, dy, slab, d->N, d->Cin,
+                           d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit, xbs, ybs);
       const int64_t total = (int64_t)d->Cout * d->Cin * 27;
       const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total, nsplit);

@@ -17,7 +17,7 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 # (default, the mode every 1e-4 parity claim refers to) or "bf16" = operands rounded to bf16 at
 # staging, fp32 accumulate (BASELINE cfg3 / cfg5 family).  Tensors stay fp32 in HBM either way and
 # the weight gradient always runs in exact fp32.
-_COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16}
+_COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16}
 _compute_mode = "fp32"
 
 
