@@ -702,31 +702,15 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_h16_kernel(
 
   const int z = z0 + wave;
   const int xg = x0 + lx;
-  if (z >= D || xg >= W) return;
-  float* outp = ksplit == 1 ? y + (int64_t)n * ybs : slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW;
-  const float* an = (ksplit == 1 && add) ? add + (int64_t)n * ybs : nullptr;
-#pragma unroll
-  for (int g = 0; g < NTW; ++g) {
-    const int yg = y0 + g * GY + ly;
-    if (yg >= H) continue;
-    const int64_t sp = (int64_t)z * HW + (int64_t)yg * W + xg;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (o < Cout) {
-        const int64_t idx = (int64_t)o * D * HW + sp;
-        float v = acc[g][r];
-        if (ksplit == 1) {
-          if (bias) v += bias[o];
-          if (an) v += an[idx];
-        }
-        outp[idx] = v;
-      }
-    }
-  }
+  const bool lane_ok = z < D && xg < W;
+  if (ksplit == 1)
+    store_conv_tile<NTW, GY>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z,
+                             y0, xg, ly, half, D, H, W, lane_ok, nullptr);
+  else
+    store_conv_tile<NTW, GY>(acc, slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW, nullptr, nullptr,
+                             o0, Cout, z, y0, xg, ly, half, D, H, W, lane_ok, nullptr);
 }
 
-// ------------------------------------------------------- forward, Cout <= 4 (out conv), fp32
 // A 32-row MFMA tile would carry only Cout useful rows.  z-Toeplitz packing fills the rows
 // with (o, s), s = 0..7 being eight consecutive output planes of one (y, x) column:
 //   y[o, z0+s, y, x] = sum_{c,dy,dx} sum_{u=0..9} Wz[(c,dy,dx,u), (o,s)] * x[c, z0-1+u, y+dy-1, x+dx-1]
