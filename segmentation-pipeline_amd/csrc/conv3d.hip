@@ -36,7 +36,7 @@ __global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ 
                                int Cin, int kin_pad, int mout_pad, int transpose, int* __restrict__ counter) {
   // logical conv being run: K-channels = kin (padded to kin_pad), M-channels = mout_pad
   const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
-  if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;  // work queue of the persistent conv kernel
+  if (counter && blockIdx.x == 0 && threadIdx.x < 8) counter[threadIdx.x] = 0;  // work queues of the persistent conv kernel
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i % mout_pad);
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 // cost around them (measured: 8-chunk layers reach 112 TFLOP/s, 48-chunk layers 140): the first
 // chunk's load latency + commit, the output stores, the launch of the next workgroup.  Here the grid
 // is one residency (2 workgroups per CU) and every workgroup takes items from a queue (item = output
-// tile x 32-channel tile x sample x split, same order as the grid above; the first G items are the
-// block indices, the rest come from an atomic counter, so a workgroup that starts late -- another
-// kernel, e.g. an RCCL collective, still holding its CU -- simply takes fewer items; every item's
-// result is independent of who computes it, so this stays bit-reproducible).  The
+// tile x 32-channel tile x sample x split, same order as the grid above; XCD-aware, see "work queue"
+// below), so a workgroup that starts late -- another kernel, e.g. an RCCL collective, still holding
+// its CU -- simply takes fewer items; every item's result is independent of who computes it, so
+// this stays bit-reproducible.  The
 // (item, chunk) sequence is flattened: during the last chunk of an item the FIRST chunk of the next
 // item is prefetched, so the MFMA stream only stops for the output stores.
 template <int NTW, int GX>
@@ -436,10 +436,38 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
       if (tid + 256 * j < WE4) *reinterpret_cast<f32x4*>(&ws[buf][(tid + 256 * j) * 4]) = wr[j];
   };
 
+  // ---- work queue.  The items are dealt in eight contiguous regions, one per XCD label
+  // (blockIdx % 8: blocks b and b + 8 are observed to share an XCD and therefore an L2), so the
+  // tiles in flight on one L2 are neighbours and their shared input halos hit in it.  A workgroup
+  // takes its region's items in order from an atomic counter (its first item is static) and steals
+  // from the other regions once its own is empty.  Only thread 0 talks to the counters.
   __shared__ int next_item_s;
   const int G = (int)gridDim.x;
-  int it = blockIdx.x;
-  if (it >= total) return;
+  const int xl = blockIdx.x & 7;
+  const int cpx = (total + 7) >> 3;  // items per region
+  auto region_size = [&](int r) { return max(0, min(cpx, total - r * cpx)); };
+  auto region_static = [&](int r) { return min(region_size(r), (G - r + 7) >> 3); };  // workgroups starting there
+  auto steal = [&]() {  // thread 0; `total` = nothing left anywhere
+    for (int a = 1; a < 8; ++a) {
+      const int r = (xl + a) & 7;
+      if (region_static(r) >= region_size(r)) continue;  // nothing dynamic in that region
+      const int k = region_static(r) + atomicAdd(work_counter + r, 1);
+      if (k < region_size(r)) return r * cpx + k;
+    }
+    return total;
+  };
+  auto resolve = [&](int taken) {  // thread 0: `taken` = this workgroup's ticket in its own region
+    const int k = region_static(xl) + taken;
+    return k < region_size(xl) ? xl * cpx + k : steal();
+  };
+  int it = xl * cpx + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= region_size(xl)) {  // more workgroups than items in this region (uniform)
+    if (tid == 0) next_item_s = steal();
+    __syncthreads();
+    it = next_item_s;
+    __syncthreads();
+    if (it >= total) return;
+  }
   Item cur = decode(it);
   compute_goff(cur);
   chunk_setup(cur, cur.ch_begin, true);
@@ -451,12 +479,12 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
 
   f32x16 acc[NTW];
   while (true) {
-    // thread 0 asks the queue for this workgroup's next item now; the answer is published through
+    // thread 0 takes a ticket for this workgroup's next item now; the item is published through
     // LDS after the first chunk (a barrier later) and consumed at the start of the last chunk
     int pending = 0;
-    if (tid == 0) pending = G + atomicAdd(work_counter, 1);
+    if (tid == 0) pending = atomicAdd(work_counter + xl, 1);
     if (cur.ch_end - cur.ch_begin == 1) {  // single-chunk items: no chunk to hide the round trip behind
-      if (tid == 0) next_item_s = pending;
+      if (tid == 0) next_item_s = resolve(pending);
       __syncthreads();
     }
 #pragma unroll
@@ -501,7 +529,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = pending;
+      if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
       commit(buf ^ 1);
       __syncthreads();
       buf ^= 1;
