@@ -1139,7 +1139,7 @@ template <int GX>
 __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
     int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
-    int64_t xbs, int64_t ybs) {
+    int ctiles, int otiles, int64_t xbs, int64_t ybs) {
   using T = BwTile<GX>;
   constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS,
                 CSW = T::CSW, DSW = T::DSW, NV = T::NV;
@@ -1151,7 +1151,20 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
-  const int ctile = blockIdx.x, otile = blockIdx.y, split = blockIdx.z;
+  // XCD-aware placement (speed only): blocks b and b + 8 are observed to share an XCD and its L2, so
+  // the block id is swizzled to give each XCD a contiguous run of virtual ids, and the virtual id is
+  // decoded with the (c-tile, o-tile) pair fastest: the workgroups on one L2 work on the same and on
+  // neighbouring voxel tiles, sharing the dy tile, the x tile and the halos.  A bijection of the
+  // grid -- which partial sums land in which slab does not change, so results stay bit-identical.
+  int vid;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pairs = ctiles * otiles;
+  const int pair = vid % pairs, split = vid / pairs;
+  const int ctile = pair % ctiles, otile = pair / ctiles;
   const int c0 = ctile * 32, o0 = otile * 32;
   const int iHW = H * W, iDHW = D * H * W;
 
@@ -2384,9 +2397,9 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     const bool gen2 = vec && ((uintptr_t)dy & 3) == 0 && (int64_t)d->Cin * spatial < (1ll << 29) &&
                       (int64_t)d->Cout * spatial < (1ll << 29) && env_int("M355_BWW_GEN", 2) == 2;
 #define M355_BWW2_LAUNCH(GXV)                                                                     \
-  hipLaunchKernelGGL((conv3_mfma_bww2_kernel<GXV>), grid, dim3(256), 0, st, x, dy, slab, d->N,    \
-                     d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles,       \
-                     p.nsplit, xbs, ybs);
+  hipLaunchKernelGGL((conv3_mfma_bww2_kernel<GXV>), dim3((unsigned)(p.ctiles * p.otiles * p.nsplit)),  \
+                     dim3(256), 0, st, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, \
+                     p.ty_tiles, p.tx_tiles, p.nsplit, p.ctiles, p.otiles, xbs, ybs);
     if (gen2) {
       if (p.gx == 32) { M355_BWW2_LAUNCH(32) } else if (p.gx == 16) { M355_BWW2_LAUNCH(16) } else { M355_BWW2_LAUNCH(8) }
     } else if (p.gx == 32)
