@@ -6,10 +6,10 @@ mirrors reference code; it shards the two loops the reference runs serially:
 
 * training (segmentation_trainer.py:162-180): patches are independent units, one
   micro-batch per rank, and the only exchange is the gradient.  `PatchParallel`
-  keeps every parameter's .grad as a view into a few flat fp32 buckets and launches
-  one asynchronous all-reduce per bucket as soon as the backward pass has produced
-  all of its gradients (reverse parameter order), so RCCL overlaps with the rest of
-  the backward.  18.08 M params = 72.3 MB -> 3 buckets of <= 25 MB; an xGMI ring moves
+  packs gradients into a few flat fp32 buckets (one multi-tensor copy per bucket, as
+  soon as the backward pass has produced all of its gradients, reverse parameter
+  order) and launches one asynchronous all-reduce per bucket, so RCCL overlaps with
+  the rest of the backward; afterwards every .grad is a view of its bucket.  18.08 M params = 72.3 MB -> 3 buckets of <= 25 MB; an xGMI ring moves
   2*(7/8)*25 MB per link per bucket, far below one backward pass.
 * sliding-window inference (prediction.py:124-152): tiles are independent units;
   tile i goes to rank i % world and ONE all_gather returns the per-tile outputs, which
@@ -49,6 +49,8 @@ class PatchParallel(nn.Module):
         self._ready = [0] * len(self.buckets)
         self._used = [set() for _ in self.buckets]
         self._hooks = []
+        # RCCL / NCCL average in the collective itself; gloo (CPU tests) needs an explicit division
+        self._backend_has_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         if self.active:
             if broadcast_parameters:
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -94,12 +96,8 @@ class PatchParallel(nn.Module):
         b, _ = self.bucket_of[idx]
 
         def hook(param):
-            # move the freshly accumulated gradient into its bucket slice (first step only
-            # costs a copy; afterwards .grad already IS the slice and this is a no-op)
-            view = self._grad_view(idx)
-            if param.grad.data_ptr() != view.data_ptr():
-                view.copy_(param.grad)
-                param.grad = view
+            # autograd has just stored this parameter's gradient (.grad was None, so it was not added
+            # into anything: no kernel); count it, and ship the bucket when its last member arrives
             self._used[b].add(idx)
             self._ready[b] += 1
             if self._ready[b] == len(self.members[b]):
@@ -107,20 +105,29 @@ class PatchParallel(nn.Module):
         return hook
 
     def _launch(self, b):
-        work = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        """Pack the gradients of bucket b with ONE multi-tensor copy and start its all-reduce."""
+        idxs = [i for i in self.members[b] if self.params[i].grad is not None]
+        views = [self._grad_view(i) for i in idxs]
+        src = [(v, self.params[i].grad) for v, i in zip(views, idxs) if self.params[i].grad.data_ptr() != v.data_ptr()]
+        if src:
+            torch._foreach_copy_([v for v, _ in src], [g for _, g in src])
+        for v, i in zip(views, idxs):
+            self.params[i].grad = v  # the optimizer reads the reduced bucket
+        # slices of parameters without a gradient are never written: they stay at their initial zero
+        avg = self._backend_has_avg
+        work = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group,
+                               async_op=True)
         self._pending.append((b, work))
 
     # -- step protocol ---------------------------------------------------------
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Keep .grad pointing into the buckets: zero in place."""
-        for flat in self.buckets:
-            flat.zero_()
+    def zero_grad(self, set_to_none: bool = True):
+        """Drop the gradients (the buckets are overwritten by the next backward; nothing to memset).
+        One backward pass per step: gradient accumulation over several passes is not supported."""
         for p in self.params:
-            if p.grad is not None and set_to_none:
-                p.grad = None
+            p.grad = None
 
     def finish_gradient_sync(self):
         """Call after loss.backward(): flushes buckets with unused parameters, waits for the
@@ -133,7 +140,8 @@ class PatchParallel(nn.Module):
                 self._launch(b)  # some members never produced a gradient this step
         for b, work in self._pending:
             work.wait()
-            self.buckets[b].div_(self.world)
+            if not self._backend_has_avg:
+                self.buckets[b].div_(self.world)
         self._pending.clear()
         self._ready = [0] * len(self.buckets)
         self._used = [set() for _ in self.buckets]
