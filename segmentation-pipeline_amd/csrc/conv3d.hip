@@ -1351,7 +1351,14 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
     if (cl < cw) {
       const float* p = slab + (int64_t)tap * plane + (int64_t)o * Cin + c0 + cl;
       int s = 0;
-      for (; s + 4 <= nsplit; s += 4) {  // 4 independent loads in flight, summed in split order
+      for (; s + 16 <= nsplit; s += 16) {  // 16 independent loads in flight, summed in split order
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = p[(int64_t)(s + u) * split_stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += t[u];
+      }
+      for (; s + 4 <= nsplit; s += 4) {
         const float t0 = p[(int64_t)s * split_stride], t1 = p[(int64_t)(s + 1) * split_stride],
                     t2 = p[(int64_t)(s + 2) * split_stride], t3 = p[(int64_t)(s + 3) * split_stride];
         v += t0; v += t1; v += t2; v += t3;
