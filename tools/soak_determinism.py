@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Soak test of the queue-driven persistent conv kernel and the swizzled weight-gradient kernel: the same
+launch repeated many times must give bit-identical results every time (a race in the work queues, the LDS
+hand-off of the next item, or the statistics partials would show up as a flipped bit sooner or later).
+usage: python tools/soak_determinism.py [iterations]"""
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from raw_ops import RawOps  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+hip = RawOps("hip")
+CASES = [  # (N, Cin, Cout, D, H, W, env)
+    (1, 32, 32, 64, 64, 64, {}),
+    (1, 96, 32, 64, 64, 64, {"M355_CONV_SLOTS": "37"}),
+    (2, 24, 72, 20, 36, 40, {"M355_CONV_SLOTS": "11"}),
+    (1, 8, 40, 16, 24, 32, {"M355_CONV_SLOTS": "5", "M355_CONV_KSPLIT": "2"}),
+    (1, 4, 32, 32, 32, 32, {"M355_CONV_SLOTS": "9"}),
+]
+for N, ci, co, D, H, W, env in CASES:
+    for k in ("M355_CONV_SLOTS", "M355_CONV_KSPLIT"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, ci, D, H, W, generator=g).cuda()
+    w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    dy = torch.randn(N, co, D, H, W, generator=g).cuda()
+    ref = None
+    for i in range(iters):
+        y = hip.conv3d_fwd(x, w, b)
+        dx = hip.conv3d_bwd_data(dy, w, x.shape)
+        dw, db = hip.conv3d_bwd_weight(x, dy, 3)
+        st = hip.conv3d_fwd_stats(x, w, b, 0)
+        cur = [y, dx, dw, db] + (list(st) if st is not None else [])
+        if ref is None:
+            ref = [t.clone() for t in cur]
+        else:
+            for j, (a, r) in enumerate(zip(cur, ref)):
+                if not torch.equal(a, r):
+                    print(f"NON-DETERMINISTIC: case {(N, ci, co, D, H, W, env)} output {j} iteration {i}: "
+                          f"max diff {(a - r).abs().max().item():.3e}")
+                    sys.exit(1)
+    print(f"ok {iters} x {(N, ci, co, D, H, W)} {env}", flush=True)
+print("soak ok")
