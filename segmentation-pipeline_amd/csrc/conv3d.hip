@@ -1939,9 +1939,9 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
       // the paired rate for NTW <= 4 (u0.c0 pinned to one per CU: 111 vs 126 TFLOP/s), ~0.93 for NTW = 8
       const bool lone = per_cu == 1 || nwg <= cus;
       const double share = lone ? 1.0 / (per_cu == 1 ? 0.93 : 0.8) : (double)per_cu;
-      // fixed cost of an item: ~2 chunks for a one-shot workgroup, ~0.5 when the persistent kernel
+      // fixed cost of an item: ~1 chunk for a one-shot workgroup, ~0.5 when the persistent kernel
       // (more items than resident workgroups) prefetches across the item boundary
-      const double fixed = nwg > (int64_t)cus * per_cu ? 0.5 : 2.0;
+      const double fixed = nwg > (int64_t)cus * per_cu ? 0.5 : 1.0;
       double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + fixed) * chunk_us;
       if (ks > 1) cost += (2.0 * ks + 1.0) * (double)out_bytes / 4.0e6 + 4.0;
       if (cost < best * 0.98) {  // candidates come in order of preference: switch only for a real gain
