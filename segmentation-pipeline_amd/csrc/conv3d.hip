@@ -2167,6 +2167,7 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
       }
     }
   }
+  if (const int force = env_int("M355_BWW_NSPLIT", 0)) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
   if (Cin <= 4 || Cout <= 4)  // tap-on-lane kernel: small LDS footprint, ~3 workgroups per CU
     nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
   nsplit = std::min<int64_t>(nsplit, ntiles);

@@ -13,8 +13,29 @@ from raw_ops import RawOps  # noqa: E402
 from conv_bench import CFG2, timeit  # noqa: E402
 
 
+def sweep_bww(hip, layers):
+    """weight gradient: every split count against the cost model's pick"""
+    for name, ci, co, sp in layers:
+        x = torch.randn(1, ci, sp, sp, sp, device="cuda")
+        dy = torch.randn(1, co, sp, sp, sp, device="cuda")
+        flops = 2.0 * 27 * ci * co * sp ** 3
+        os.environ.pop("M355_BWW_NSPLIT", None)
+        base = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False), 5)
+        res = []
+        for ns in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 21, 24, 32, 42, 48, 64, 85, 96, 128, 170, 192, 256, 384, 512):
+            os.environ["M355_BWW_NSPLIT"] = str(ns)
+            res.append((timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False), 5), ns))
+        os.environ.pop("M355_BWW_NSPLIT", None)
+        res.sort()
+        best = " ".join(f"{n}:{t * 1e3:.0f}" for t, n in res[:5])
+        print(f"{name:6s} bww Cin={ci:4d} Cout={co:4d} S={sp:3d} model {base * 1e3:6.0f} us ({flops / base / 1e9:5.1f} TF) "
+              f"| best5 nsplit:us {best}", flush=True)
+
+
 def main():
     hip = RawOps("hip")
+    if "--bww" in sys.argv:
+        return sweep_bww(hip, [l for l in CFG2 if l[1] > 4 and l[2] > 4])
     layers = [l for l in CFG2 if l[1] > 4 and l[2] > 4]
     if "--small" in sys.argv:
         layers = [l for l in layers if l[3] <= 32]
