@@ -68,6 +68,10 @@ static float f16r(float f) {
   memcpy(&out, &r, 4);
   return out;
 }
+/* test hook: the operand rounding of a compute mode (tests/test_oracle_cpu.py checks it against torch's casts) */
+float m355o_round_operand(float v, int32_t compute) {
+  return compute == M355_COMPUTE_BF16 ? bf16r(v) : compute == M355_COMPUTE_F16 ? f16r(v) : v;
+}
 #define OPND(d, v) ((d)->compute == M355_COMPUTE_BF16 ? (double)bf16r(v) : (d)->compute == M355_COMPUTE_F16 ? (double)f16r(v) : (double)(v))
 
 /* ------------------------------------------------------------------ conv3d

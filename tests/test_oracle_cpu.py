@@ -181,6 +181,24 @@ def test_c_blur_weight_transform_matches_torch_composition(oracle, standardize, 
     close(dw, w.grad.float(), 2e-5, 1e-6)
 
 
+def test_c_operand_rounding_matches_torch_casts(oracle):
+    """bf16 / fp16 operand rounding of the oracle (round-to-nearest-even, subnormals, overflow to inf) ==
+    torch's float -> bfloat16 / float16 casts, bit for bit."""
+    import ctypes as C
+    from raw_ops import build_oracle
+    lib = C.CDLL(build_oracle())
+    lib.m355o_round_operand.restype = C.c_float
+    lib.m355o_round_operand.argtypes = [C.c_float, C.c_int32]
+    g = torch.Generator().manual_seed(3)
+    vals = torch.cat([torch.randn(2000, generator=g), torch.randn(500, generator=g) * 1e-6, torch.randn(500, generator=g) * 1e5,
+                      torch.tensor([0.0, -0.0, 65504.0, 65519.9, 65520.0, -70000.0, 6e-8, 5.96e-8, 2.98e-8, 3e-8, 1.0 + 2 ** -11,
+                                    1.0 + 3 * 2 ** -11, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8])])
+    for mode, dt in ((1, torch.bfloat16), (2, torch.float16)):
+        want = vals.to(dt).float()
+        got = torch.tensor([lib.m355o_round_operand(float(v), mode) for v in vals])
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), mode
+
+
 def test_c_patches_and_confusion(oracle):
     vol = rnd(2, 9, 8, 7, seed=1)
     locs = R.grid_locations((9, 8, 7), (4, 4, 4), (1, 1, 1))
