@@ -55,12 +55,16 @@ __global__ __launch_bounds__(256) void blur_weight_fwd_kernel(const float* __res
     float sd;
     filter_stats(wa, B * 27, scratch, &m, &sd);
     inv = 1.f / (sd + 1e-5f);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
       mean_std[a * 2 + 0] = m;
       mean_std[a * 2 + 1] = sd;
     }
   }
-  for (int e = threadIdx.x; e < B * 216; e += 256) {
+  // blockIdx.y splits the B*216 outputs of a filter into chunks (the statistics above are recomputed per
+  // chunk: a few KB of cached reads) so that small filter counts still fill the chip
+  const int chunk = (B * 216 + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int e_end = min(B * 216, ((int)blockIdx.y + 1) * chunk);
+  for (int e = (int)blockIdx.y * chunk + threadIdx.x; e < e_end; e += 256) {
     const int b = e / 216, r = e - b * 216;
     const int p = r / 27, t = r - p * 27;
     const int dz = blur_d(p >> 2, t / 9, transposed), dy = blur_d((p >> 1) & 1, (t / 3) % 3, transposed),
@@ -146,8 +150,10 @@ extern "C" int m355_blur_weight_fwd(const float* w, const float* scale, float* w
   M355_REQUIRE(w && scale && wexp && (mean_std || !standardize), M355_EINVALID_ARG, "blur_weight_fwd: null pointer");
   M355_REQUIRE(A > 0 && B > 0 && A <= 65535 && (int64_t)B * 216 < (1ll << 31), M355_EINVALID_ARG,
                "blur_weight_fwd: bad filter count (%d, %d)", A, B);
-  hipLaunchKernelGGL(blur_weight_fwd_kernel, dim3((unsigned)A), dim3(256), 0, (hipStream_t)stream, w, scale, wexp,
-                     mean_std, A, B, standardize, transposed);
+  // ~2048 outputs per block
+  const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div((int64_t)B * 216, 2048), 64));
+  hipLaunchKernelGGL(blur_weight_fwd_kernel, dim3((unsigned)A, chunks), dim3(256), 0, (hipStream_t)stream, w, scale,
+                     wexp, mean_std, A, B, standardize, transposed);
   return check_launch("blur_weight_fwd");
 }
 
