@@ -874,6 +874,149 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_fwd_smallcout_kernel(
   }
 }
 
+// ---- Cout <= 4 forward on the vector ALU ----
+// With three output channels the MFMA formulations above still spend 4.4x the useful flops (row
+// padding x z-Toeplitz inflation).  The packed fp32 FMA (v_pk_fma_f32: two FMAs per lane per issue)
+// runs at the same peak rate as the fp32 MFMA and wastes only the 4th channel: each thread owns a run
+// of 8 x-adjacent voxels and all (padded to 4) output channels -- 16 float2 accumulators; an input
+// row segment of 10 floats is read from LDS once per (channel, dz, dy) and used for 3 taps x 8 voxels
+// x 4 channels; the weights of a tap are one uniform 16-byte scalar load (SGPR operands of the FMA,
+// the voxel value is broadcast with op_sel).  Tile = 4 z x 8 y x 64 x, 4 input channels per LDS chunk,
+// the next chunk prefetched into registers through a buffer descriptor; two workgroups per CU.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int VS_TZ = 4, VS_TY = 8, VS_TX = 64, VS_CC = 4;
+constexpr int VS_RS = VS_TX + 4;                 // row: [left halo][64][right halo][2 pad] -> 16-byte aligned segments
+constexpr int VS_PS = (VS_TY + 2) * VS_RS, VS_CS = (VS_TZ + 2) * VS_PS;
+// wq[(c*27 + tap)*4 + o] = w[o][c][tap] (o >= Cout: 0)
+__global__ void pack_w3_valu_kernel(const float* __restrict__ w, float* __restrict__ wq, int Cout, int Cin) {
+  const int total = Cin * 27 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = i & 3, r = i >> 2;
+    wq[i] = o < Cout ? w[((int64_t)o * Cin + r / 27) * 27 + r % 27] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_valu_smallcout_kernel(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, int Cin, int Cout, int D, int H, int W,
+    int ty_tiles, int tx_tiles, int64_t xbs, int64_t ybs) {
+  constexpr int XE = VS_CC * VS_CS, XPER = (XE + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float xs[XE];
+  const int tid = threadIdx.x;
+  const int tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
+  int bt = blockIdx.x;
+  const int txt = bt % tx_tiles;
+  bt /= tx_tiles;
+  const int tyt = bt % ty_tiles;
+  const int tzt = bt / ty_tiles;
+  const int z0 = tzt * VS_TZ, y0 = tyt * VS_TY, x0 = txt * VS_TX;
+  const int n = blockIdx.y;
+  const float* xn = x + (int64_t)n * xbs;
+  const int iHW = H * W, iDHW = D * H * W;
+
+  // chunk-invariant byte offsets of this thread's halo elements (padding / past the tile: out of range)
+  unsigned goff[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    const int c = e / VS_CS, r = e - c * VS_CS;
+    const int zz = r / VS_PS, r2 = r - zz * VS_PS;
+    const int yy = r2 / VS_RS, xx = r2 - yy * VS_RS;
+    const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+    const bool ok = e < XE && xx < VS_TX + 2 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                    (unsigned)gx < (unsigned)W;
+    goff[i] = ok ? (unsigned)(c * iDHW + gz * iHW + gy * W + gx) * 4u : OOB;
+  }
+
+  f32x2 acc[8][2];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) acc[v][0] = acc[v][1] = (f32x2){0.f, 0.f};
+
+  float xr[XPER];
+  auto fetch = [&](int c0, bool live) {  // !live: zero-sized descriptor, no memory traffic
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xn + (int64_t)c0 * iDHW), 0, live ? min(VS_CC, Cin - c0) * iDHW * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[i], 0, 0));
+  };
+  fetch(0, true);
+  for (int c0 = 0; c0 < Cin; c0 += VS_CC) {
+    __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XE) xs[tid + 256 * i] = xr[i];
+    __syncthreads();
+    fetch(c0 + VS_CC < Cin ? c0 + VS_CC : c0, c0 + VS_CC < Cin);  // next chunk in flight during the FMAs
+    const int cn = min(VS_CC, Cin - c0);
+    for (int c = 0; c < cn; ++c) {
+      const float* wc = wq + (int64_t)(c0 + c) * 27 * 4;
+      const float* xc = xs + c * VS_CS + tz * VS_PS + ty * VS_RS + tx * 8;
+      // software-pipelined over the 9 (dz, dy) rows: the LDS segment and the 12 scalar weights of row
+      // r + 1 are requested before the 48 packed FMAs of row r (sched_barrier: hipcc otherwise issues
+      // each scalar load right before its first use and waits on it)
+      float seg[2][10];
+      f32x4 wrow[2][3];
+      auto request = [&](int r, int slot) {  // r is a compile-time constant after unrolling
+        const float* row = xc + (r / 3) * VS_PS + (r % 3) * VS_RS;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(row), s1 = *reinterpret_cast<const f32x4*>(row + 4);
+        const f32x2 s2 = *reinterpret_cast<const f32x2*>(row + 8);
+        seg[slot][0] = s0[0]; seg[slot][1] = s0[1]; seg[slot][2] = s0[2]; seg[slot][3] = s0[3];
+        seg[slot][4] = s1[0]; seg[slot][5] = s1[1]; seg[slot][6] = s1[2]; seg[slot][7] = s1[3];
+        seg[slot][8] = s2[0]; seg[slot][9] = s2[1];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) wrow[slot][dx] = *reinterpret_cast<const f32x4*>(wc + (r * 3 + dx) * 4);  // uniform
+      };
+      request(0, 0);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        if (r + 1 < 9) request(r + 1, (r + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const f32x2 w01 = (f32x2){wrow[r & 1][dx][0], wrow[r & 1][dx][1]};
+          const f32x2 w23 = (f32x2){wrow[r & 1][dx][2], wrow[r & 1][dx][3]};
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            const f32x2 xv = (f32x2){seg[r & 1][v + dx], seg[r & 1][v + dx]};
+            acc[v][0] = __builtin_elementwise_fma(xv, w01, acc[v][0]);
+            acc[v][1] = __builtin_elementwise_fma(xv, w23, acc[v][1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  const int gz = z0 + tz, gy = y0 + ty, gx0 = x0 + tx * 8;
+  if (gz >= D || gy >= H || gx0 >= W) return;
+  float* yn = y + (int64_t)n * ybs;
+  const float* an = add ? add + (int64_t)n * ybs : nullptr;
+  const bool vec = gx0 + 8 <= W && ((((uintptr_t)yn) | ((uintptr_t)an)) & 15) == 0 && (W & 3) == 0;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    if (o >= Cout) break;
+    const float bv = bias ? bias[o] : 0.f;
+    const int64_t idx = (int64_t)o * iDHW + (int64_t)gz * iHW + (int64_t)gy * W + gx0;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = acc[k][o >> 1][o & 1] + bv;
+    if (vec) {
+      if (an) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(an + idx), a1 = *reinterpret_cast<const f32x4*>(an + idx + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += a0[k]; v[4 + k] += a1[k]; }
+      }
+      *reinterpret_cast<f32x4*>(yn + idx) = (f32x4){v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(yn + idx + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (gx0 + k < W) yn[idx + k] = v[k] + (an ? an[idx + k] : 0.f);
+    }
+  }
+}
+
 // y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                      const float* __restrict__ add, float* __restrict__ y, int N,
@@ -2229,6 +2372,16 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
                  "conv3d_fwd: workspace too small (%zu < %zu)", workspace_bytes, small_cout_ws(d));
     M355_REQUIRE(((uintptr_t)workspace & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
     float* wpz = (float*)workspace;
+    if (env_int("M355_SMALLCOUT_VALU", 1) && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
+      // packed-FMA kernel (see conv3_valu_smallcout_kernel); the workspace of the MFMA variant is larger
+      hipLaunchKernelGGL(pack_w3_valu_kernel, dim3((unsigned)ceil_div(d->Cin * 27 * 4, 256)), dim3(256), 0, st, w, wpz,
+                         d->Cout, d->Cin);
+      const int tyv = (int)ceil_div(d->H, VS_TY), txv = (int)ceil_div(d->W, VS_TX);
+      dim3 gv((unsigned)(ceil_div(d->D, VS_TZ) * tyv * txv), (unsigned)d->N);
+      hipLaunchKernelGGL(conv3_valu_smallcout_kernel, gv, dim3(256), 0, st, x, wpz, bias, add, y, d->Cin, d->Cout,
+                         d->D, d->H, d->W, tyv, txv, xbs, ybs);
+      return check_launch("conv3_valu_smallcout");
+    }
     const int kin_pad = (int)round_up(d->Cin, 2);
     {
       const int64_t total = (int64_t)kin_pad * TZ_K * 32;
