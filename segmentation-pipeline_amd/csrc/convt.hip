@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void convt_k2s2_fwd_mfma_kernel(
 template <int NVT, int MT>
 __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
-    int Cout, int D, int H, int W, int64_t xbs, int64_t ybs) {
+    int Cout_all, int D, int H, int W, int64_t xbs, int64_t ybs, int ksplit, int o_per_split,
+    float* __restrict__ slab) {
+  // split-K: blockIdx.z = n * ksplit + ks; this workgroup contracts output channels [o_lo, Cout) only
+  // and writes its partial dX to slab[ks] (dense [N][Cin][S]); convt_dx_reduce_kernel sums the splits
   constexpr int KO = 4, KK = KO * 8;
   constexpr int P = 256 / NVT, ROWS = 16 / P;        // float2 rows staged per thread
   constexpr int CT = 32 * MT, WSS = CT + 1, WPT = CT * KK / 256;
@@ -166,7 +169,9 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
   const int S = D * H * W;
   const int v0 = blockIdx.x * NVT;
   const int c0 = blockIdx.y * CT;
-  const int n = blockIdx.z;
+  const int n = (int)blockIdx.z / ksplit, ks = (int)blockIdx.z % ksplit;
+  const int o_lo = ks * o_per_split;
+  const int Cout = min(Cout_all, o_lo + o_per_split);  // end of this split's channel range
   const float* dyn = dy + (int64_t)n * ybs;
   const int OH = 2 * H, OW = 2 * W;
   const int64_t OS = (int64_t)S * 8;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
       const int k = i & (KK - 1), c = i >> 5;  // KK == 32
       const int o = o0 + (k >> 3);
       const bool ok = c0 + c < Cin && o < Cout;
-      wpf[j] = w[ok ? ((int64_t)(c0 + c) * Cout + o) * 8 + (k & 7) : 0];
+      wpf[j] = w[ok ? ((int64_t)(c0 + c) * Cout_all + o) * 8 + (k & 7) : 0];  // row stride: ALL output channels
     }
   };
   auto commit = [&](int o0) {
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
     }
   };
 
-  fetch(0);
-  for (int o0 = 0; o0 < Cout; o0 += KO) {
+  fetch(o_lo);
+  for (int o0 = o_lo; o0 < Cout; o0 += KO) {
     __syncthreads();  // previous slab fully consumed
     commit(o0);
     __syncthreads();
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_mfma_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float* dxn = dx + (int64_t)n * xbs;
+  float* dxn = ksplit == 1 ? dx + (int64_t)n * xbs : slab + ((int64_t)ks * gridDim.z / ksplit + n) * Cin * S;
 #pragma unroll
   for (int g = 0; g < NGW; ++g) {
     const int v = v0 + (wave_n * NGW + g) * 32 + l32;
@@ -409,6 +414,17 @@ __global__ void convt_slab_reduce_kernel(const float* __restrict__ slab, float* 
       for (int s = 0; s < nsplit; ++s) v += bslab[(int64_t)s * Cout + o];
       dbias[o] = (float)v;
     }
+}
+
+// dx[n, c, v] = sum over splits of slab[ks][n][c][v] (fixed order)
+__global__ void convt_dx_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dx, int N, int64_t CS,
+                                       int64_t xbs, int ksplit) {
+  const int64_t total = (int64_t)N * CS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = slab[i];
+    for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + i];
+    dx[(i / CS) * xbs + i % CS] = v;
+  }
 }
 
 // ----------------------------------------------------- generic direct kernels
@@ -593,9 +609,32 @@ static int convt_fwd_nvt(const m355_conv3d_desc* d) {
   return 0;
 }
 
+// data-gradient plan: voxel tile, channel tile, and a split of the K = 8*Cout contraction when the level has
+// too few voxels to fill the chip (deep levels: few, long, latency-bound workgroups otherwise)
+struct ConvtBwdPlan {
+  int mt, nvt, ksplit, o_per_split;
+  size_t slab_bytes;
+};
+static ConvtBwdPlan plan_convt_bwd(const m355_conv3d_desc* d) {
+  ConvtBwdPlan p{};
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  p.mt = d->Cin > 64 ? 4 : 2;  // all input channels of a standard level in one pass over dY
+  const int64_t cblocks = ceil_div(d->Cin, 32 * p.mt);
+  p.nvt = 256;
+  while (p.nvt > 64 && ceil_div(S, p.nvt) * cblocks * d->N < 512) p.nvt >>= 1;
+  const int64_t wgs = ceil_div(S, p.nvt) * cblocks * d->N;
+  int64_t ks = 1;
+  if (wgs < 256) ks = std::min<int64_t>(std::min<int64_t>(8, ceil_div(512, wgs)), std::max(1, d->Cout / 16));
+  p.o_per_split = (int)round_up(ceil_div(d->Cout, ks), 4);
+  p.ksplit = (int)ceil_div(d->Cout, p.o_per_split);
+  p.slab_bytes = p.ksplit > 1 ? (size_t)round_up((int64_t)p.ksplit * d->N * d->Cin * S * 4, 256) : 0;
+  return p;
+}
+
 extern "C" size_t m355_conv_transpose3d_workspace(const m355_conv3d_desc* d) {
   if (!d) return 0;
-  return convt_slab_bytes(d) + convt_dbias_bytes(d);
+  const size_t bwd = is_k2s2(d) ? plan_convt_bwd(d).slab_bytes : 0;
+  return std::max(convt_slab_bytes(d) + convt_dbias_bytes(d), bwd);
 }
 
 extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
@@ -642,27 +681,35 @@ extern "C" int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const f
                                               size_t workspace_bytes, void* stream) {
   if (int rc = validate_convt(d, "conv_transpose3d_bwd_data")) return rc;
   M355_REQUIRE(dy && w && dx, M355_EINVALID_ARG, "conv_transpose3d_bwd_data: null pointer");
-  (void)workspace; (void)workspace_bytes;
   hipStream_t st = (hipStream_t)stream;
   const int OD = convt_out(d->D, d), OH = convt_out(d->H, d), OW = convt_out(d->W, d);
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   if (is_k2s2(d) && (ybs % 2 == 0) && ((uintptr_t)dy & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
-    const int mt = d->Cin > 64 ? 4 : 2;  // all input channels of a standard level in one pass over dY
-    const int64_t cblocks = ceil_div(d->Cin, 32 * mt);
-    int nvt = 256;
-    while (nvt > 64 && ceil_div(S, nvt) * cblocks * d->N < 512) nvt >>= 1;
-    dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)cblocks, (unsigned)d->N);
+    const ConvtBwdPlan bp = plan_convt_bwd(d);
+    const int mt = bp.mt, nvt = bp.nvt, ksplit = bp.ksplit;
+    float* slab = nullptr;
+    if (ksplit > 1) {
+      M355_REQUIRE(workspace && workspace_bytes >= bp.slab_bytes, M355_EWORKSPACE,
+                   "conv_transpose3d_bwd_data: workspace too small (%zu < %zu)", workspace_bytes, bp.slab_bytes);
+      slab = (float*)workspace;
+    }
+    dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)ceil_div(d->Cin, 32 * mt), (unsigned)(d->N * ksplit));
 #define M355_CONVT_BWD(NVT, MT)                                                                                \
   hipLaunchKernelGGL((convt_k2s2_bwd_data_mfma_kernel<NVT, MT>), grid, dim3(256), 0, st, dy, w, dx, d->Cin,    \
-                     d->Cout, d->D, d->H, d->W, xbs, ybs)
+                     d->Cout, d->D, d->H, d->W, xbs, ybs, ksplit, bp.o_per_split, slab)
     if (mt == 2) {
       if (nvt == 256) M355_CONVT_BWD(256, 2); else if (nvt == 128) M355_CONVT_BWD(128, 2); else M355_CONVT_BWD(64, 2);
     } else {
       if (nvt == 256) M355_CONVT_BWD(256, 4); else if (nvt == 128) M355_CONVT_BWD(128, 4); else M355_CONVT_BWD(64, 4);
     }
 #undef M355_CONVT_BWD
+    if (ksplit > 1) {
+      const int64_t total = (int64_t)d->N * d->Cin * S;
+      hipLaunchKernelGGL(convt_dx_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256),
+                         0, st, slab, dx, d->N, (int64_t)d->Cin * S, xbs, ksplit);
+    }
     return check_launch("convt_k2s2_bwd_data");
   }
   const int64_t total = (int64_t)d->N * d->Cin * d->D * d->H * d->W;
