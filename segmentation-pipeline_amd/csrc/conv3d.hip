@@ -1556,9 +1556,9 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
   const float* qb = qs + s_l * QS + toff + half;
   const float* pb = ps + l32 * DSW + half;
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
 
   const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
   const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
@@ -1630,11 +1630,17 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
       for (int yy = 0; yy < TY; ++yy) {
         const float* prow = pb + (z * TY + yy) * TX;
         const float* qrow = qb + z * PS + yy * RS;
+        // two independent accumulation chains (even / odd voxel pairs): a single chain makes every MFMA
+        // wait for the previous one's result
 #pragma unroll
-        for (int xp = 0; xp < TX / 2; ++xp)
+        for (int xp = 0; xp < TX / 2; xp += 2) {
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(prow[2 * xp], qrow[2 * xp], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(prow[2 * xp + 2], qrow[2 * xp + 2], acc2, 0, 0, 0);
+        }
       }
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
   float* sl = slab + (int64_t)split * Cout * Cin * 27;
   if (tap_raw < 27 && s_l < CQ) {
 #pragma unroll
