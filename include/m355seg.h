@@ -57,6 +57,9 @@ enum { M355_ACT_NONE = 0, M355_ACT_RELU = 1, M355_ACT_LEAKY_RELU = 2 };
 
 int m355_version(void);
 const char* m355_last_error(void);
+/* The M355_* tuning overrides (test / sweep hooks: M355_CONV_NTW, M355_CONV_KSPLIT, M355_CONV_SLOTS, ...) are
+ * read from the environment once, when the library is loaded; call this after changing them. */
+void m355_reload_tuning(void);
 
 /* ------------------------------------------------------------------ conv3d
  * Replaces nn.Conv3d as used by Block3d (models/components.py:36,42,51) and the
@@ -278,6 +281,14 @@ int m355_blur_weight_fwd(const float* w, const float* scale, float* wexp, float*
                          int32_t standardize, int32_t transposed, void* stream);
 int m355_blur_weight_bwd(const float* dwexp, const float* w, const float* scale, const float* mean_std, float* dw,
                          int32_t A, int32_t B, int32_t standardize, int32_t transposed, void* stream);
+
+/* WSConv3d weight standardisation (reference models/components.py:81-88; also the optional first step of
+ * the Blur convolutions, folded into m355_blur_weight_* above): per dim-0 filter a of n = Cin*k^3 entries,
+ *   wn = (w - mean_a) / (std_a + 1e-5)   with torch.std's unbiased estimator.
+ * mean_std [A][2] is written by fwd and read by bwd (dw from dwn). */
+int m355_weight_standardize_fwd(const float* w, float* wn, float* mean_std, int32_t A, int32_t n, void* stream);
+int m355_weight_standardize_bwd(const float* dwn, const float* w, const float* mean_std, float* dw, int32_t A,
+                                int32_t n, void* stream);
 
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio

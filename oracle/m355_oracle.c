@@ -861,6 +861,37 @@ int m355o_blur_weight_bwd(const float* dwexp, const float* w, const float* scale
   return 0;
 }
 
+/* WSConv3d weight standardisation, models/components.py:81-88 (torch.std is unbiased). */
+int m355o_weight_standardize_fwd(const float* w, float* wn, float* mean_std, int32_t A, int32_t n, void* stream) {
+  (void)stream;
+  for (int a = 0; a < A; ++a) {
+    const float* wa = w + (int64_t)a * n;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) s1 += wa[i];
+    const double m = s1 / n;
+    for (int i = 0; i < n; ++i) s2 += (wa[i] - m) * (wa[i] - m);
+    const double sd = n > 1 ? sqrt(s2 / (n - 1)) : 0.0;
+    mean_std[a * 2 + 0] = (float)m;
+    mean_std[a * 2 + 1] = (float)sd;
+    for (int i = 0; i < n; ++i) wn[(int64_t)a * n + i] = (float)((wa[i] - m) / (sd + 1e-5));
+  }
+  return 0;
+}
+int m355o_weight_standardize_bwd(const float* dwn, const float* w, const float* mean_std, float* dw, int32_t A,
+                                 int32_t n, void* stream) {
+  (void)stream;
+  for (int a = 0; a < A; ++a) {
+    const float* wa = w + (int64_t)a * n;
+    const float* g = dwn + (int64_t)a * n;
+    const double m = mean_std[a * 2 + 0], sd = mean_std[a * 2 + 1], se = sd + 1e-5;
+    double sg = 0.0, sgw = 0.0;
+    for (int i = 0; i < n; ++i) { sg += g[i]; sgw += g[i] * (wa[i] - m); }
+    const double c1 = sg / n, c2 = (n > 1 && sd > 0.0) ? sgw / (se * se * (n - 1) * sd) : 0.0;
+    for (int i = 0; i < n; ++i) dw[(int64_t)a * n + i] = (float)((g[i] - c1) / se - (wa[i] - m) * c2);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict: prediction.py:132-143.  The arithmetic lives in torchio 0.18.45
  * (GridSampler / GridAggregator overlap_mode='average'), absent from the reference tree:

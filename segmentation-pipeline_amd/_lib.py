@@ -44,6 +44,7 @@ _CD, _ND = C.POINTER(ConvDesc), C.POINTER(NormDesc)
 SIGNATURES = {
     "m355_version": (C.c_int, []),
     "m355_last_error": (C.c_char_p, []),
+    "m355_reload_tuning": (None, []),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
     "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_stats_slots": (_i64, [_CD]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     "m355_depth_to_space2": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_blur_weight_fwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "m355_blur_weight_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P]),
+    "m355_weight_standardize_fwd": (C.c_int, [_P, _P, _P, _i32, _i32, _P]),
+    "m355_weight_standardize_bwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _P]),
     "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_finalize": (C.c_int, [_P, _P, _P, _i32, _i64, _P]),
@@ -125,6 +128,11 @@ def lib():
         if _lib.m355_version() != 1:
             raise M355Error(f"ABI version mismatch: library reports {_lib.m355_version()}, expected 1")
     return _lib
+
+
+def reload_tuning():
+    """Re-read the M355_* environment overrides (the library caches them at load time)."""
+    lib().m355_reload_tuning()
 
 
 def check(rc, what):

@@ -10,6 +10,30 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoi(v);
+}
+static Tuning read_tuning() {
+  Tuning t;
+  t.conv_ntw = env_int("M355_CONV_NTW", 0);
+  t.conv_ksplit = env_int("M355_CONV_KSPLIT", 0);
+  t.conv_slots = env_int("M355_CONV_SLOTS", 0);
+  t.conv_persistent = env_int("M355_CONV_PERSISTENT", 1);
+  t.no_small = env_int("M355_NO_SMALL", 0);
+  t.smallcout_valu = env_int("M355_SMALLCOUT_VALU", 1);
+  t.bww_nsplit = env_int("M355_BWW_NSPLIT", 0);
+  t.bww_gen = env_int("M355_BWW_GEN", 2);
+  t.bww_queue = env_int("M355_BWW_QUEUE", 1);
+  t.h16_persistent = env_int("M355_H16_PERSISTENT", 1);
+  t.tile16 = env_int("M355_TILE16", 1);
+  t.fuse_softmax = env_int("M355_FUSE_SOFTMAX", 1);
+  return t;
+}
+static Tuning g_tuning = read_tuning();
+const Tuning& tuning() { return g_tuning; }
+
 int num_cus() {
   static int cache[64] = {0};
   int dev = 0;
@@ -29,5 +53,6 @@ int num_cus() {
 }
 }  // namespace m355
 
+extern "C" void m355_reload_tuning(void) { m355::g_tuning = m355::read_tuning(); }
 extern "C" int m355_version(void) { return M355_ABI_VERSION; }
 extern "C" const char* m355_last_error(void) { return m355::g_err; }

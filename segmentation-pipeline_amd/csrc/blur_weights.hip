@@ -141,9 +141,69 @@ __global__ __launch_bounds__(256) void blur_weight_bwd_kernel(const float* __res
   }
 }
 
+// Plain weight standardisation of WSConv3d (models/components.py:81-88):
+//   wn[a][i] = (w[a][i] - mean_a) / (std_a + 1e-5),  unbiased std over the n = Cin*k^3 entries of filter a.
+__global__ __launch_bounds__(256) void weight_standardize_fwd_kernel(const float* __restrict__ w, float* __restrict__ wn,
+                                                                     float* __restrict__ mean_std, int n) {
+  __shared__ double scratch[4];
+  const int a = blockIdx.x;
+  const float* wa = w + (int64_t)a * n;
+  float m, sd;
+  filter_stats(wa, n, scratch, &m, &sd);
+  const float inv = 1.f / (sd + 1e-5f);
+  if (threadIdx.x == 0) {
+    mean_std[a * 2 + 0] = m;
+    mean_std[a * 2 + 1] = sd;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) wn[(int64_t)a * n + i] = (wa[i] - m) * inv;
+}
+
+// dw_k = (g_k - mean(g)) / (s + eps) - (w_k - m) * sum_i g_i (w_i - m) / ((s + eps)^2 (n - 1) s)
+__global__ __launch_bounds__(256) void weight_standardize_bwd_kernel(const float* __restrict__ dwn,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ mean_std,
+                                                                     float* __restrict__ dw, int n) {
+  __shared__ double scratch[4];
+  const int a = blockIdx.x;
+  const float* wa = w + (int64_t)a * n;
+  const float* ga = dwn + (int64_t)a * n;
+  const float m = mean_std[a * 2 + 0], sd = mean_std[a * 2 + 1];
+  double sg = 0.0, sgw = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double g = ga[i];
+    sg += g;
+    sgw += g * ((double)wa[i] - m);
+  }
+  sg = block_sum<double, 256, true>(sg, scratch);
+  sgw = block_sum<double, 256, true>(sgw, scratch);
+  const double se = (double)sd + 1e-5;
+  const double c1 = sg / n;
+  const double c2 = (n > 1 && sd > 0.f) ? sgw / (se * se * (n - 1) * (double)sd) : 0.0;
+  for (int i = threadIdx.x; i < n; i += 256)
+    dw[(int64_t)a * n + i] = (float)(((double)ga[i] - c1) / se - ((double)wa[i] - m) * c2);
+}
+
 }  // namespace m355
 
 using namespace m355;
+
+extern "C" int m355_weight_standardize_fwd(const float* w, float* wn, float* mean_std, int32_t A, int32_t n,
+                                           void* stream) {
+  M355_REQUIRE(w && wn && mean_std, M355_EINVALID_ARG, "weight_standardize_fwd: null pointer");
+  M355_REQUIRE(A > 0 && n > 0, M355_EINVALID_ARG, "weight_standardize_fwd: bad filter shape (%d, %d)", A, n);
+  hipLaunchKernelGGL(weight_standardize_fwd_kernel, dim3((unsigned)A), dim3(256), 0, (hipStream_t)stream, w, wn,
+                     mean_std, n);
+  return check_launch("weight_standardize_fwd");
+}
+
+extern "C" int m355_weight_standardize_bwd(const float* dwn, const float* w, const float* mean_std, float* dw,
+                                           int32_t A, int32_t n, void* stream) {
+  M355_REQUIRE(dwn && w && mean_std && dw, M355_EINVALID_ARG, "weight_standardize_bwd: null pointer");
+  M355_REQUIRE(A > 0 && n > 0, M355_EINVALID_ARG, "weight_standardize_bwd: bad filter shape (%d, %d)", A, n);
+  hipLaunchKernelGGL(weight_standardize_bwd_kernel, dim3((unsigned)A), dim3(256), 0, (hipStream_t)stream, dwn, w,
+                     mean_std, dw, n);
+  return check_launch("weight_standardize_bwd");
+}
 
 extern "C" int m355_blur_weight_fwd(const float* w, const float* scale, float* wexp, float* mean_std, int32_t A,
                                     int32_t B, int32_t standardize, int32_t transposed, void* stream) {

@@ -61,12 +61,15 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
   return r;
 }
 
-// Integer tuning override from the environment (0 / unset = use the built-in heuristic).
-static inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  if (!v || !*v) return dflt;
-  return atoi(v);
-}
+// Tuning overrides (test / sweep hooks).  The M355_* environment variables are read ONCE, when the
+// library is first used, and again only on m355_reload_tuning(): the launch paths never call getenv.
+// 0 / unset = use the built-in heuristic.
+struct Tuning {
+  int conv_ntw = 0, conv_ksplit = 0, conv_slots = 0, conv_persistent = 1;
+  int no_small = 0, smallcout_valu = 1, bww_nsplit = 0, bww_gen = 2, bww_queue = 1, h16_persistent = 1, tile16 = 1;
+  int fuse_softmax = 1;
+};
+const Tuning& tuning();
 
 static inline int64_t dense_or(int64_t stride, int64_t dense) { return stride ? stride : dense; }
 

@@ -2050,8 +2050,8 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   //   one chunk 54 x NTW MFMAs of 64 cycles per wave at ~2.04 GHz; + fill/epilogue (see `fixed`)
   //   split-K   ks x out bytes written + read again by the reduce kernel (~4 TB/s) + a launch
   const int64_t out_bytes = (int64_t)N * mout * D * H * W * 4;
-  const int force_ntw = env_int("M355_CONV_NTW", 0);
-  const int force_ks = env_int("M355_CONV_KSPLIT", 0);
+  const int force_ntw = tuning().conv_ntw;
+  const int force_ks = tuning().conv_ksplit;
   const int cands[4] = {4, 8, 2, 1};
   int chosen = 1, chosen_ks = 1;
   double best = 1e30;
@@ -2111,10 +2111,10 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   const int ksplit = chosen_ks;
   {
     // resident workgroups (LDS + registers: 2 per CU up to NTW = 4); the override exists for the tests
-    const int64_t slots = env_int("M355_CONV_SLOTS", (p.ntw <= 4 ? 2 : 1) * num_cus());
+    const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (p.ntw <= 4 ? 2 : 1) * num_cus());
     const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
-                   env_int("M355_CONV_PERSISTENT", 1);
+                   tuning().conv_persistent;
   }
   // packed weights + 256 B for the work counter of the persistent kernel
   p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (h16 ? 2 : 4), 256) + 256;
@@ -2134,14 +2134,14 @@ static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 
 // Cout <= 4 forward in exact fp32: z-Toeplitz packed rows instead of a mostly-empty 32-row tile
 static bool small_cout_fwd(const m355_conv3d_desc* d) {
   return d->Cout <= 4 && d->compute == M355_COMPUTE_F32 && d->W >= 32 && d->D >= 8 && d->Cin >= 8 &&
-         !env_int("M355_NO_SMALL", 0) && (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 31);
+         !tuning().no_small && (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 31);
 }
 static size_t small_cout_ws(const m355_conv3d_desc* d) {
   return (size_t)round_up((int64_t)round_up(d->Cin, 2) * TZ_K * 32 * 4, 256);
 }
 static bool small_bww(const m355_conv3d_desc* d) {
   // tap-on-lane kernel; a sample must fit the 32-bit byte offsets of a buffer descriptor
-  return (d->Cin <= 4 || d->Cout <= 4) && !env_int("M355_NO_SMALL", 0) &&
+  return (d->Cin <= 4 || d->Cout <= 4) && !tuning().no_small &&
          (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 29);
 }
 
@@ -2154,7 +2154,7 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
   if (p.persistent) {
-    const int64_t slots = env_int("M355_CONV_SLOTS", (NTW <= 4 ? 2 : 1) * num_cus());
+    const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus());
     hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
                        add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
                        p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter);
@@ -2316,7 +2316,7 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
       }
     }
   }
-  if (const int force = env_int("M355_BWW_NSPLIT", 0)) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
+  if (const int force = tuning().bww_nsplit) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
   if (Cin <= 4 || Cout <= 4)  // tap-on-lane kernel: small LDS footprint, ~3 workgroups per CU
     nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
   nsplit = std::min<int64_t>(nsplit, ntiles);
@@ -2378,7 +2378,7 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
                  "conv3d_fwd: workspace too small (%zu < %zu)", workspace_bytes, small_cout_ws(d));
     M355_REQUIRE(((uintptr_t)workspace & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
     float* wpz = (float*)workspace;
-    if (env_int("M355_SMALLCOUT_VALU", 1) && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
+    if (tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
       // packed-FMA kernel (see conv3_valu_smallcout_kernel); the workspace of the MFMA variant is larger
       hipLaunchKernelGGL(pack_w3_valu_kernel, dim3((unsigned)ceil_div(d->Cin * 27 * 4, 256)), dim3(256), 0, st, w, wpz,
                          d->Cout, d->Cin);
@@ -2562,7 +2562,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     // buffer descriptor (the hardware zero-fills what lies past it)
     const int64_t spatial = (int64_t)d->D * d->H * d->W;
     const bool gen2 = vec && ((uintptr_t)dy & 3) == 0 && (int64_t)d->Cin * spatial < (1ll << 29) &&
-                      (int64_t)d->Cout * spatial < (1ll << 29) && env_int("M355_BWW_GEN", 2) == 2;
+                      (int64_t)d->Cout * spatial < (1ll << 29) && tuning().bww_gen == 2;
 #define M355_BWW2_LAUNCH(GXV)                                                                     \
   hipLaunchKernelGGL((conv3_mfma_bww2_kernel<GXV>), dim3((unsigned)(p.ctiles * p.otiles * p.nsplit)),  \
                      dim3(256), 0, st, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, \

@@ -26,6 +26,50 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+# ---- sharding of independent inference units (sliding-window tiles, ensemble members) ----------
+# Opt-in and exclusive.  Sharding assumes EVERY rank holds the same input and calls the predictor
+# at the same time, which is not true for e.g. rank-local validation inside a DDP training job, so
+# it must be requested (`with unit_sharding():`).  Only the OUTERMOST sharder inside such a region
+# shards; nested ones (an ensemble of ensembles, research/msseg2/competition/ms-inference.py:115-125,
+# or PatchPredict around an ensemble) run all of their units locally -- otherwise the ranks would
+# issue different collective sequences (a hang on RCCL) or mix tiles of different members.
+_shard_enabled = False
+_shard_depth = 0
+
+
+class unit_sharding:
+    """`with unit_sharding():` -- PatchPredict / Ensemble* called inside spread their units over
+    the ranks of the default process group (one gather per call).  No-op without torch.distributed."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _shard_enabled
+        self.prev = _shard_enabled
+        _shard_enabled = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _shard_enabled
+        _shard_enabled = self.prev
+
+
+class shard_scope:
+    """Used by the sharders themselves: `with shard_scope() as active:` -- `active` is True for the
+    outermost sharder of an enabled region when torch.distributed has more than one rank."""
+
+    def __enter__(self):
+        global _shard_depth
+        active = _shard_enabled and _shard_depth == 0 and is_distributed()
+        _shard_depth += 1
+        return active
+
+    def __exit__(self, *exc):
+        global _shard_depth
+        _shard_depth -= 1
+
+
 class PatchParallel(nn.Module):
     """Data-parallel wrapper with bucketed, backward-overlapped gradient all-reduce.
 
@@ -145,6 +189,25 @@ class PatchParallel(nn.Module):
         self._pending.clear()
         self._ready = [0] * len(self.buckets)
         self._used = [set() for _ in self.buckets]
+        self.sync_buffers()
+
+    def sync_buffers(self):
+        """BatchNorm running statistics are updated from per-rank batches (the reference's
+        per-process semantics, models/components.py:24): average the floating-point buffers over the
+        ranks in ONE flat all-reduce so that eval-mode predictions and `state_dict()` agree on every
+        rank (integer buffers such as num_batches_tracked advance identically and are left alone)."""
+        if not self.active:
+            return
+        bufs = [b for b in self.module.buffers() if b.is_floating_point() and b.numel() > 0]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat /= self.world
+        off = 0
+        for b in bufs:
+            b.data.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
 
     def state_dict(self, *args, **kwargs):
         return self.module.state_dict(*args, **kwargs)
@@ -167,11 +230,13 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dtype, device, group=None):
+def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dtype, device, group=None,
+                 sharded: bool = True):
     """ONE collective: every rank contributes its tiles (padded to the max per-rank count);
-    returns [n_tiles, *tile_shape] in global tile order on every rank."""
-    world = dist.get_world_size(group) if is_distributed() else 1
-    rank = dist.get_rank(group) if is_distributed() else 0
+    returns [n_tiles, *tile_shape] in global tile order on every rank.  `sharded=False`: the caller
+    computed every tile locally (no collective)."""
+    world = dist.get_world_size(group) if (sharded and is_distributed()) else 1
+    rank = dist.get_rank(group) if (sharded and is_distributed()) else 0
     per = (n_tiles + world - 1) // world
     send = torch.zeros((per,) + tuple(tile_shape), dtype=dtype, device=device)
     n_local = len(shard_indices(n_tiles, rank, world))

@@ -39,12 +39,6 @@ def _uniform_int(value, what):
     return vals.pop()
 
 
-def _standardize(weight):
-    # components.py:83-84 / :114-116 / :147-149: torch.std is the unbiased estimator
-    weight = weight - weight.mean(dim=(1, 2, 3, 4), keepdim=True)
-    return weight / (weight.std(dim=(1, 2, 3, 4), keepdim=True) + 1e-5)
-
-
 def _box_blur(weight, kernel):
     """F.conv3d(weight, kernel, padding=1, groups=in_channels) for the all-equal 2x2x2
     `kernel` buffer of the Blur convolutions (components.py:118,151): a k -> k+1 box
@@ -75,43 +69,6 @@ def _blur_scale(kernel, weight):
     return kernel.reshape(kernel.shape[0], -1)[:, 0].contiguous()
 
 
-# A stride-2 conv with a 4x4x4 kernel and padding 1 is a stride-1 3x3x3 conv over the space-to-depth
-# input: along one axis, input index 2Z + d - 1 has parity (d-1)&1 and half-resolution offset
-# floor((d-1)/2) in {-1, 0, 0, +1} for d = 0..3, i.e. tap t = offset + 1 of a 3-tap kernel.
-#   parity 0: t=1 <- d=1, t=2 <- d=3        parity 1: t=0 <- d=0, t=1 <- d=2
-# The transposed conv (k=4, s=2, p=1) is the mirror image: output parity P at position 2z'+P reads
-#   P=0: t=0 <- d=3, t=1 <- d=1            P=1: t=1 <- d=2, t=2 <- d=0
-# Both give an 8-of-27 sparse 3x3x3 filter that runs on the fp32-MFMA conv kernels.
-_S2D_TAP = {(0, 1): 1, (0, 2): 3, (1, 0): 0, (1, 1): 2}      # (parity, tap) -> d   (strided conv)
-_D2S_TAP = {(0, 0): 3, (0, 1): 1, (1, 1): 2, (1, 2): 0}      # (parity, tap) -> d   (transposed conv)
-
-
-def _expansion_index(table, device):
-    """gather index [8 parities, 27 taps] into the 64 entries of a 4x4x4 filter, and a 0/1 mask."""
-    idx = torch.zeros(8, 27, dtype=torch.long)
-    mask = torch.zeros(8, 27)
-    for p in range(8):
-        par = (p >> 2, (p >> 1) & 1, p & 1)
-        for t in range(27):
-            tap = (t // 9, (t // 3) % 3, t % 3)
-            d = [table.get((par[a], tap[a])) for a in range(3)]
-            if None not in d:
-                idx[p, t] = (d[0] * 4 + d[1]) * 4 + d[2]
-                mask[p, t] = 1.0
-    return idx.to(device), mask.to(device)
-
-
-def _expand_4x4x4(w4, table):
-    """[A, B, 4, 4, 4] -> [A, B, 8, 27] sparse 3x3x3 filters per parity (differentiable gather)."""
-    idx, mask = _expansion_index(table, w4.device)
-    flat = w4.reshape(w4.shape[0], w4.shape[1], 64)
-    return flat[:, :, idx.reshape(-1)].reshape(w4.shape[0], w4.shape[1], 8, 27) * mask
-
-
-def _is_blur_geometry(w_eff, stride, padding, output_padding=0):
-    return tuple(w_eff.shape[2:]) == (4, 4, 4) and stride == 2 and padding == 1 and output_padding == 0
-
-
 class WSConv3d(nn.Conv3d):
     """Weight-standardised convolution (reference components.py:76-88)."""
 
@@ -121,7 +78,7 @@ class WSConv3d(nn.Conv3d):
 
     def effective(self):
         # the reference forwards only **kwargs to F.conv3d, so the bias is unused (:86)
-        return _standardize(self.weight), None
+        return ops.weight_standardize(self.weight), None
 
     def forward(self, x):
         return run_conv(self, x)
@@ -141,7 +98,7 @@ class BlurConv3d(nn.Conv3d):
     def effective(self):
         w = self.weight
         if self.weight_standardization:
-            w = _standardize(w)
+            w = ops.weight_standardize(w)
         return _box_blur(w, self.kernel), None  # bias never used (:119)
 
     def forward(self, x):
@@ -178,7 +135,7 @@ class BlurConvTranspose3d(nn.ConvTranspose3d):
             return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1), out=out)
         w = self.weight
         if self.weight_standardization:
-            w = _standardize(w)
+            w = ops.weight_standardize(w)
         w = _box_blur(w, self.kernel)
         return ops.conv_transpose3d(
             x, w, None, stride=_uniform_int(self.stride, "stride"),

@@ -1,8 +1,8 @@
 """Test-time ensembles (mirror of segmentation_pipeline/models/ensemble.py:9-103).
 
 The member forward passes run on the HIP kernels; the reductions over the ensemble
-axis are index / selection arithmetic on the stacked predictions.  With
-torch.distributed initialised the members are independent units: member e runs on rank
+axis are index / selection arithmetic on the stacked predictions.  Inside
+`distributed.unit_sharding()` the members are independent units: member e runs on rank
 e % world and ONE all_gather returns the predictions in member order, so the result is
 bit-identical to the single-GPU ensemble.
 """
@@ -36,26 +36,29 @@ def apply_strategy(predictions: Sequence[torch.Tensor], strategy: str):
     raise RuntimeError(f"Invalid prediction strategy {strategy}")
 
 
-def _run_members(thunks):
-    """Evaluate the member forward passes, sharded over the ranks when distributed."""
+def _run_members(thunks, device):
+    """Evaluate the member forward passes; inside `distributed.unit_sharding()` the OUTERMOST
+    ensemble (or sliding-window predictor) spreads its members over the ranks, nested ones run all
+    of theirs locally (see distributed.shard_scope)."""
     from .. import distributed as D
-    if not D.is_distributed():
-        return [t() for t in thunks]
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    mine = D.shard_indices(len(thunks), rank, world)
-    local = [thunks[i]().contiguous() for i in mine]
-    # every rank learns the member shape / dtype from rank 0 (which always owns member 0)
-    meta = torch.zeros(8, dtype=torch.int64, device=local[0].device if local else None)
-    if rank == 0:
-        meta[0] = local[0].dim()
-        meta[1:1 + local[0].dim()] = torch.tensor(local[0].shape)
-    dist.broadcast(meta, src=0)
-    shape = tuple(int(v) for v in meta[1:1 + int(meta[0])])
-    device = meta.device
-    stacked = torch.stack(local) if local else None
-    out = D.gather_tiles(stacked, len(thunks), shape, torch.float32, device)
-    return list(out)
+    with D.shard_scope() as sharded:
+        if not sharded:
+            return [t() for t in thunks]
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        mine = D.shard_indices(len(thunks), rank, world)
+        local = [thunks[i]().contiguous() for i in mine]
+        # every rank learns the member shape from rank 0 (which always owns member 0); ranks without a
+        # member (fewer members than ranks) still take part, with tensors on the INPUT's device
+        meta = torch.zeros(8, dtype=torch.int64, device=device)
+        if rank == 0:
+            meta[0] = local[0].dim()
+            meta[1:1 + local[0].dim()] = torch.tensor(local[0].shape)
+        dist.broadcast(meta, src=0)
+        shape = tuple(int(v) for v in meta[1:1 + int(meta[0])])
+        stacked = torch.stack(local) if local else None
+        out = D.gather_tiles(stacked, len(thunks), shape, torch.float32, device)
+        return list(out)
 
 
 def _flip_sets(dims):
@@ -72,7 +75,7 @@ class EnsembleModels(nn.Module):
         self.strategy = parse_strategy(strategy)
 
     def forward(self, x):
-        return apply_strategy(_run_members([(lambda m=m: m(x)) for m in self.models]), self.strategy)
+        return apply_strategy(_run_members([(lambda m=m: m(x)) for m in self.models], x.device), self.strategy)
 
 
 class EnsembleFlips(nn.Module):
@@ -85,7 +88,7 @@ class EnsembleFlips(nn.Module):
 
     def forward(self, x):
         thunks = [(lambda f=f: self.model(x.flip(f).contiguous()).flip(f)) for f in self.flips]
-        return apply_strategy(_run_members(thunks), self.strategy)
+        return apply_strategy(_run_members(thunks, x.device), self.strategy)
 
 
 class EnsembleOrientations(nn.Module):
@@ -104,4 +107,4 @@ class EnsembleOrientations(nn.Module):
             for f in self.flips:
                 thunks.append(lambda perm=perm, inverse=inverse, f=f:
                               self.model(x.permute(0, 1, *perm).flip(f).contiguous()).flip(f).permute(0, 1, *inverse))
-        return apply_strategy(_run_members(thunks), self.strategy)
+        return apply_strategy(_run_members(thunks, x.device), self.strategy)

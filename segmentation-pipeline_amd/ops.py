@@ -694,6 +694,35 @@ def blur_weight(w, scale, standardize=False, transposed=False):
     return _BlurWeightFn.apply(w, scale, bool(standardize), bool(transposed))
 
 
+class _WeightStandardizeFn(torch.autograd.Function):
+    """WSConv3d's (w - mean) / (std + 1e-5) per output filter (reference models/components.py:81-88)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        L = _lib.lib()
+        _require(w)
+        w = w.contiguous()
+        A, n = w.shape[0], w[0].numel()
+        wn = torch.empty_like(w)
+        ms = torch.empty((A, 2), dtype=torch.float32, device=w.device)
+        check(L.m355_weight_standardize_fwd(_p(w), _p(wn), _p(ms), A, n, _stream()), "weight_standardize_fwd")
+        ctx.save_for_backward(w, ms)
+        return wn
+
+    @staticmethod
+    def backward(ctx, dwn):
+        L = _lib.lib()
+        w, ms = ctx.saved_tensors
+        dw = torch.empty_like(w)
+        check(L.m355_weight_standardize_bwd(_p(dwn.contiguous()), _p(w), _p(ms), _p(dw), w.shape[0], w[0].numel(),
+                                            _stream()), "weight_standardize_bwd")
+        return dw
+
+
+def weight_standardize(w):
+    return _WeightStandardizeFn.apply(w)
+
+
 # --------------------------------------------------- sliding window / evaluation
 def patch_gather(volume, locations, patch_size):
     """volume [C,V0,V1,V2], locations int32 [P,3] (i0,j0,k0) -> patches [P,C,*patch_size]"""

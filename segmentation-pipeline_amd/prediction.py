@@ -7,7 +7,7 @@
   is an evaluator concern and forces a sync every iteration).
 * PatchPredict.predict (:124-152): torchio GridSampler / GridAggregator('average')
   become a deterministic tile list + the patch_gather / patch_accumulate kernels;
-  with torch.distributed initialised the tiles are sharded over the ranks and
+  inside `distributed.unit_sharding()` the tiles are sharded over the ranks and
   returned by a single all_gather (distributed.gather_tiles).
 """
 import itertools
@@ -96,25 +96,23 @@ class PatchPredict:
         k = self._ops
         vshape = tuple(volume.shape[1:])
         locs = grid_locations(vshape, self.patch_size, self.patch_overlap)
-        world = torch.distributed.get_world_size() if D.is_distributed() else 1
-        rank = torch.distributed.get_rank() if D.is_distributed() else 0
-        mine = D.shard_indices(len(locs), rank, world)
-        outs = []
-        with torch.no_grad():
-            for s in range(0, len(mine), self.patch_batch_size):
-                idx = mine[s:s + self.patch_batch_size]
-                loc = torch.tensor([locs[i] for i in idx], dtype=torch.int32, device=volume.device)
-                outs.append(model(k.patch_gather(volume, loc, self.patch_size)))
+        with D.shard_scope() as sharded:  # tiles over ranks only inside distributed.unit_sharding(), outermost sharder
+            world = torch.distributed.get_world_size() if sharded else 1
+            rank = torch.distributed.get_rank() if sharded else 0
+            mine = D.shard_indices(len(locs), rank, world)
+            outs = []
+            with torch.no_grad():
+                for s in range(0, len(mine), self.patch_batch_size):
+                    idx = mine[s:s + self.patch_batch_size]
+                    loc = torch.tensor([locs[i] for i in idx], dtype=torch.int32, device=volume.device)
+                    outs.append(model(k.patch_gather(volume, loc, self.patch_size)))
         local = torch.cat(outs, dim=0) if outs else None
-        if local is not None:
-            c_out, dtype = local.shape[1], local.dtype
-            meta = torch.tensor([c_out], device=volume.device)
-        else:
-            meta = torch.tensor([0], device=volume.device)
+        meta = torch.tensor([local.shape[1] if local is not None else 0], device=volume.device)
         if world > 1:  # ranks without tiles learn the channel count (tiny, once per volume)
             torch.distributed.all_reduce(meta, op=torch.distributed.ReduceOp.MAX)
         c_out = int(meta.item())
-        tiles = D.gather_tiles(local, len(locs), (c_out,) + self.patch_size, torch.float32, volume.device)
+        tiles = D.gather_tiles(local, len(locs), (c_out,) + self.patch_size, torch.float32, volume.device,
+                               sharded=world > 1)
         # aggregation in grid order on every rank: identical bits regardless of world size
         accum = torch.zeros((c_out,) + vshape, dtype=torch.float32, device=volume.device)
         count = torch.zeros(vshape, dtype=torch.float32, device=volume.device)

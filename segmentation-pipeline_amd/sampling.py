@@ -70,14 +70,21 @@ class WeightedSampler(UniformSampler):
 
     def sample_locations(self, probability_map: torch.Tensor, n: int, generator=None) -> torch.Tensor:
         shape = probability_map.shape[-3:]
-        cdf = torch.cumsum(self.centre_distribution(probability_map), dim=0)
+        pdf = self.centre_distribution(probability_map)
+        cdf = torch.cumsum(pdf, dim=0)
+        cdf = cdf / cdf[-1]
         u = torch.rand(n, dtype=torch.float64, device=cdf.device, generator=generator)
-        flat = torch.searchsorted(cdf, u, right=True).clamp_max(cdf.numel() - 1)
+        # a draw at / beyond the last cdf value (rounding) falls back to the last centre with non-zero
+        # probability -- never to the zeroed border, whose patch would leave the volume
+        last_valid = torch.nonzero(pdf > 0)[-1, 0]
+        flat = torch.minimum(torch.searchsorted(cdf, u, right=True), last_valid)
         k = flat % shape[2]
         j = (flat // shape[2]) % shape[1]
         i = flat // (shape[1] * shape[2])
         centre = torch.stack([i, j, k], dim=1)
         corner = centre - torch.tensor([p // 2 for p in self.patch_size], device=centre.device)
+        hi = torch.tensor([s - p for s, p in zip(shape, self.patch_size)], device=centre.device)
+        corner = torch.minimum(corner.clamp_min(0), hi)  # the gather kernel does no bounds checks of its own
         return corner.to(torch.int32)
 
     def __call__(self, volume: torch.Tensor, probability_map: torch.Tensor, n: int, generator=None,

@@ -2,12 +2,31 @@
 as a torchio-free harness: same order of operations and the same four TorchTimer phase
 names (utils/torch_timer.py:6-30), so GPU and CPU-reference timings are comparable.
 """
+import math
+import signal
+import threading
 import time
-from typing import Dict, Optional
+from typing import Callable, Dict, Iterable, Optional
 
 import torch
 
 from . import distributed as D
+
+# Cooperative stop flag (segmentation_trainer.py:18-30): the reference installs SIGINT / SIGTERM /
+# SIGUSR2 handlers at import time; here installation is explicit (install_signal_handlers()).
+EXIT = threading.Event()
+
+
+def _clean_exit_handler(signum, frame):
+    EXIT.set()
+    print("Exiting cleanly", flush=True)
+
+
+def install_signal_handlers():
+    signal.signal(signal.SIGINT, _clean_exit_handler)
+    signal.signal(signal.SIGTERM, _clean_exit_handler)
+    if hasattr(signal, "SIGUSR2"):
+        signal.signal(signal.SIGUSR2, _clean_exit_handler)
 
 
 class PhaseTimer:
@@ -61,6 +80,92 @@ def train_step(model, criterion, optimizer, predictor, batch, device, timer: Opt
     if timer:
         timer.stamp("model_backward")
     return loss_dict, batch
+
+
+class TrainLoop:
+    """The iteration loop of SegmentationTrainer.train (segmentation_trainer.py:162-280) around
+    `train_step`, without the torchio / logger plumbing: max_iterations, wall-clock budget with the
+    reference's save buffer (min(10 %, 5 min), :110-113), scoring every `scoring_interval` iterations
+    with best-score bookkeeping and patience (`max_iterations_with_no_improvement`, :250-268), and the
+    cooperative EXIT flag (:270-275).
+
+    Under torch.distributed every rank must leave the loop on the SAME iteration (a rank that stops
+    alone leaves the others blocked in the next gradient all-reduce), so the per-iteration decision is
+    taken on all-reduced values: the stop flags (exit signal, time expired) with MAX and the score
+    with the mean over ranks -- ONE small collective per iteration (distributed.all_reduce_mean_scalars).
+    """
+
+    def __init__(self, scoring_interval: int = 1, scoring_function: Optional[Callable[[Dict], float]] = None,
+                 max_iterations_with_no_improvement: float = math.inf,
+                 save_rate: Optional[int] = None, save_fn: Optional[Callable[[str, int], None]] = None):
+        self.scoring_interval = scoring_interval
+        self.scoring_function = scoring_function
+        self.max_iterations_with_no_improvement = max_iterations_with_no_improvement
+        self.save_rate, self.save_fn = save_rate, save_fn
+        self.iteration = 0
+        self.max_score = -math.inf
+        self.max_score_iteration = 0
+        self.stop_reason = None
+
+    def state_dict(self):   # segmentation_trainer.py:86-96
+        return {"iteration": self.iteration, "max_score": self.max_score, "max_score_iteration": self.max_score_iteration}
+
+    def load_state_dict(self, state):
+        self.iteration, self.max_score = state["iteration"], state["max_score"]
+        self.max_score_iteration = state["max_score_iteration"]
+
+    def _agree(self, stop_flags, score, device):
+        """-> (exit_set, time_expired, mean score) identical on every rank."""
+        vals = torch.tensor([float(stop_flags[0]), float(stop_flags[1]), 0.0 if score is None else float(score)],
+                            dtype=torch.float64, device=device)
+        if D.is_distributed():
+            D.all_reduce_mean_scalars(vals)           # flags: mean > 0 <=> some rank raised it
+        return bool(vals[0] > 0), bool(vals[1] > 0), float(vals[2])
+
+    def run(self, model, criterion, optimizer, predictor, batches: Iterable, device, max_iterations: int,
+            max_training_time: Optional[float] = None, log_fn: Optional[Callable[[Dict], None]] = None,
+            timer: Optional[PhaseTimer] = None):
+        """`batches`: iterator of dicts with stacked "X" / "y" tensors (the collate_subjects output,
+        utils/utils.py:75-85).  `max_training_time` in seconds.  Returns the last loss dict."""
+        if max_training_time is not None:
+            save_buffer = min(int(max_training_time * 0.1), 5 * 60)
+            stop_time = time.time() + max_training_time - save_buffer
+        else:
+            stop_time = math.inf
+        sync_device = device if (D.is_distributed() and torch.distributed.get_backend() == "nccl") else torch.device("cpu")
+        it = iter(batches)
+        loss_dict = None
+        self.stop_reason = "max_iterations"
+        for _ in range(max_iterations):
+            loss_dict, _batch = train_step(model, criterion, optimizer, predictor, next(it), device, timer)
+            log_dict = dict(loss_dict)
+            score = None
+            scoring = self.scoring_function is not None and self.iteration % self.scoring_interval == 0
+            if scoring:
+                score = float(self.scoring_function(log_dict))
+            exit_set, expired, score = self._agree((EXIT.is_set(), time.time() > stop_time), score, sync_device)
+            if self.save_rate and self.save_fn and self.iteration % self.save_rate == 0:
+                self.save_fn("checkpoints/", self.iteration)
+            if scoring:
+                log_dict["model_score"] = score
+                if score > self.max_score:
+                    self.max_score, self.max_score_iteration = score, self.iteration
+                    if self.save_fn:
+                        self.save_fn("best_checkpoints/", self.iteration)
+            if timer is not None:
+                log_dict["timer"] = dict(timer.timestamps)
+            if log_fn:
+                log_fn(log_dict)
+            if self.iteration - self.max_score_iteration > self.max_iterations_with_no_improvement:
+                self.stop_reason = "no_improvement"
+                break
+            if exit_set or expired:
+                self.stop_reason = "exit_signal" if exit_set else "time_expired"
+                break
+            self.iteration += 1
+        if self.save_fn:
+            self.save_fn("checkpoints/", self.iteration)
+        return loss_dict
 
 
 def hard_dice_from_counts(counts: torch.Tensor) -> torch.Tensor:

@@ -71,3 +71,18 @@ def oracle():
 def hip():
     from raw_ops import RawOps
     return RawOps("hip")
+
+
+@pytest.fixture
+def tuning(monkeypatch):
+    """set(**env): override M355_* tuning knobs for one test.  The library caches them at load time, so the
+    environment is re-read now (m355_reload_tuning) and again when the test ends."""
+    from segmentation_pipeline_amd import _lib
+
+    def set_(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        _lib.reload_tuning()
+    yield set_
+    monkeypatch.undo()
+    _lib.reload_tuning()

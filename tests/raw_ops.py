@@ -19,7 +19,7 @@ from segmentation_pipeline_amd import _lib  # noqa: E402
 from segmentation_pipeline_amd._lib import ConvDesc, NormDesc  # noqa: E402
 
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libm355_oracle.so")
+ORACLE_LIB = os.environ.get("M355_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libm355_oracle.so")  # override: the ASan build (oracle/Makefile)
 
 
 def build_oracle():
@@ -262,6 +262,20 @@ class RawOps:
         dw = torch.empty_like(w)
         self._chk(self.fn("blur_weight_bwd")(_p(dwexp), _p(w), _p(scale), _p(ms), _p(dw), A, B, int(standardize),
                                              int(transposed), self._stream()), "blur_weight_bwd")
+        return dw
+
+    def weight_standardize_fwd(self, w):
+        w = self.to(w)
+        A, n = w.shape[0], w[0].numel()
+        wn, ms = torch.empty_like(w), self.empty(A, 2)
+        self._chk(self.fn("weight_standardize_fwd")(_p(w), _p(wn), _p(ms), A, n, self._stream()), "weight_standardize_fwd")
+        return wn, ms
+
+    def weight_standardize_bwd(self, dwn, w, ms):
+        dwn, w, ms = map(self.to, (dwn, w, ms))
+        dw = torch.empty_like(w)
+        self._chk(self.fn("weight_standardize_bwd")(_p(dwn), _p(w), _p(ms), _p(dw), w.shape[0], w[0].numel(),
+                                                    self._stream()), "weight_standardize_bwd")
         return dw
 
     def softmax_fwd(self, x, inner=1, diag_bias=0.0):

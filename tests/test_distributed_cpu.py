@@ -140,7 +140,17 @@ def _volume():
 def _predict(rank=0, world=1):
     torch.set_num_threads(1)  # torch-CPU softmax bits depend on the thread split; the double must be deterministic
     pp = PatchPredict(patch_batch_size=2, patch_size=6, patch_overlap=2, ops_backend=CpuPatchOps)
-    return pp.predict_volume(TileModel(), _volume())
+    with D.unit_sharding():
+        return pp.predict_volume(TileModel(), _volume())
+
+
+def _predict_not_opted_in(rank, world):
+    """Without unit_sharding() a predictor called under an initialised process group works on
+    rank-local data (validation inside a DDP job): no collective, every tile computed locally."""
+    torch.set_num_threads(1)
+    pp = PatchPredict(patch_batch_size=2, patch_size=6, patch_overlap=2, ops_backend=CpuPatchOps)
+    vol = _volume() + float(rank)       # different data per rank
+    return pp.predict_volume(TileModel(), vol), vol
 
 
 def test_sharded_sliding_window_is_bit_identical_to_unsharded():
@@ -156,6 +166,13 @@ def test_sharded_sliding_window_is_bit_identical_to_unsharded():
     with torch.no_grad():
         patches = TileModel()(CpuPatchOps.patch_gather(vol, torch.tensor(locs), (6, 6, 6)))
     torch.testing.assert_close(single, R.aggregate_average(patches, locs, vol.shape[1:]), rtol=0, atol=1e-6)
+
+
+def test_predictor_without_opt_in_is_rank_local():
+    for out, vol in spawn(_predict_not_opted_in):
+        pp = PatchPredict(patch_batch_size=2, patch_size=6, patch_overlap=2, ops_backend=CpuPatchOps)
+        torch.set_num_threads(1)
+        assert torch.equal(out, pp.predict_volume(TileModel(), vol))
 
 
 def _gather_worker(rank, world):
@@ -199,14 +216,28 @@ class _Member(nn.Module):
         return torch.softmax(h, dim=1)
 
 
+class _Member2(_Member):
+    def forward(self, x):
+        return super().forward(x * 0.5 + 0.25)
+
+
 def _ensemble_worker(rank=0, world=1):
-    from segmentation_pipeline_amd.models import EnsembleFlips, EnsembleOrientations
+    from segmentation_pipeline_amd.models import EnsembleFlips, EnsembleModels, EnsembleOrientations
     torch.set_num_threads(1)
     x = torch.randn((1, 2, 4, 4, 4), generator=torch.Generator().manual_seed(21))
-    a = EnsembleFlips(_Member(), "mean")(x)
-    b = EnsembleFlips(_Member(), "majority", spatial_dims=(3, 4))(x)
-    c = EnsembleOrientations(_Member(), "mean")(x)
-    return a, b, c
+    with D.unit_sharding():
+        a = EnsembleFlips(_Member(), "mean")(x)
+        b = EnsembleFlips(_Member(), "majority", spatial_dims=(3, 4))(x)
+        c = EnsembleOrientations(_Member(), "mean")(x)
+        # ensemble of ensembles (research/msseg2/competition/ms-inference.py:115-125): only the outer one shards
+        d = EnsembleModels([EnsembleFlips(_Member(), "mean"), EnsembleFlips(_Member2(), "mean"),
+                            EnsembleFlips(_Member(), "mean", spatial_dims=(4,))], "mean")(x)
+        # fewer members than ranks: rank 1 owns nothing and still takes part in the gather
+        e = EnsembleModels([_Member2()], "mean")(x)
+        # sliding window around an ensemble: tiles are sharded, the inner ensemble runs locally on every tile
+        pp = PatchPredict(patch_batch_size=2, patch_size=3, patch_overlap=1, ops_backend=CpuPatchOps)
+        f = pp.predict_volume(EnsembleFlips(_Member(), "mean", spatial_dims=(3, 4)), x[0])
+    return a, b, c, d, e, f
 
 
 def test_sharded_ensembles_equal_single_process():
@@ -216,6 +247,104 @@ def test_sharded_ensembles_equal_single_process():
     for got in spawn(_ensemble_worker):
         for g, s in zip(got, single):
             assert torch.equal(g, s)
+
+
+def _loop_worker(rank, world):
+    from segmentation_pipeline_amd import trainer as T
+    from segmentation_pipeline_amd.prediction import StandardPredict
+    model = Net()
+    ddp = D.PatchParallel(model, bucket_bytes=4096)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    crit = lambda p, y: R.hybrid_logistic_dice_loss(p, y)
+    x, y = _data(rank)
+    seen = []
+
+    def batches():
+        while True:
+            if rank == 1 and len(seen) == 2:
+                T.EXIT.set()        # only rank 1 receives the signal, during its third iteration
+            yield {"X": x, "y": y}
+
+    T.EXIT.clear()
+    loop = T.TrainLoop(scoring_interval=1, scoring_function=lambda d: -float(d["loss"]))
+    loop.run(ddp, crit, opt, StandardPredict(), batches(), torch.device("cpu"), max_iterations=10,
+             log_fn=lambda d: seen.append(d["model_score"]))
+    T.EXIT.clear()
+    return loop.iteration, loop.stop_reason, seen, {k: v.clone() for k, v in model.state_dict().items()}
+
+
+def test_train_loop_stop_flag_is_agreed_across_ranks():
+    """segmentation_trainer.py:270-275 under DDP: the exit flag raised on ONE rank stops EVERY rank on the
+    same iteration (otherwise the others would block in the next all-reduce); scores are rank means."""
+    (it0, why0, s0, sd0), (it1, why1, s1, sd1) = spawn(_loop_worker)
+    assert it0 == it1 == 2 and why0 == why1 == "exit_signal"
+    assert s0 == s1 and len(s0) == 3
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k])
+
+
+def test_train_loop_patience_and_time_budget_single_process():
+    from segmentation_pipeline_amd import trainer as T
+    from segmentation_pipeline_amd.prediction import StandardPredict
+    torch.manual_seed(0)
+    model = Net()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    x, y = _data(0)
+    scores = iter([1.0, 0.5, 0.4, 0.3, 0.2, 0.1])
+    saves = []
+    loop = T.TrainLoop(scoring_interval=1, scoring_function=lambda d: next(scores), max_iterations_with_no_improvement=2,
+                       save_rate=2, save_fn=lambda d, i: saves.append((d, i)))
+    loop.run(model, lambda p, t: R.hybrid_logistic_dice_loss(p, t), opt, StandardPredict(),
+             iter(lambda: {"X": x, "y": y}, None), torch.device("cpu"), max_iterations=6)
+    assert loop.stop_reason == "no_improvement" and loop.iteration == 3 and loop.max_score == 1.0
+    assert ("best_checkpoints/", 0) in saves and ("checkpoints/", 2) in saves and saves[-1] == ("checkpoints/", 3)
+    state = loop.state_dict()
+    loop2 = T.TrainLoop()
+    loop2.load_state_dict(state)
+    assert loop2.iteration == 3
+    # wall-clock budget: the save buffer min(10 %, 5 min) is subtracted (segmentation_trainer.py:110-113)
+    loop3 = T.TrainLoop()
+    loop3.run(model, lambda p, t: R.hybrid_logistic_dice_loss(p, t), opt, StandardPredict(),
+              iter(lambda: {"X": x, "y": y}, None), torch.device("cpu"), max_iterations=1000, max_training_time=0.0)
+    assert loop3.stop_reason == "time_expired" and loop3.iteration == 0
+
+
+class BNNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c = nn.Conv3d(2, 4, 3, padding=1)
+        self.n = nn.BatchNorm3d(4)
+
+    def forward(self, x):
+        return torch.softmax(self.n(self.c(x)), dim=1)
+
+
+def _bn_worker(rank, world):
+    model = BNNet()
+    ddp = D.PatchParallel(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    x = torch.randn((2, 2, 4, 4, 4), generator=torch.Generator().manual_seed(100 + rank)) * (1.0 + rank)
+    stats = []
+    for _ in range(2):
+        model.train()
+        ddp.zero_grad()
+        ddp(x).square().mean().backward()
+        ddp.finish_gradient_sync()
+        opt.step()
+        model.eval()
+    with torch.no_grad():
+        probe = model(torch.ones(1, 2, 4, 4, 4))
+    return {k: v.clone() for k, v in model.state_dict().items()}, probe
+
+
+def test_batchnorm_buffers_agree_across_ranks_after_steps():
+    """BatchNorm statistics come from per-rank batches (reference semantics); PatchParallel averages the
+    running statistics after every step, so state_dict() and eval-mode predictions agree on all ranks."""
+    (sd0, p0), (sd1, p1) = spawn(_bn_worker)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert torch.equal(p0, p1)
+    assert sd0["n.num_batches_tracked"].item() == 2 and not torch.equal(sd0["n.running_mean"], torch.zeros(4))
 
 
 def test_samplers_index_arithmetic_and_distribution():
@@ -249,3 +378,12 @@ def test_samplers_index_arithmetic_and_distribution():
     assert labels.shape == (4000, 1, 4, 3, 2) and labels[:, 0, 2, 1, 1].max() == 100.0
     with pytest.raises(RuntimeError):
         ws.centre_distribution(torch.zeros(1, 10, 9, 8))
+    # a draw beyond the last cdf value (float rounding) must land on a VALID centre, never on the zeroed border
+    import segmentation_pipeline_amd.sampling as S
+    orig = S.torch.rand
+    S.torch.rand = lambda n, **k: torch.ones(n, dtype=k.get("dtype", torch.float32))
+    try:
+        locs = ws.sample_locations(pm, 3)
+    finally:
+        S.torch.rand = orig
+    assert (locs >= 0).all() and (locs[:, 0] <= 6).all() and (locs[:, 1] <= 6).all() and (locs[:, 2] <= 6).all()

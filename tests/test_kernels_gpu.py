@@ -73,12 +73,11 @@ def test_conv3d_generic_direct(hip, oracle, case):
 
 @pytest.mark.parametrize("env", [{"M355_CONV_SLOTS": "7"}, {"M355_CONV_SLOTS": "5", "M355_CONV_KSPLIT": "2"},
                                  {"M355_CONV_SLOTS": "3", "M355_CONV_NTW": "8"}])
-def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, monkeypatch):
+def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, tuning):
     """The persistent forward kernel (workgroups walk several output tiles, prefetching across the
     tile boundary) on ragged volumes, N = 2, residual add, split-K and the one-per-CU NTW = 8 tile:
     a tiny residency forces every workgroup through many items."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    tuning(**env)
     for (N, ci, co, D, H, W) in [(2, 12, 40, 9, 10, 36), (1, 5, 33, 6, 21, 16), (1, 8, 8, 12, 9, 8)]:
         x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
         add = rnd(N, co, D, H, W, seed=4)
@@ -89,12 +88,10 @@ def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}])
-def test_conv3d_fused_statistics(hip, oracle, env, monkeypatch):
+def test_conv3d_fused_statistics(hip, oracle, env, tuning):
     """m355_conv3d_fwd_stats + m355_norm_stats_from_partials == statistics of the conv output (GroupNorm and
     BatchNorm geometry, ragged volumes with overhanging tiles, N = 2, one-shot and persistent kernels)."""
-    monkeypatch.setenv("M355_CONV_KSPLIT", "1")  # split-K plans (what these small volumes would get) have no fusion
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    tuning(M355_CONV_KSPLIT=1, **env)  # split-K plans (what these small volumes would get) have no fusion
     for (N, ci, co, D, H, W, groups) in [(2, 8, 16, 9, 10, 36, 4), (1, 5, 40, 6, 21, 16, 8), (2, 8, 24, 12, 9, 8, 0),
                                         (1, 16, 32, 16, 16, 32, 8)]:
         x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
@@ -229,6 +226,15 @@ def test_blur_weight_transform(hip, oracle, standardize, transposed):
         g = rnd(*eo.shape, seed=2)
         close(hip.blur_weight_bwd(g, w, scale, mso, standardize, transposed),
               oracle.blur_weight_bwd(g, w, scale, mso, standardize, transposed), 2e-5, 1e-6, "dw")
+
+
+def test_weight_standardize_fwd_bwd(hip, oracle):
+    w, g = rnd(40, 24, 3, 3, 3, seed=1), rnd(40, 24, 3, 3, 3, seed=2)
+    wn_h, ms_h = hip.weight_standardize_fwd(w)
+    wn_o, ms_o = oracle.weight_standardize_fwd(w)
+    close(wn_h, wn_o, 1e-5, 1e-5, "standardize fwd")
+    close(ms_h, ms_o, 1e-5, 1e-6, "mean/std")
+    close(hip.weight_standardize_bwd(g, w, ms_o), oracle.weight_standardize_bwd(g, w, ms_o), 1e-4, 1e-5, "standardize bwd")
 
 
 def test_blur_convs_mfma_path_matches_direct_kernels():

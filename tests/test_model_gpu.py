@@ -13,8 +13,9 @@ from torch import nn
 
 from segmentation_pipeline_amd import ops
 from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
-from segmentation_pipeline_amd.models import (BlurConv3d, BlurConvTranspose3d, EnsembleFlips, ModularUNet,
-                                              NestedResUNet, StochasticMatrix, WSConv3d)
+from segmentation_pipeline_amd.models import (BlurConv3d, BlurConvTranspose3d, EnsembleFlips, EnsembleModels,
+                                              EnsembleOrientations, ModularUNet, NestedResUNet, StochasticMatrix,
+                                              WSConv3d)
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +198,48 @@ def test_ensemble_flips_golden(golden):
         assert maxerr(EnsembleFlips(model, "mean")(x), g["flips.mean"]) <= PROB_TOL
         maj = EnsembleFlips(model, "majority", spatial_dims=(3, 4))(x)
     assert torch.equal(maj.cpu(), g.t("flips.majority34"))
+
+
+def _ens_members(g):
+    members = []
+    for i in (0, 1):
+        m = ModularUNet(2, 3, [8, 16], 2, block_params=dict(GN8), **CONVT)
+        m.load_state_dict(g.state_dict(f"m{i}.sd."))
+        members.append(m.cuda().eval())
+    return members
+
+
+def test_ensemble_orientations_models_and_nested_golden(golden):
+    """models/ensemble.py:38-103 on two tiny members: 48 orientations, model ensembles, and the ensemble of
+    flip-ensembles the reference's production inference builds (ms-inference.py:115-125); 'mean' within the
+    fp32 tolerance, 'majority' one-hot masks bit-exact."""
+    g = golden("ensembles_ws.npz")
+    members = _ens_members(g)
+    x = g.t("x").cuda()
+    with torch.no_grad():
+        assert maxerr(EnsembleOrientations(members[0], "mean")(x), g["orient.mean"]) <= PROB_TOL
+        assert torch.equal(EnsembleOrientations(members[0], "majority")(x).cpu(), g.t("orient.majority"))
+        assert maxerr(EnsembleModels(members, "mean")(x), g["models.mean"]) <= PROB_TOL
+        assert torch.equal(EnsembleModels(members, "majority")(x).cpu(), g.t("models.majority"))
+        assert torch.equal(EnsembleFlips(members[1], "majority")(x).cpu(), g.t("flips.majority"))
+        nested = EnsembleModels([EnsembleFlips(m, "mean", spatial_dims=(3, 4)) for m in members], "mean")
+        assert maxerr(nested(x), g["nested.mean"]) <= PROB_TOL
+
+
+def test_wsconv3d_forward_and_gradients_golden(golden):
+    """WSConv3d (components.py:76-88): standardisation kernel + conv, forward and both gradients; the bias
+    parameter is unused in the reference (grad None)."""
+    g = golden("ensembles_ws.npz")
+    ws = WSConv3d(4, 6, 3, padding=1)
+    ws.load_state_dict(g.state_dict("ws.sd."))
+    ws = ws.cuda()
+    x = g.t("ws.x").cuda().requires_grad_()
+    y = ws(x)
+    assert maxerr(y, g["ws.y"]) <= 1e-4
+    (y * y).sum().backward()
+    grad_close(x.grad, g["ws.dx"], "ws.dx")
+    grad_close(ws.weight.grad, g["ws.dw"], "ws.dw", rtol=2e-3)
+    assert ws.bias.grad is None
 
 
 def test_batch_stride_concat_path_n2_grads_flow(golden):

@@ -136,11 +136,40 @@ def _s2d_torch(x):
         N, Cc * 8, D // 2, H // 2, W // 2)
 
 
+
+# ---- torch restatement of the space-to-depth form of the Blur convolutions (test-side only) ----
+# A stride-2 conv with a 4x4x4 kernel and padding 1 is a stride-1 3x3x3 conv over the space-to-depth
+# input: along one axis, input index 2Z + d - 1 has parity (d-1)&1 and half-resolution offset
+# floor((d-1)/2) in {-1, 0, 0, +1} for d = 0..3, i.e. tap t = offset + 1 of a 3-tap kernel.
+_S2D_TAP = {(0, 1): 1, (0, 2): 3, (1, 0): 0, (1, 1): 2}      # (parity, tap) -> d   (strided conv)
+_D2S_TAP = {(0, 0): 3, (0, 1): 1, (1, 1): 2, (1, 2): 0}      # (parity, tap) -> d   (transposed conv)
+
+
+def _expand_4x4x4(w4, table):
+    """[A, B, 4, 4, 4] -> [A, B, 8, 27] sparse 3x3x3 filters per parity (differentiable gather)."""
+    idx = torch.zeros(8, 27, dtype=torch.long)
+    mask = torch.zeros(8, 27, dtype=w4.dtype)
+    for p in range(8):
+        par = (p >> 2, (p >> 1) & 1, p & 1)
+        for t in range(27):
+            tap = (t // 9, (t // 3) % 3, t % 3)
+            d = [table.get((par[a], tap[a])) for a in range(3)]
+            if None not in d:
+                idx[p, t] = (d[0] * 4 + d[1]) * 4 + d[2]
+                mask[p, t] = 1.0
+    flat = w4.reshape(w4.shape[0], w4.shape[1], 64)
+    return flat[:, :, idx.reshape(-1)].reshape(w4.shape[0], w4.shape[1], 8, 27) * mask
+
+
+def _standardize(w):  # models/components.py:83-84 (torch.std: unbiased)
+    w = w - w.mean(dim=(1, 2, 3, 4), keepdim=True)
+    return w / (w.std(dim=(1, 2, 3, 4), keepdim=True) + 1e-5)
+
+
 def test_c_space_to_depth_and_blur_identities(oracle):
     """s2d/d2s are exact permutations, and the reference's strided Blur convolutions
     (models/components.py:119,152: 4x4x4 effective filter, stride 2, padding 1) equal a stride-1
     3x3x3 convolution over the s2d input / followed by d2s."""
-    from segmentation_pipeline_amd.models.components import _D2S_TAP, _S2D_TAP, _expand_4x4x4
     x = rnd(2, 3, 4, 6, 8, seed=1)
     y = oracle.space_to_depth(x)
     assert torch.equal(y, _s2d_torch(x))
@@ -161,8 +190,7 @@ def test_c_blur_weight_transform_matches_torch_composition(oracle, standardize, 
     """m355o_blur_weight_{fwd,bwd} == standardise -> box blur -> gather written with torch ops (the
     composition the goldens generated from the reference's BlurConv3d / BlurConvTranspose3d pin,
     models/components.py:112-119,145-152), forward and autograd backward."""
-    from segmentation_pipeline_amd.models.components import (_D2S_TAP, _S2D_TAP, _box_blur, _expand_4x4x4,
-                                                             _standardize)
+    from segmentation_pipeline_amd.models.components import _box_blur
     A, B = 5, 6
     w = (rnd(A, B, 3, 3, 3, seed=1) * 0.3 + 0.05).double().requires_grad_()
     kernel = torch.full((B, 1, 2, 2, 2), 1.0 / 64 if not transposed else 1.0 / B, dtype=torch.double)
@@ -179,6 +207,18 @@ def test_c_blur_weight_transform_matches_torch_composition(oracle, standardize, 
     ref.backward(g.double())
     dw = oracle.blur_weight_bwd(g, w.detach().float(), scale, ms, standardize, transposed)
     close(dw, w.grad.float(), 2e-5, 1e-6)
+
+
+def test_c_weight_standardize_matches_torch_autograd(oracle):
+    """WSConv3d (models/components.py:81-88): (w - mean) / (std + 1e-5), unbiased std, and its gradient."""
+    w = torch.randn((6, 4, 3, 3, 3), generator=torch.Generator().manual_seed(3), dtype=torch.float64).requires_grad_()
+    wn_ref = (w - w.mean(dim=(1, 2, 3, 4), keepdim=True)) / (w.std(dim=(1, 2, 3, 4), keepdim=True) + 1e-5)
+    g = torch.randn(w.shape, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    (wn_ref * g).sum().backward()
+    wn, ms = oracle.weight_standardize_fwd(w.detach().float())
+    torch.testing.assert_close(wn.double(), wn_ref.detach(), rtol=1e-5, atol=1e-5)
+    dw = oracle.weight_standardize_bwd(g.float(), w.detach().float(), ms)
+    torch.testing.assert_close(dw.double(), w.grad, rtol=1e-4, atol=1e-5)
 
 
 def test_c_operand_rounding_matches_torch_casts(oracle):

@@ -11,7 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from raw_ops import RawOps  # noqa: E402
+from raw_ops import RawOps
+from segmentation_pipeline_amd._lib import reload_tuning as _reload  # the library caches the M355_* knobs  # noqa: E402
 
 
 def rnd(*shape, seed=0):
@@ -72,6 +73,7 @@ def main():
         for k in ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_BWW_GEN"):
             os.environ.pop(k, None)
         os.environ.update(env)
+        _reload()
         x, w, b = rnd(N, ci, D, H, W, seed=3 * i), rnd(co, ci, 3, 3, 3, seed=3 * i + 1) * 0.2, rnd(co, seed=3 * i + 2)
         add = rnd(N, co, D, H, W, seed=7 * i) if rng.random() < 0.3 else None
         dy = rnd(N, co, D, H, W, seed=5 * i)

@@ -94,10 +94,50 @@ def run_model(model, crit, x, y, tag, out):
         out[f"{tag}.probs_eval"] = model(x).numpy()
 
 
-def main():
+def gen_ensembles_ws(M, C):
+    """8. (round 2) WSConv3d gradients; EnsembleOrientations / EnsembleModels / nested ensembles
+    (models/ensemble.py:38-103) on two tiny GN/ConvT members -> ensembles_ws.npz"""
+    out = {}
+    g = torch.Generator().manual_seed(23)
+    torch.manual_seed(2)
+    ws = M.WSConv3d(4, 6, 3, padding=1)
+    xin = torch.randn((2, 4, 6, 5, 8), generator=g, requires_grad=True)
+    y = ws(xin)
+    (y * y).sum().backward()
+    out["ws.x"], out["ws.y"], out["ws.dx"] = xin.detach().numpy(), y.detach().numpy(), xin.grad.numpy()
+    out["ws.dw"] = ws.weight.grad.numpy()
+    assert ws.bias.grad is None
+    out.update(sd_np(ws, "ws.sd."))
+    members = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = M.ModularUNet(2, 3, [8, 16], 2, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                          upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+        m.eval()
+        members.append(m)
+        out.update(sd_np(m, f"m{seed}.sd."))
+    xin = torch.randn((2, 2, 8, 8, 8), generator=g)      # cubic: EnsembleOrientations permutes the axes
+    out["x"] = xin.numpy()
+    with torch.no_grad():
+        out["orient.mean"] = M.EnsembleOrientations(members[0], "mean")(xin).numpy()
+        out["orient.majority"] = M.EnsembleOrientations(members[0], "majority")(xin).numpy().astype(np.int64)
+        out["models.mean"] = M.EnsembleModels(members, "mean")(xin).numpy()
+        out["models.majority"] = M.EnsembleModels(members, "majority")(xin).numpy().astype(np.int64)
+        out["flips.majority"] = M.EnsembleFlips(members[1], "majority")(xin).numpy().astype(np.int64)
+        # ensemble of ensembles, the reference's production inference (research/msseg2/competition/ms-inference.py:115-125)
+        nested = M.EnsembleModels([M.EnsembleFlips(m, "mean", spatial_dims=(3, 4)) for m in members], "mean")
+        out["nested.mean"] = nested(xin).numpy()
+    np.savez_compressed(os.path.join(OUT, "ensembles_ws.npz"), **out)
+
+
+def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     M, C = load_reference()
     torch.set_num_threads(8)
+    if only:
+        for name in only:
+            {"ensembles_ws": gen_ensembles_ws}[name](M, C)
+        return
     meta = {"torch": torch.__version__}
 
     # 1. default config: BN / AvgPool / trilinear (cfg1 family)
@@ -271,6 +311,7 @@ def main():
     out["grad_norms"] = np.asarray([p_.grad.double().norm().item() for p_ in model.parameters()])
     out["grad_heads"] = np.stack([np.resize(p_.grad.flatten()[:8].numpy(), 8) for p_ in model.parameters()])
     np.savez_compressed(os.path.join(OUT, "cfg2_arch_32cube.npz"), **out)
+    gen_ensembles_ws(M, C)
 
     with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
         f.write("Generated by tools/gen_golden.py from the reference modules at /root/reference\n")
@@ -282,4 +323,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]))     # `python tools/gen_golden.py ensembles_ws` regenerates only that file

@@ -9,7 +9,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from raw_ops import RawOps  # noqa: E402
+from raw_ops import RawOps
+from segmentation_pipeline_amd._lib import reload_tuning as _reload  # the library caches the M355_* knobs  # noqa: E402
 from conv_bench import CFG2, timeit  # noqa: E402
 
 
@@ -20,12 +21,15 @@ def sweep_bww(hip, layers):
         dy = torch.randn(1, co, sp, sp, sp, device="cuda")
         flops = 2.0 * 27 * ci * co * sp ** 3
         os.environ.pop("M355_BWW_NSPLIT", None)
+        _reload()
         base = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False), 5)
         res = []
         for ns in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 21, 24, 32, 42, 48, 64, 85, 96, 128, 170, 192, 256, 384, 512):
             os.environ["M355_BWW_NSPLIT"] = str(ns)
+            _reload()
             res.append((timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False), 5), ns))
         os.environ.pop("M355_BWW_NSPLIT", None)
+        _reload()
         res.sort()
         best = " ".join(f"{n}:{t * 1e3:.0f}" for t, n in res[:5])
         print(f"{name:6s} bww Cin={ci:4d} Cout={co:4d} S={sp:3d} model {base * 1e3:6.0f} us ({flops / base / 1e9:5.1f} TF) "
@@ -47,6 +51,7 @@ def main():
             flops = 2.0 * 27 * kin * mout * sp ** 3
             for k in ("M355_CONV_NTW", "M355_CONV_KSPLIT"):
                 os.environ.pop(k, None)
+                _reload()
             base = timeit(lambda: hip.conv3d_fwd(x, w), 5)
             res = []
             for ntw in (8, 4, 2, 1):
@@ -54,6 +59,7 @@ def main():
                     if ks > kin // 4:
                         continue
                     os.environ["M355_CONV_NTW"], os.environ["M355_CONV_KSPLIT"] = str(ntw), str(ks)
+                    _reload()
                     try:
                         res.append((timeit(lambda: hip.conv3d_fwd(x, w), 5), ntw, ks))
                     except RuntimeError:

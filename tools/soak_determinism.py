@@ -10,7 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from raw_ops import RawOps  # noqa: E402
+from raw_ops import RawOps
+from segmentation_pipeline_amd._lib import reload_tuning as _reload  # the library caches the M355_* knobs  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 hip = RawOps("hip")
@@ -25,6 +26,7 @@ for N, ci, co, D, H, W, env in CASES:
     for k in ("M355_CONV_SLOTS", "M355_CONV_KSPLIT"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    _reload()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, ci, D, H, W, generator=g).cuda()
     w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).cuda()
