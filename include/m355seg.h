@@ -42,14 +42,20 @@ enum {
 
 enum { M355_F32 = 0 };
 
-/* arithmetic of the 3x3x3 convolutions (tensors in HBM are fp32 either way):
+/* arithmetic of the 3x3x3 convolutions:
  *   M355_COMPUTE_F32  exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (default)
- *   M355_COMPUTE_BF16 operands rounded to bf16 (round-to-nearest-even) when they are staged,
- *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE cfg3).
+ *   M355_COMPUTE_BF16 operands rounded to bf16 (round-to-nearest-even), v_mfma_f32_32x32x16_bf16 with
+ *                     fp32 accumulation (BASELINE cfg3).
  *   M355_COMPUTE_F16  the same with IEEE fp16 operands, v_mfma_f32_32x32x16_f16 (BASELINE cfg5:
  *                     "mixed fp16 with MFMA channel-GEMM path"); values beyond +-65504 become inf.
  * Applies to conv3d fwd, bwd_data and (when W % 32 == 0 and both channel counts > 4) bwd_weight;
- * every other case of the weight gradient runs in exact fp32. */
+ * every other case of the weight gradient runs in exact fp32.
+ * In the 16-bit modes the convolution kernels read their input in the "c8" layout
+ *     x16[n][cb][voxel][8]   cb = channel block of 8 (zero-padded past C), 16-bit elements,
+ * i.e. the 8 channels of a voxel are one aligned 16-byte item = one MFMA operand fragment (h16.hpp).
+ * The *_h16 entry points take such tensors directly (the normalisation / pooling passes of the model
+ * path write them, m355_norm_act_fwd_h16 ...); the plain entry points accept fp32 NCDHW and convert
+ * into their workspace first. */
 enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1, M355_COMPUTE_F16 = 2 };
 
 /* activation fused into the normalise pass (components.py:26,54-55) */
@@ -92,17 +98,36 @@ int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
  *   stat_partials[((n * P + p) * Cout + o) * 2 + {0,1}],   P = m355_conv3d_stats_slots(desc)
  * (every slot of every channel is written; slots of waves that lie outside the volume hold zeros).
  * m355_norm_stats_from_partials() turns them into mean / rstd without reading y again.
- * P == 0 means this descriptor has no fused statistics (not 3x3x3 s1 p1, Cout <= 4, bf16 operand
- * mode, or a split-K plan): call m355_conv3d_fwd + m355_norm_stats instead. */
+ * P == 0 means this descriptor has no fused statistics (not 3x3x3 s1 p1, the fp32 Cout <= 4 kernel, or a
+ * split-K plan): call m355_conv3d_fwd + m355_norm_stats instead. */
 int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d);
 int m355_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, const float* w,
                           const float* bias, const float* add, float* y, float* stat_partials,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- c8 tensors (16-bit compute modes) ----
+ * bytes of a dense c8 tensor; conversion fp32 NCDHW <-> c8 (round-to-nearest-even; batch strides in
+ * ELEMENTS of the respective tensor, 0 = dense). */
+size_t m355_act16_bytes(int32_t N, int32_t C, int64_t S);
+int m355_act16_pack(const float* x, void* x16, int32_t N, int32_t C, int64_t S, int64_t x_batch_stride,
+                    int64_t x16_batch_stride, int32_t compute, void* stream);
+int m355_act16_unpack(const void* x16, float* x, int32_t N, int32_t C, int64_t S, int64_t x16_batch_stride,
+                      int64_t x_batch_stride, int32_t compute, void* stream);
+/* conv3d forward / data gradient (3x3x3 s1 p1, desc->compute = BF16 | F16) on a c8 input: x16 holds
+ * desc->Cin channels (fwd), dy16 desc->Cout channels (bwd_data); outputs are fp32 NCDHW exactly as in
+ * m355_conv3d_fwd(_stats) / m355_conv3d_bwd_data (stat_partials may be NULL).  Workspace:
+ * m355_conv3d_h16_workspace(desc, which) bytes, which = 0 forward, 1 data gradient. */
+size_t m355_conv3d_h16_workspace(const m355_conv3d_desc* d, int32_t which);
+int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const float* w,
+                        const float* bias, const float* add, float* y, float* stat_partials, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride, const float* w,
+                             float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
  * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA
  * implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel (workgroups walk
- * several tiles), 2 z-Toeplitz small-Cout kernel; out[1] = voxel groups per wave (NTW), out[2] = lanes
+ * several tiles), 2 z-Toeplitz small-Cout kernel, 4 the 16-bit operand kernel (persistent); out[1] = voxel groups per wave (NTW), out[2] = lanes
  * along x per group (GX), out[3] = split-K factor.  Pure host function. */
 int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4);
 

@@ -13,19 +13,9 @@
 //   from an LDS halo tile with compile-time tap offsets), K = 27 * Cin.
 // The MFMA's k-pair (lanes 0-31 / 32-63) is (channel c, channel c+1) at the same
 // tap, so both halves use one immediate offset.
-#include "common.hpp"
+#include "conv3d_common.hpp"
 
 namespace m355 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Opaque copy: stops LICM from hoisting per-element address decode out of a loop (which
-// would keep hundreds of loop-invariant registers alive and spill).
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 
 // ---------------------------------------------------------------- weight pack
 // fwd:      wp[(c*27 + tap)*cout_pad + o]          = w[(o*Cin + c)*27 + tap]
@@ -54,108 +44,6 @@ __global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ 
 }
 
 // ------------------------------------------------------------ MFMA fwd kernel
-template <int NTW, int GX>
-struct FwdTile {
-  static constexpr int GY = 32 / GX;
-  static constexpr int TZ = 4;  // one z slice per wave
-  static constexpr int TY = NTW * GY;
-  static constexpr int TX = GX;
-  static constexpr int RS = TX + 2;
-  static constexpr int PS = (TY + 2) * RS;
-  static constexpr int CS = (TZ + 2) * PS;
-  static constexpr int CC = 4;  // input channels per LDS chunk (even: MFMA k-pair)
-  static constexpr int NROWS = CC * (TZ + 2) * (TY + 2);
-};
-
-// Output tile of one wave: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// The bias / residual values of all 16 rows are loaded as one batch (one wait) and the row offsets
-// k*DHW are uniform, so the 16*NTW stores go out back to back.  (Written the obvious way --
-// `if (o < Cout) { v = acc; if (bias) v += bias[o]; if (add) v += add[idx]; y[idx] = v; }` per
-// element -- hipcc emits a branch, a load and a vmcnt(0) per element: ~10 us per tile with the
-// matrix core idle.)
-template <int NTW, int GY>
-__device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float* __restrict__ dst,
-                                                const float* __restrict__ addp, const float* __restrict__ bias,
-                                                int o0, int Cout, int z, int y0, int xg, int ly, int half,
-                                                int D, int H, int W, bool lane_ok, float* __restrict__ stat) {
-  // lane_ok: this lane's (z, x) column lies inside the volume.  Every lane stays active to the end
-  // (the statistics below are reduced with cross-lane shuffles).
-  // stat (may be null): (sum, sum of squares) of the values this WAVE stores, per output channel ->
-  // stat[o*2 + {0,1}]; the normalisation that follows the conv sums these partials instead of
-  // reading y again (m355_conv3d_fwd_stats / m355_norm_stats_from_partials).
-  const int64_t HW = (int64_t)H * W, DHW = HW * D;
-  const int ob = o0 + 4 * half;  // this lane's first output channel; row r is channel ob + (r&3) + 8*(r>>2)
-  float bb[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bb[r] = 0.f;
-  if (bias) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bb[r] = bias[min(ob + (r & 3) + 8 * (r >> 2), Cout - 1)];
-  }
-  float s1[16], s2[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
-#pragma unroll
-  for (int g = 0; g < NTW; ++g) {
-    const int yg = y0 + g * GY + ly;
-    const bool ok = lane_ok && yg < H;
-    const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
-    if (addp) {
-      float aa[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = (r & 3) + 8 * (r >> 2);
-        aa[r] = addp[(ok && ob + k < Cout) ? base + (int64_t)k * DHW : 0];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] += aa[r];
-    }
-    if (stat) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float t = ok ? v[r] : 0.f;
-        s1[r] += t;
-        s2[r] = fmaf(t, t, s2[r]);
-      }
-    }
-    if (ok) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = (r & 3) + 8 * (r >> 2);
-        if (ob + k < Cout) dst[base + (int64_t)k * DHW] = v[r];
-      }
-    }
-  }
-  if (stat) {
-    // reduce-scatter over the 32 lanes of each half (xor < 32 stays inside the half): 32 values
-    // (16 rows x {sum, sumsq}) are summed over 32 lanes with 16+8+4+2+1 shuffles; lane l ends up
-    // holding value index l & 31 = q*16 + r.  Fixed order -> bit-reproducible.
-    float a[32];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      a[r] = s1[r];
-      a[16 + r] = s2[r];
-    }
-    const int l32 = threadIdx.x & 31;
-#pragma unroll
-    for (int h = 16; h >= 1; h >>= 1) {
-      const bool up = (l32 & h) != 0;
-#pragma unroll
-      for (int i = 0; i < h; ++i) {
-        const float send = up ? a[i] : a[i + h];
-        const float keep = up ? a[i + h] : a[i];
-        a[i] = keep + __shfl_xor(send, h, 64);
-      }
-    }
-    const int r = l32 & 15, q = l32 >> 4;
-    const int o = ob + (r & 3) + 8 * (r >> 2);
-    if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
-  }
-}
-
 // One output tile per workgroup (used when a launch has no more tiles than resident workgroups;
 // otherwise conv3_mfma_fwd_p_kernel below).  Two workgroups per CU up to NTW = 4, one for NTW = 8,
 // i.e. one or two waves per SIMD: the next chunk's input halo tile and weights travel
@@ -553,190 +441,6 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     it = nit;
     cur = nxt;
   }
-}
-
-// ---------------------------------------------------------------- bf16 compute mode
-// Same implicit GEMM with operands rounded to bf16 (RNE) and v_mfma_f32_32x32x16_bf16 (fp32
-// accumulate, 16x the fp32-MFMA rate).  The K-step of 16 is 16 input channels at ONE tap:
-// lanes 0-31 carry channels c..c+7, lanes 32-63 c+8..c+15, so LDS is channel-last in groups of
-// 8 bf16 = 16 B and every fragment is a single aligned ds_read_b128:
-//   xs[half][halo voxel][8]      B fragment: lane (voxel, half), tap offset = DS immediate
-//   ws[tap][half][32 o][8]       A fragment: lane (o, half)
-// At this rate the kernel is bound by staging (global -> cvt -> LDS), not by the MFMA pipe:
-// synchronous staging, two workgroups per CU overlap each other.
-// The 16-bit element type is a template parameter: __bf16 (M355_COMPUTE_BF16) or _Float16
-// (M355_COMPUTE_F16, v_mfma_f32_32x32x16_f16); everything else is identical.
-template <typename HT>
-struct H16;
-template <>
-struct H16<__bf16> {
-  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
-  typedef __bf16 x4 __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
-struct H16<_Float16> {
-  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
-  typedef _Float16 x4 __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-// packed bf16 weights: wpb[(((ch*27 + tap)*2 + half)*mout_pad + m)*8 + j], channel = ch*16 + half*8 + j
-template <typename HT>
-__global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
-                                   int Cin, int nchunks, int mout_pad, int transpose) {
-  const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 7);
-    int64_t r = i >> 3;
-    const int m = (int)(r % mout_pad);
-    r /= mout_pad;
-    const int half = (int)(r & 1);
-    r >>= 1;
-    const int tap = (int)(r % 27);
-    const int kc = (int)(r / 27) * 16 + half * 8 + j;
-    float v = 0.f;
-    if (!transpose) {
-      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
-    } else {
-      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
-    }
-    wp[i] = (HT)v;
-  }
-}
-
-template <int NTW, int GX, typename HT>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_h16_kernel(
-    const float* __restrict__ x, const HT* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
-    int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
-    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride) {
-  using T = FwdTile<NTW, GX>;
-  using hx8 = typename H16<HT>::x8;
-  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
-  constexpr int XI = 2 * HV;                   // (half, voxel) staging items of 8 channels
-  constexpr int XPER = (XI + 255) / 256;
-  constexpr int WI = 27 * 2 * 32;              // 16-byte weight items per chunk
-  constexpr int WPER = (WI + 255) / 256;
-  __shared__ __attribute__((aligned(16))) hx8 xs[XI];
-  __shared__ __attribute__((aligned(16))) hx8 ws[WI];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int l32 = lane & 31;
-  const int ly = l32 / GX, lx = l32 % GX;
-
-  int bt = blockIdx.x;
-  const int txt = bt % tx_tiles;
-  bt /= tx_tiles;
-  const int tyt = bt % ty_tiles;
-  const int tzt = bt / ty_tiles;
-  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
-  const int o0 = blockIdx.y * 32;
-  const int n = blockIdx.z / ksplit;
-  const int ks = blockIdx.z % ksplit;
-  const int cps = (nchunks + ksplit - 1) / ksplit;
-  const int ch_begin = ks * cps;
-  const int ch_end = min(nchunks, ch_begin + cps);
-
-  const float* xn = x + (int64_t)n * xbs;
-  const int64_t HW = (int64_t)H * W;
-  const int DHW = (int)(HW * D);
-
-  // chunk-invariant spatial offset of this thread's staging items (-1: zero padding)
-  int goff[XPER];
-#pragma unroll
-  for (int i = 0; i < XPER; ++i) {
-    const int e = tid + 256 * i;
-    int off = -1;
-    if (e < XI) {
-      const int r = e % HV;
-      const int zz = r / PS, r2 = r - zz * PS;
-      const int yy = r2 / RS, xx = r2 - yy * RS;
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) off = gz * (int)HW + gy * W + gx;
-    }
-    goff[i] = off;
-  }
-
-  f32x16 acc[NTW];
-#pragma unroll
-  for (int g = 0; g < NTW; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-
-  const hx8* xb = xs + half * HV + wave * PS + ly * RS + lx;
-  const hx8* wb = ws + half * 32 + l32;
-  const uint4* wsrc0 = reinterpret_cast<const uint4*>(wp);
-
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    __syncthreads();
-    // ---- stage x: item e = (half h, halo voxel r): 8 channels -> one 16-byte LDS store.
-    // Phase 1 issues EVERY global load of the chunk (x and weights) before anything consumes
-    // one, so the whole chunk is a single memory round trip; phase 2 converts and stores.
-    float xr[XPER][8];
-    uint4 wr[WPER];
-#pragma unroll
-    for (int i = 0; i < XPER; ++i) {
-      const int e = tid + 256 * i;
-      const int cbase = ch * 16 + (e >= HV ? 8 : 0);
-      const bool sp_ok = goff[i] >= 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // the clamp must be on the ABSOLUTE offset: channels >= Cin lie past the end of the tensor
-        const bool ok = sp_ok && cbase + j < Cin;
-        xr[i][j] = xn[ok ? (int64_t)(cbase + j) * DHW + goff[i] : 0];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WPER; ++i) {
-      const int e = tid + 256 * i;
-      const int ec = e < WI ? e : WI - 1;
-      const int row = ec >> 5, o = ec & 31;  // row = tap*2 + half
-      wr[i] = wsrc0[((int64_t)ch * 54 + row) * cout_pad + o0 + o];
-    }
-#pragma unroll
-    for (int i = 0; i < XPER; ++i) {
-      const int e = tid + 256 * i;
-      const int cbase = ch * 16 + (e >= HV ? 8 : 0);
-      const bool sp_ok = goff[i] >= 0;
-      hx8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (HT)((sp_ok && cbase + j < Cin) ? xr[i][j] : 0.f);
-      if (e < XI) xs[e] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < WPER; ++i)
-      if (tid + 256 * i < WI) reinterpret_cast<uint4*>(ws)[tid + 256 * i] = wr[i];
-    __syncthreads();
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const hx8 a = wb[tap * 64];
-#pragma unroll
-      for (int g = 0; g < NTW; ++g) {
-        const hx8 b = xb[dz * PS + (g * GY + dy) * RS + dx];
-        acc[g] = H16<HT>::mfma(a, b, acc[g]);
-      }
-    }
-  }
-
-  const int z = z0 + wave;
-  const int xg = x0 + lx;
-  const bool lane_ok = z < D && xg < W;
-  if (ksplit == 1)
-    store_conv_tile<NTW, GY>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z,
-                             y0, xg, ly, half, D, H, W, lane_ok, nullptr);
-  else
-    store_conv_tile<NTW, GY>(acc, slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * HW, nullptr, nullptr,
-                             o0, Cout, z, y0, xg, ly, half, D, H, W, lane_ok, nullptr);
 }
 
 // A 32-row MFMA tile would carry only Cout useful rows.  z-Toeplitz packing fills the rows
@@ -1654,177 +1358,6 @@ __global__ __launch_bounds__(256) void conv3_mfma_bww_small_kernel(
   }
 }
 
-// ------------------------------------------------ bwd-weight, bf16 compute mode (W % 32 == 0)
-// dW[o,c,tap] = sum_v dy[o,v] * x[c,v+off(tap)] on v_mfma_f32_32x32x16_bf16: i = o, j = c,
-// k = 16 x-adjacent voxels (lane half h carries voxels 8h..8h+7 as ONE 16-byte fragment).
-// A tap's dx shift would misalign those 16-byte reads by 2 bytes, so the input tile is kept in
-// LDS three times, pre-shifted by dx = -1/0/+1 (built while staging with one lane shuffle each
-// way); dz/dy shifts are whole rows and stay aligned.  Tile = 2x2x32 voxels:
-//   dys[32 o][128 + 8]            (row stride 17 x 16 B: conflict-free b128 reads)
-//   xs3[3 dx][32 c][16 rows x 32 + 8]   (channel stride 65 x 16 B)
-// Memory-bound at this MFMA rate; the next tile is prefetched into registers during the MFMAs.
-template <typename HT>
-__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_h16_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
-    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
-    int64_t xbs, int64_t ybs) {
-  using hx8 = typename H16<HT>::x8;
-  constexpr int TZ = 2, TY = 2, TX = 32, NV = TZ * TY * TX;     // 128
-  constexpr int ROWS = (TZ + 2) * (TY + 2);                      // 16 halo rows per channel
-  constexpr int DROW = NV + 8;                                   // bf16 elements per dy row
-  constexpr int XCH = ROWS * TX + 8;                             // bf16 elements per channel per copy
-  constexpr int XCPY = 32 * XCH;                                 // bf16 elements per shifted copy
-  constexpr int XITEMS = 32 * ROWS * 8;                          // (c, row, q) float4 items
-  constexpr int XPER = XITEMS / 256;                             // 16
-  __shared__ __attribute__((aligned(16))) HT dys[32 * DROW];
-  __shared__ __attribute__((aligned(16))) HT xs3[3 * XCPY];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l32 = lane & 31;
-  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32, split = blockIdx.z;
-  const int iHW = H * W, iDHW = D * H * W;
-
-  // this wave's taps: element offsets of (dx copy, dz/dy row shift) inside xs3
-  int toff[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = min(wave * 7 + t, 26);
-    toff[t] = (tap % 3) * XCPY + ((tap / 9) * (TY + 2) + (tap / 3) % 3) * TX;
-  }
-  f32x16 acc[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // staging roles
-  const int q = tid & 7;                 // float4 column of an x item
-  const int so = tid >> 3, sseg = tid & 7;  // dy: output channel, 16-voxel segment
-  const int sz = sseg >> 2, sy = (sseg >> 1) & 1, sxh = sseg & 1;
-
-  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
-  const int ntiles = N * tiles_per_n;
-
-  f32x4 xr[XPER];
-  float xh[XPER];
-  f32x4 dr[4];
-  unsigned mrow, mhalo, mdy;  // validity bits applied at commit
-  auto fetch = [&](int tile) {
-    int t = tile;
-    const int n = t / tiles_per_n;
-    t -= n * tiles_per_n;
-    const int txt = t % tx_tiles;
-    t /= tx_tiles;
-    const int tyt = t % ty_tiles;
-    const int tzt = t / ty_tiles;
-    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
-    const float* xn = x + (int64_t)n * xbs;
-    const float* dn = dy + (int64_t)n * ybs;
-    mrow = 0u;
-    mhalo = 0u;
-    const int hx = q == 0 ? x0 - 1 : x0 + TX;       // only lanes q == 0 / q == 7 use their halo value
-    const bool hx_ok = (q == 0 || q == 7) && hx >= 0 && hx < W;
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-      const int rowi = (tid >> 3) + 32 * k;          // (c, halo row) index, 512 in all
-      const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      const int zz = rr / (TY + 2), yy = rr - zz * (TY + 2);
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
-      const bool rok = gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
-      const int base = gc * iDHW + gz * iHW + gy * W;
-      xr[k] = *reinterpret_cast<const f32x4*>(xn + (rok ? base + x0 + 4 * q : 0));
-      xh[k] = xn[(rok && hx_ok) ? base + hx : 0];
-      mrow |= rok ? (1u << k) : 0u;
-      mhalo |= (rok && hx_ok) ? (1u << k) : 0u;
-    }
-    const int gz = z0 + sz, gy = y0 + sy;
-    const bool dok = o0 + so < Cout && gz < D && gy < H;
-    const int dbase = dok ? (o0 + so) * iDHW + gz * iHW + gy * W + x0 + 16 * sxh : 0;
-    mdy = dok ? 1u : 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dr[u] = *reinterpret_cast<const f32x4*>(dn + dbase + 4 * u);
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-      const bool rok = (mrow >> k) & 1u;
-      f32x4 v = xr[k];
-      if (!rok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float hv = ((mhalo >> k) & 1u) ? xh[k] : 0.f;
-      // neighbours inside the 8-lane row group
-      float left = __shfl_up(v[3], 1, 64), right = __shfl_down(v[0], 1, 64);
-      if (q == 0) left = hv;
-      if (q == 7) right = hv;
-      const int rowi = (tid >> 3) + 32 * k;
-      const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      HT* dst = xs3 + c * XCH + rr * TX + 4 * q;
-      using bf16x4 = typename H16<HT>::x4;
-      bf16x4 m1, m0, p1;
-      m1[0] = (HT)left; m1[1] = (HT)v[0]; m1[2] = (HT)v[1]; m1[3] = (HT)v[2];   // x - 1
-      m0[0] = (HT)v[0]; m0[1] = (HT)v[1]; m0[2] = (HT)v[2]; m0[3] = (HT)v[3];   // x
-      p1[0] = (HT)v[1]; p1[1] = (HT)v[2]; p1[2] = (HT)v[3]; p1[3] = (HT)right;  // x + 1
-      *reinterpret_cast<bf16x4*>(dst) = m1;
-      *reinterpret_cast<bf16x4*>(dst + XCPY) = m0;
-      *reinterpret_cast<bf16x4*>(dst + 2 * XCPY) = p1;
-    }
-    hx8 d0, d1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      d0[u] = (HT)(mdy ? dr[0][u] : 0.f);
-      d0[4 + u] = (HT)(mdy ? dr[1][u] : 0.f);
-      d1[u] = (HT)(mdy ? dr[2][u] : 0.f);
-      d1[4 + u] = (HT)(mdy ? dr[3][u] : 0.f);
-    }
-    HT* dd = dys + so * DROW + sseg * 16;
-    *reinterpret_cast<hx8*>(dd) = d0;
-    *reinterpret_cast<hx8*>(dd + 8) = d1;
-  };
-
-  if (split < ntiles) {
-    fetch(split);
-    commit();
-  }
-  __syncthreads();
-  const HT* ab = dys + l32 * DROW + 8 * half;
-  const HT* bb = xs3 + l32 * XCH + 8 * half;
-  for (int tile = split; tile < ntiles; tile += nsplit) {
-    const bool more = tile + nsplit < ntiles;
-    if (more) fetch(tile + nsplit);
-#pragma unroll
-    for (int zy = 0; zy < TZ * TY; ++zy) {
-      const int z = zy / TY, yy = zy % TY;
-#pragma unroll
-      for (int xk = 0; xk < 2; ++xk) {
-        const hx8 a = *reinterpret_cast<const hx8*>(ab + zy * TX + 16 * xk);
-        const HT* brow = bb + (z * (TY + 2) + yy) * TX + 16 * xk;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-          const hx8 b = *reinterpret_cast<const hx8*>(brow + toff[t]);
-          acc[t] = H16<HT>::mfma(a, b, acc[t]);
-        }
-      }
-    }
-    __syncthreads();
-    if (more) commit();
-    __syncthreads();
-  }
-  float* sl = slab + (int64_t)split * Cout * Cin * 27;
-  const int c = c0 + l32;
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = wave * 7 + t;
-    if (tap < 27 && c < Cin) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
-      }
-    }
-  }
-}
-
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                    int64_t total, int nsplit) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -2005,19 +1538,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_bwd_weight_kernel(
 }
 
 // ------------------------------------------------------------------ planning
-struct FwdPlan {
-  bool mfma;
-  bool persistent;  // more items than resident workgroups: conv3_mfma_fwd_p_kernel
-  int gx, ntw;
-  int tz_tiles, ty_tiles, tx_tiles;
-  int otiles, kin_pad, mout_pad, nchunks, ksplit;
-  size_t wp_bytes, slab_bytes;
-};
-
 // Plan for a 3x3x3/s1/p1 conv with K-channels `kin` and M-channels `mout`.
 // Lanes along x per 32-voxel group: the widest of {32, 16, 8} unless a narrower one wastes noticeably
 // fewer padded voxels (W = 24: 16 -> 2 tiles = 32 columns, 8 -> 3 tiles = 24 columns).
-static int pick_gx(int W) {
+int pick_gx(int W) {
   int best = 8;
   int64_t best_pad = round_up(W, 8);
   for (int gx : {16, 32}) {
@@ -2030,7 +1554,7 @@ static int pick_gx(int W) {
   return best;
 }
 
-static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32) {
+FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   FwdPlan p{};
   p.mfma = true;
   p.gx = pick_gx(W);
@@ -2057,9 +1581,11 @@ static FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int comp
   double best = 1e30;
   const int cus = num_cus();
   for (int i = 0; i < 4 && h16; ++i) {
-    // 16-bit operand modes (HBM/LDS-bound kernel): fill the chip once, largest tile first
+    // 16-bit operand modes (LDS / staging-bound kernel, conv3d_h16.hip): fill the chip once, largest tile
+    // first; the instantiated tiles are NTW <= 4 (<= 2 for 8 lanes along x)
     const int ntw = cands[i];
-    if (force_ntw && ntw != force_ntw) continue;
+    if (ntw == 8 || (p.gx == 8 && ntw == 4)) continue;
+    if (force_ntw && ntw != force_ntw && force_ntw != 8 && !(p.gx == 8 && force_ntw == 4)) continue;
     const int ty = ntw * gy;
     if (ty > H && ntw > 1 && !force_ntw) continue;
     const int64_t nwg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
@@ -2165,73 +1691,35 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
                      p.ksplit, xbs, ybs, slab_stride, stat);
 }
 
-// Runs the MFMA implicit GEMM: out[n, m, v] = bias + add + sum_{kc,tap} wp * in[n, kc, v+tap]
-template <int NTW, int GX, typename HT>
-static void launch_h16(const FwdPlan& p, const float* x, const HT* wp, const float* bias,
-                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
-                        int H, int W, int64_t xbs, int64_t ybs, hipStream_t st) {
-  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
-            (unsigned)(N * p.ksplit));
-  const int64_t slab_stride = (int64_t)N * mout * D * H * W;
-  hipLaunchKernelGGL((conv3_mfma_h16_kernel<NTW, GX, HT>), grid, dim3(256), 0, st, x, wp, bias, add, y,
-                     slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
-                     p.ksplit, xbs, ybs, slab_stride);
-}
-
-// 16-bit operand modes (bf16 / fp16): tensors stay fp32 in HBM, operands are rounded while staged
-template <typename HT>
-static int run_h16_conv(const FwdPlan& p, const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
-                        const float* bias, const float* add, float* out, int N, int kin, int mout, int D, int H,
-                        int W, int64_t in_bs, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st) {
-  M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
-               "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
-  M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
-  M355_REQUIRE((int64_t)std::max(kin, mout) * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
-               "conv3d(16-bit operands): tensor exceeds 2^31 elements per sample");
-  HT* wpb = (HT*)ws;
-  float* slab = (float*)((char*)ws + p.wp_bytes);
-  {
-    const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
-    hipLaunchKernelGGL(pack_w3_h16_kernel<HT>, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w, p.nchunks,
-                       p.mout_pad, transpose ? 1 : 0);
-  }
-  const float* kb = p.ksplit == 1 ? bias : nullptr;
-  const float* ka = p.ksplit == 1 ? add : nullptr;
-#define M355_H16_CASE(NTW, GX)                                                                          \
-  if (p.ntw == NTW && p.gx == GX) {                                                                     \
-    launch_h16<NTW, GX, HT>(p, in, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, st);   \
-  } else
-  M355_H16_CASE(8, 32) M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
-  M355_H16_CASE(8, 16) M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
-  M355_H16_CASE(8, 8) M355_H16_CASE(4, 8) M355_H16_CASE(2, 8) M355_H16_CASE(1, 8) {
-    set_error("conv3d(16-bit operands): no kernel for ntw=%d gx=%d", p.ntw, p.gx);
-    return M355_EUNSUPPORTED;
-  }
-#undef M355_H16_CASE
-  if (p.ksplit > 1) {
-    const int64_t S = (int64_t)D * H * W;
-    const int64_t total = (int64_t)N * mout * S;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out, N, mout, S,
-                       p.ksplit, total, out_bs);
-  }
-  return check_launch("conv3d_mfma_h16");
+// bytes of the c8 staging copy the fp32-input entry points make in 16-bit operand modes
+static size_t act16_staging_bytes(int N, int C, int D, int H, int W) {
+  return (size_t)round_up((int64_t)N * c8_blocks(C) * D * H * W * 16, 256);
 }
 
 static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
                          const float* bias, const float* add, float* out, int N, int kin,
                          int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
-                         size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32, float* stat = nullptr) {
+                         size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32, float* stat = nullptr,
+                         const void* in16 = nullptr, int64_t in16_bs = 0) {
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
-  M355_REQUIRE(!stat || (compute == M355_COMPUTE_F32 && p.ksplit == 1), M355_EINVALID_ARG,
+  M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
-  if (compute == M355_COMPUTE_BF16)
-    return run_h16_conv<__bf16>(p, in, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W, in_bs,
-                                out_bs, ws, ws_bytes, st);
-  if (compute == M355_COMPUTE_F16)
-    return run_h16_conv<_Float16>(p, in, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W, in_bs,
-                                  out_bs, ws, ws_bytes, st);
+  if (compute != M355_COMPUTE_F32) {
+    if (!in16) {
+      // fp32 NCDHW input: one conversion pass into the c8 layout (the model path hands over c8 tensors that its
+      // normalisation / pooling passes wrote, m355_conv3d_fwd_h16)
+      const size_t base = p.wp_bytes + p.slab_bytes;
+      M355_REQUIRE(ws_bytes >= base + act16_staging_bytes(N, kin, D, H, W), M355_EWORKSPACE,
+                   "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes,
+                   base + act16_staging_bytes(N, kin, D, H, W));
+      void* stage = (char*)ws + base;
+      in16_bs = c8_blocks(kin) * (int64_t)D * H * W * 8;
+      if (int rc = launch_pack_act16(in, stage, N, kin, (int64_t)D * H * W, in_bs, in16_bs, compute, st)) return rc;
+      in16 = stage;
+    }
+    return run_h16_conv(p, compute, in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W,
+                        out_bs, ws, ws_bytes, st, stat);
+  }
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
@@ -2334,7 +1822,8 @@ extern "C" size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
   if (small_cout_fwd(d)) return small_cout_ws(d);
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
-  return p.wp_bytes + p.slab_bytes;
+  return p.wp_bytes + p.slab_bytes +
+         (d->compute != M355_COMPUTE_F32 ? act16_staging_bytes(d->N, d->Cin, d->D, d->H, d->W) : 0);
 }
 
 static int validate_conv(const m355_conv3d_desc* d, const char* who) {
@@ -2353,7 +1842,7 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
 // when statistics are fused (4 waves x spatial tiles); 0 = this descriptor has no fused statistics
 // (not 3x3x3 s1 p1, small-Cout kernel, bf16 operand mode, or a split-K plan).
 static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
-  if (!is_k3s1p1(d) || small_cout_fwd(d) || d->compute != M355_COMPUTE_F32) return 0;
+  if (!is_k3s1p1(d) || small_cout_fwd(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return 0;
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
@@ -2425,6 +1914,76 @@ extern "C" int m355_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, 
   return conv3d_fwd_impl(d, x, w, bias, add, y, stat_partials, workspace, workspace_bytes, stream);
 }
 
+// ---- 16-bit operand modes with c8 tensors handed over by the caller (h16.hpp) ----
+extern "C" size_t m355_act16_bytes(int32_t N, int32_t C, int64_t S) {
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  return (size_t)N * (size_t)c8_blocks(C) * (size_t)S * 16;
+}
+
+static int validate_act16(const char* who, const void* a, const void* b, int N, int C, int64_t S, int compute) {
+  M355_REQUIRE(a && b, M355_EINVALID_ARG, "%s: null pointer", who);
+  M355_REQUIRE(N > 0 && C > 0 && S > 0 && N <= 65535 && c8_blocks(C) <= 65535, M355_EINVALID_ARG, "%s: bad shape", who);
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "%s: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16", who);
+  return M355_OK;
+}
+
+extern "C" int m355_act16_pack(const float* x, void* x16, int32_t N, int32_t C, int64_t S, int64_t x_batch_stride,
+                               int64_t x16_batch_stride, int32_t compute, void* stream) {
+  if (int rc = validate_act16("act16_pack", x, x16, N, C, S, compute)) return rc;
+  M355_REQUIRE(((uintptr_t)x16 & 15) == 0 && x16_batch_stride % 8 == 0, M355_EINVALID_ARG, "act16_pack: c8 tensor not 16B aligned");
+  return launch_pack_act16(x, x16, N, C, S, dense_or(x_batch_stride, (int64_t)C * S),
+                           dense_or(x16_batch_stride, c8_blocks(C) * S * 8), compute, (hipStream_t)stream);
+}
+
+extern "C" int m355_act16_unpack(const void* x16, float* x, int32_t N, int32_t C, int64_t S, int64_t x16_batch_stride,
+                                 int64_t x_batch_stride, int32_t compute, void* stream) {
+  if (int rc = validate_act16("act16_unpack", x16, x, N, C, S, compute)) return rc;
+  M355_REQUIRE(((uintptr_t)x16 & 15) == 0 && x16_batch_stride % 8 == 0, M355_EINVALID_ARG, "act16_unpack: c8 tensor not 16B aligned");
+  return launch_unpack_act16(x16, x, N, C, S, dense_or(x16_batch_stride, c8_blocks(C) * S * 8),
+                             dense_or(x_batch_stride, (int64_t)C * S), compute, (hipStream_t)stream);
+}
+
+extern "C" size_t m355_conv3d_h16_workspace(const m355_conv3d_desc* d, int32_t which) {
+  if (!d || !is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
+  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
+                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
+  return p.wp_bytes + p.slab_bytes;
+}
+
+static int validate_h16(const m355_conv3d_desc* d, const char* who) {
+  if (int rc = validate_conv(d, who)) return rc;
+  M355_REQUIRE(is_k3s1p1(d) && d->compute != M355_COMPUTE_F32, M355_EUNSUPPORTED,
+               "%s: c8 input is only defined for the 3x3x3 / stride 1 / pad 1 kernels in a 16-bit compute mode", who);
+  return M355_OK;
+}
+
+extern "C" int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const float* w,
+                                   const float* bias, const float* add, float* y, float* stat_partials, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (int rc = validate_h16(d, "conv3d_fwd_h16")) return rc;
+  M355_REQUIRE(x16 && w && y && workspace, M355_EINVALID_ARG, "conv3d_fwd_h16: null pointer");
+  M355_REQUIRE(!stat_partials || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
+               "conv3d_fwd_h16: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  return run_mfma_conv(nullptr, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D, d->H, d->W, 0,
+                       dense_or(d->y_batch_stride, (int64_t)d->Cout * S), workspace, workspace_bytes,
+                       (hipStream_t)stream, d->compute, stat_partials, x16,
+                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8));
+}
+
+extern "C" int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride,
+                                        const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (int rc = validate_h16(d, "conv3d_bwd_data_h16")) return rc;
+  M355_REQUIRE(dy16 && w && dx && workspace, M355_EINVALID_ARG, "conv3d_bwd_data_h16: null pointer");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  return run_mfma_conv(nullptr, w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin, d->D, d->H, d->W,
+                       0, dense_or(d->x_batch_stride, (int64_t)d->Cin * S), workspace, workspace_bytes,
+                       (hipStream_t)stream, d->compute, nullptr, dy16,
+                       dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8));
+}
+
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
   M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
   out4[0] = out4[1] = out4[2] = out4[3] = 0;
@@ -2432,14 +1991,15 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  out4[0] = p.persistent ? 3 : 1; out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  out4[0] = d->compute != M355_COMPUTE_F32 ? 4 : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 
 extern "C" size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  return p.wp_bytes + p.slab_bytes;
+  return p.wp_bytes + p.slab_bytes +
+         (d->compute != M355_COMPUTE_F32 ? act16_staging_bytes(d->N, d->Cout, d->D, d->H, d->W) : 0);
 }
 
 extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const float* w,
@@ -2514,13 +2074,9 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
       // tile 2x2x32; the slab layout / split count of the fp32 plan are reused
       const int tz2 = (int)ceil_div(d->D, 2), ty2 = (int)ceil_div(d->H, 2), tx2 = d->W / 32;
       const int nsplit = (int)std::min<int64_t>(p.nsplit, (int64_t)d->N * tz2 * ty2 * tx2);
-      dim3 gb((unsigned)p.ctiles, (unsigned)p.otiles, (unsigned)nsplit);
-      if (d->compute == M355_COMPUTE_BF16)
-        hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<__bf16>, gb, dim3(256), 0, st, x, dy, slab, d->N, d->Cin,
-                           d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit, xbs, ybs);
-      else
-        hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<_Float16>, gb, dim3(256), 0, st, x, dy, slab, d->N, d->Cin,
-                           d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit, xbs, ybs);
+      if (int rc = launch_bww_h16(d->compute, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit,
+                                  p.ctiles, p.otiles, xbs, ybs, st))
+        return rc;
       const int64_t total = (int64_t)d->Cout * d->Cin * 27;
       const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total, nsplit);

@@ -1,0 +1,150 @@
+// Shared pieces of the 3x3x3 convolution kernels (conv3d.hip: fp32 MFMA path, planning, ABI;
+// conv3d_h16.hip: bf16 / fp16 operand kernels).
+#pragma once
+#include "common.hpp"
+#include "h16.hpp"
+
+namespace m355 {
+
+
+// Opaque copy: stops LICM from hoisting per-element address decode out of a loop (which
+// would keep hundreds of loop-invariant registers alive and spill).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// ------------------------------------------------------------ MFMA fwd kernel
+template <int NTW, int GX>
+struct FwdTile {
+  static constexpr int GY = 32 / GX;
+  static constexpr int TZ = 4;  // one z slice per wave
+  static constexpr int TY = NTW * GY;
+  static constexpr int TX = GX;
+  static constexpr int RS = TX + 2;
+  static constexpr int PS = (TY + 2) * RS;
+  static constexpr int CS = (TZ + 2) * PS;
+  static constexpr int CC = 4;  // input channels per LDS chunk (even: MFMA k-pair)
+  static constexpr int NROWS = CC * (TZ + 2) * (TY + 2);
+};
+
+// Output tile of one wave: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// The bias / residual values of all 16 rows are loaded as one batch (one wait) and the row offsets
+// k*DHW are uniform, so the 16*NTW stores go out back to back.  (Written the obvious way --
+// `if (o < Cout) { v = acc; if (bias) v += bias[o]; if (add) v += add[idx]; y[idx] = v; }` per
+// element -- hipcc emits a branch, a load and a vmcnt(0) per element: ~10 us per tile with the
+// matrix core idle.)
+template <int NTW, int GY>
+__device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float* __restrict__ dst,
+                                                const float* __restrict__ addp, const float* __restrict__ bias,
+                                                int o0, int Cout, int z, int y0, int xg, int ly, int half,
+                                                int D, int H, int W, bool lane_ok, float* __restrict__ stat) {
+  // lane_ok: this lane's (z, x) column lies inside the volume.  Every lane stays active to the end
+  // (the statistics below are reduced with cross-lane shuffles).
+  // stat (may be null): (sum, sum of squares) of the values this WAVE stores, per output channel ->
+  // stat[o*2 + {0,1}]; the normalisation that follows the conv sums these partials instead of
+  // reading y again (m355_conv3d_fwd_stats / m355_norm_stats_from_partials).
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  const int ob = o0 + 4 * half;  // this lane's first output channel; row r is channel ob + (r&3) + 8*(r>>2)
+  float bb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bb[r] = 0.f;
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[r] = bias[min(ob + (r & 3) + 8 * (r >> 2), Cout - 1)];
+  }
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NTW; ++g) {
+    const int yg = y0 + g * GY + ly;
+    const bool ok = lane_ok && yg < H;
+    const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
+    if (addp) {
+      float aa[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        aa[r] = addp[(ok && ob + k < Cout) ? base + (int64_t)k * DHW : 0];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += aa[r];
+    }
+    if (stat) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ok ? v[r] : 0.f;
+        s1[r] += t;
+        s2[r] = fmaf(t, t, s2[r]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        if (ob + k < Cout) dst[base + (int64_t)k * DHW] = v[r];
+      }
+    }
+  }
+  if (stat) {
+    // reduce-scatter over the 32 lanes of each half (xor < 32 stays inside the half): 32 values
+    // (16 rows x {sum, sumsq}) are summed over 32 lanes with 16+8+4+2+1 shuffles; lane l ends up
+    // holding value index l & 31 = q*16 + r.  Fixed order -> bit-reproducible.
+    float a[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a[r] = s1[r];
+      a[16 + r] = s2[r];
+    }
+    const int l32 = threadIdx.x & 31;
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+      const bool up = (l32 & h) != 0;
+#pragma unroll
+      for (int i = 0; i < h; ++i) {
+        const float send = up ? a[i] : a[i + h];
+        const float keep = up ? a[i + h] : a[i];
+        a[i] = keep + __shfl_xor(send, h, 64);
+      }
+    }
+    const int r = l32 & 15, q = l32 >> 4;
+    const int o = ob + (r & 3) + 8 * (r >> 2);
+    if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
+  }
+}
+
+
+// ------------------------------------------------------------------ planning
+struct FwdPlan {
+  bool mfma;
+  bool persistent;  // more items than resident workgroups: the queue-driven kernel variants
+  int gx, ntw;
+  int tz_tiles, ty_tiles, tx_tiles;
+  int otiles, kin_pad, mout_pad, nchunks, ksplit;
+  size_t wp_bytes, slab_bytes;
+};
+
+int pick_gx(int W);
+FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32);
+
+// 16-bit operand convolution (conv3d_h16.hip).  in16: c8 layout (h16.hpp) with `in16_bs` ELEMENTS between
+// samples; out: fp32 NCDHW.  Workspace: p.wp_bytes (packed weights + work queue) + p.slab_bytes.
+int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
+                 int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
+                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat);
+// weight gradient on the 16-bit MFMA (fp32 NCDHW operands rounded while staged; W % 32 == 0)
+int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
+                   int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
+                   hipStream_t st);
+
+// y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                     const float* __restrict__ add, float* __restrict__ y, int N,
+                                     int Cout, int64_t S, int ksplit, int64_t slab_stride,
+                                     int64_t ybs);
+
+}  // namespace m355

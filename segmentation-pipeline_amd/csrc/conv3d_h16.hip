@@ -1,0 +1,633 @@
+// 3x3x3 / stride 1 / pad 1 convolution with 16-bit operands (M355_COMPUTE_BF16 / M355_COMPUTE_F16) on
+// v_mfma_f32_32x32x16_{bf16,f16}: fp32 accumulate, 16x the fp32-MFMA rate.  Forward and data gradient
+// (the latter = the same kernel on dy with flipped / transposed packed weights).
+//
+// Reference ops replaced: nn.Conv3d inside Block3d (models/components.py:36,42,51) and the out conv
+// (models/modular_unet.py:83,99) under BASELINE cfg3 ("bf16") / cfg5 ("mixed fp16 with MFMA channel-GEMM
+// path"); the reference itself has no reduced-precision path, the fp32 result is the oracle.
+//
+// GEMM view:  Y[o, v] = sum_{c, tap} Wp[(c, tap), o] * X[c, v + off(tap)],  M = Cout, N = voxels.
+// The K-step of 16 is 16 input channels at ONE tap: lanes 0-31 carry channels c..c+7 of voxel (lane & 31),
+// lanes 32-63 channels c+8..c+15.  The input arrives in the c8 layout (h16.hpp: [cb][voxel][8 channels],
+// one 16-byte item per voxel and channel block), so
+//   * a lane's B fragment is ONE item: global -> register -> LDS -> ds_read_b128 -> MFMA, never converted,
+//     never transposed (the fp32-input version of this kernel gathered 8 channel planes with 8 scalar loads
+//     and 8 conversions per item and was bound by exactly that);
+//   * a tap shift is a whole-item offset in the LDS halo tile -- an immediate of the ds_read;
+//   * zero padding, tile overhang and channel blocks past the tensor come from the buffer descriptor
+//     (out-of-range offset -> the hardware returns 0): no masks, no branches.
+// LDS:  xs[half][halo voxel]  (B fragments),  ws[tap][half][32 o]  (A fragments), 16 bytes each, one buffer;
+// the next chunk (16 channels: halo tile + 27 taps x 32 output channels of weights) travels global ->
+// registers while the current one is multiplied, its loads interleaved into the MFMA stream, and is
+// committed to LDS between two barriers.  Two workgroups per CU cover each other's commits.
+// With 32 lanes along x (GY = 1) an output row's B fragment for tap row dy is the fragment of input row
+// g + dy: the NTW + 2 row fragments of a (dz, dx) pair are read once and used by all 3 * NTW MFMAs of that
+// pair (0.75 LDS reads per MFMA at NTW = 4 instead of 1.25) -- LDS bandwidth is what bounds this loop.
+// Persistent: one residency of workgroups takes (output tile x 32-channel tile x sample x split) items from
+// per-XCD queues, prefetching the first chunk of the next item during the last chunk of the current one.
+#include "conv3d_common.hpp"
+
+namespace m355 {
+
+// ------------------------------------------------------------------ layout conversion
+// fp32 NCDHW -> c8: one thread per (voxel, channel block): 8 coalesced plane reads, one 16-byte store.
+template <typename HT>
+__global__ __launch_bounds__(256) void pack_act16_kernel(const float* __restrict__ x, HT* __restrict__ x16, int C,
+                                                         int64_t S, int64_t xbs, int64_t x16bs) {
+  using hx8 = typename H16<HT>::x8;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const float* xn = x + (int64_t)n * xbs + (int64_t)cb * 8 * S;
+  hx8* dst = reinterpret_cast<hx8*>(x16 + (int64_t)n * x16bs) + (int64_t)cb * S;
+  const int nc = min(8, C - cb * 8);
+  for (int64_t s = blockIdx.x * 256ll + threadIdx.x; s < S; s += gridDim.x * 256ll) {
+    hx8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (HT)(j < nc ? xn[(int64_t)j * S + s] : 0.f);
+    dst[s] = v;
+  }
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void unpack_act16_kernel(const HT* __restrict__ x16, float* __restrict__ x, int C,
+                                                           int64_t S, int64_t x16bs, int64_t xbs) {
+  using hx8 = typename H16<HT>::x8;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  float* xn = x + (int64_t)n * xbs + (int64_t)cb * 8 * S;
+  const hx8* src = reinterpret_cast<const hx8*>(x16 + (int64_t)n * x16bs) + (int64_t)cb * S;
+  const int nc = min(8, C - cb * 8);
+  for (int64_t s = blockIdx.x * 256ll + threadIdx.x; s < S; s += gridDim.x * 256ll) {
+    const hx8 v = src[s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nc) xn[(int64_t)j * S + s] = (float)v[j];
+  }
+}
+
+int launch_pack_act16(const float* x, void* x16, int N, int C, int64_t S, int64_t xbs, int64_t x16bs, int compute,
+                      hipStream_t st) {
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div(S, 256 * 4), 4096), (unsigned)c8_blocks(C), (unsigned)N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(pack_act16_kernel<__bf16>, grid, dim3(256), 0, st, x, (__bf16*)x16, C, S, xbs, x16bs);
+  else
+    hipLaunchKernelGGL(pack_act16_kernel<_Float16>, grid, dim3(256), 0, st, x, (_Float16*)x16, C, S, xbs, x16bs);
+  return check_launch("pack_act16");
+}
+
+int launch_unpack_act16(const void* x16, float* x, int N, int C, int64_t S, int64_t x16bs, int64_t xbs, int compute,
+                        hipStream_t st) {
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div(S, 256 * 4), 4096), (unsigned)c8_blocks(C), (unsigned)N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(unpack_act16_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x16, x, C, S, x16bs, xbs);
+  else
+    hipLaunchKernelGGL(unpack_act16_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x16, x, C, S, x16bs, xbs);
+  return check_launch("unpack_act16");
+}
+
+// ------------------------------------------------------------------ weight pack
+// wpb[(((ch*27 + tap)*2 + half)*mout_pad + m)*8 + j], channel = ch*16 + half*8 + j; zero rows / columns past
+// the tensor.  transpose: the data-gradient filter (flipped taps, channels swapped).  Also zeroes the work
+// queues of the persistent kernel (every launch of it is preceded by this pack on the same stream).
+template <typename HT>
+__global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
+                                   int Cin, int nchunks, int mout_pad, int transpose, int* __restrict__ counter) {
+  const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
+  if (counter && blockIdx.x == 0 && threadIdx.x < 8) counter[threadIdx.x] = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    int64_t r = i >> 3;
+    const int m = (int)(r % mout_pad);
+    r /= mout_pad;
+    const int half = (int)(r & 1);
+    r >>= 1;
+    const int tap = (int)(r % 27);
+    const int kc = (int)(r / 27) * 16 + half * 8 + j;
+    float v = 0.f;
+    if (!transpose) {
+      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
+    } else {
+      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
+    }
+    wp[i] = (HT)v;
+  }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int NTW, int GX, typename HT>
+__global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
+    const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
+    int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int nchunks, int ksplit, int nbatch,
+    int64_t xbs16, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int* __restrict__ work_counter) {
+  using T = FwdTile<NTW, GX>;
+  using hx8 = typename H16<HT>::x8;
+  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
+  constexpr bool REUSE = GX == 32;               // row-fragment reuse across (output row, tap row), see the header
+  constexpr int XI = 2 * HV;                     // (half, halo voxel) items of 16 bytes
+  constexpr int XPER = (XI + 255) / 256;
+  constexpr int WI = 27 * 2 * 32;                // (tap, half, o) items of 16 bytes
+  constexpr int WPER = (WI + 255) / 256;
+  constexpr int NSTEP = REUSE ? 9 : 27;          // MFMA steps per chunk: (dx, dz) pairs, or single taps
+  __shared__ __attribute__((aligned(16))) hx8 xs[XI];
+  __shared__ __attribute__((aligned(16))) hx8 ws[WI];
+  __shared__ int next_item_s;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const int ly = l32 / GX, lx = l32 % GX;
+  const int iHW = H * W;
+  const int S = D * iHW;
+
+  const int sp_tiles = tz_tiles * ty_tiles * tx_tiles;
+  const int total = sp_tiles * otiles * nbatch * ksplit;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+
+  struct Item {
+    int z0, y0, x0, o0, n, ks, ch_begin, ch_end, sp;
+  };
+  auto decode = [&](int it) {
+    Item q;
+    int sp = it % sp_tiles, r = it / sp_tiles;
+    q.sp = sp;
+    const int txt = sp % tx_tiles;
+    sp /= tx_tiles;
+    q.x0 = txt * TX;
+    q.y0 = (sp % ty_tiles) * TY;
+    q.z0 = (sp / ty_tiles) * TZ;
+    q.o0 = (r % otiles) * 32;
+    r /= otiles;
+    q.ks = r % ksplit;
+    q.n = r / ksplit;
+    q.ch_begin = q.ks * cps;
+    q.ch_end = min(nchunks, q.ch_begin + cps);
+    return q;
+  };
+
+  // byte offsets of this thread's halo items from the first channel block of a chunk; zero padding, items
+  // past the tile and the missing second block of an odd block count lie outside the descriptor -> 0
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[XPER];
+  auto compute_goff = [&](const Item& q) {
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+      const int e = tid + 256 * i;
+      const int h = e / HV, r = e - h * HV;
+      const int zz = r / PS, r2 = r - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = q.z0 + zz - 1, gy = q.y0 + yy - 1, gx = q.x0 + xx - 1;
+      const bool ok = e < XI && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      goff[i] = ok ? (unsigned)(h * S + gz * iHW + gy * W + gx) * 16u : OOB;
+    }
+  };
+
+  f32x4 xr[XPER], wr[WPER];
+  __amdgpu_buffer_rsrc_t rx;
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp);
+  auto chunk_setup = [&](const Item& q, int ch, bool live) {  // !live: zero-sized descriptor, no memory traffic
+    const int nb = min(2, CB - 2 * ch);
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x16 + (int64_t)q.n * xbs16 + (int64_t)(2 * ch) * S * 8), 0,
+                                           live ? nb * S * 16 : 0, 0x00020000);
+    wsrc = reinterpret_cast<const f32x4*>(wp) + (int64_t)ch * 54 * cout_pad + q.o0;
+  };
+  auto fetch_x = [&](int k) {  // k is a compile-time constant wherever this is called
+    xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, goff[k], 0, 0));
+  };
+  auto fetch_w = [&](int k) {
+    const int idx = tid + 256 * k;
+    const int idc = idx < WI ? idx : WI - 1;  // clamp: keeps the array fully scalarised
+    wr[k] = wsrc[(int64_t)(idc >> 5) * cout_pad + (idc & 31)];
+  };
+  // prefetch items issued during MFMA step s: the halo items (HBM latency) from the first step on, the
+  // weight items (L2-resident, short latency) during the last steps, where no fragment prefetch competes
+  // for registers
+  constexpr int WSTEPS = NSTEP < 4 ? NSTEP : 4;
+  auto fetch_step = [&](int s) {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k)
+      if (k % NSTEP == s) fetch_x(k);
+#pragma unroll
+    for (int k = 0; k < WPER; ++k)
+      if (NSTEP - 1 - (k % WSTEPS) == s) fetch_w(k);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XI) reinterpret_cast<f32x4*>(xs)[tid + 256 * i] = xr[i];
+#pragma unroll
+    for (int j = 0; j < WPER; ++j)
+      if (tid + 256 * j < WI) reinterpret_cast<f32x4*>(ws)[tid + 256 * j] = wr[j];
+  };
+
+  // ---- work queue (see conv3_mfma_fwd_p_kernel in conv3d.hip): eight contiguous item regions, one per XCD
+  // label (blockIdx % 8), each with an atomic ticket counter; a workgroup whose region is empty steals.
+  const int G = (int)gridDim.x;
+  const int xl = blockIdx.x & 7;
+  const int cpx = (total + 7) >> 3;
+  auto region_size = [&](int r) { return max(0, min(cpx, total - r * cpx)); };
+  auto region_static = [&](int r) { return min(region_size(r), (G - r + 7) >> 3); };
+  auto steal = [&]() {  // thread 0; `total` = nothing left anywhere
+    for (int a = 1; a < 8; ++a) {
+      const int r = (xl + a) & 7;
+      if (region_static(r) >= region_size(r)) continue;
+      const int k = region_static(r) + atomicAdd(work_counter + r, 1);
+      if (k < region_size(r)) return r * cpx + k;
+    }
+    return total;
+  };
+  auto resolve = [&](int taken) {
+    const int k = region_static(xl) + taken;
+    return k < region_size(xl) ? xl * cpx + k : steal();
+  };
+  int it = xl * cpx + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= region_size(xl)) {  // more workgroups than items in this region (uniform)
+    if (tid == 0) next_item_s = steal();
+    __syncthreads();
+    it = next_item_s;
+    __syncthreads();
+    if (it >= total) return;
+  }
+  Item cur = decode(it);
+  compute_goff(cur);
+  chunk_setup(cur, cur.ch_begin, true);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) fetch_step(s);
+  commit();
+  __syncthreads();
+
+  const hx8* xb = xs + half * HV + wave * PS + ly * RS + lx;
+  const hx8* wb = ws + half * 32 + l32;
+
+  f32x16 acc[NTW];
+  while (true) {
+    int pending = 0;
+    if (tid == 0) pending = atomicAdd(work_counter + xl, 1);
+    if (cur.ch_end - cur.ch_begin == 1) {  // single-chunk items: no chunk to hide the ticket's round trip behind
+      if (tid == 0) next_item_s = resolve(pending);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < NTW; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    Item nxt = cur;
+    int nit = total;
+    for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
+      if (ch + 1 < cur.ch_end) {
+        chunk_setup(cur, ch + 1, true);
+      } else {  // last chunk of this item: prefetch the first chunk of the next one
+        nit = next_item_s;
+        const bool live = nit < total;
+        nxt = decode(live ? nit : it);
+        compute_goff(nxt);
+        chunk_setup(nxt, nxt.ch_begin, live);
+      }
+      if constexpr (REUSE) {
+        // step s = (dx, dz): rows j = 0 .. NTW+1 of plane wave + dz at column offset dx; MFMA (g, dy) uses
+        // row g + dy and the weights of tap (dz, dy, dx).  MFMAs run row by row, so a row fragment dies early;
+        // the fragments of step s+1 are requested in the order step s+1 consumes them, one per MFMA from the
+        // point where step s has freed enough registers (NR reads behind 3*NTW MFMAs).
+        constexpr int NR = NTW + 5;                       // fragment reads per step
+        constexpr int NM = 3 * NTW;                       // MFMAs per step
+        constexpr int BARE = NM > NR ? NM - NR : 0;       // leading MFMAs without a read behind them
+        hx8 fa[2][3], fb[2][NTW + 2];
+        auto lds_step = [&](int s, int slot) {
+          const int dx = s / 3, dz = s % 3;
+          const hx8* wt = wb + (dz * 9 + dx) * 64;        // + dy * 3 * 64
+          const hx8* xt = xb + dz * PS + dx;              // + j * RS
+          fa[slot][0] = wt[0];
+          fb[slot][0] = xt[0];
+          fb[slot][1] = xt[RS];
+          fa[slot][1] = wt[3 * 64];
+          fb[slot][2] = xt[2 * RS];
+          fa[slot][2] = wt[6 * 64];
+#pragma unroll
+          for (int j = 3; j < NTW + 2; ++j) fb[slot][j] = xt[j * RS];
+        };
+        lds_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          if (s + 1 < NSTEP) lds_step(s + 1, (s + 1) & 1);
+          fetch_step(s);
+#pragma unroll
+          for (int j = 0; j < NTW + 2; ++j)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const int g = j - dy;
+              if (g >= 0 && g < NTW) acc[g] = H16<HT>::mfma(fa[s & 1][dy], fb[s & 1][j], acc[g]);
+            }
+          if (BARE > 0) __builtin_amdgcn_sched_group_barrier(0x008, BARE, 0);
+#pragma unroll
+          for (int m = 0; m < NM - BARE; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM - BARE - 1) / (NM - BARE), 0);  // DS read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // VMEM reads of the prefetch
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        hx8 fa[2], fb[2][NTW];
+        auto lds_step = [&](int s, int slot) {
+          const int dz = s / 9, dy = (s / 3) % 3, dx = s % 3;
+          fa[slot] = wb[s * 64];
+#pragma unroll
+          for (int g = 0; g < NTW; ++g) fb[slot][g] = xb[dz * PS + (g * GY + dy) * RS + dx];
+        };
+        lds_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          if (s + 1 < NSTEP) lds_step(s + 1, (s + 1) & 1);
+          fetch_step(s);
+#pragma unroll
+          for (int g = 0; g < NTW; ++g) acc[g] = H16<HT>::mfma(fa[s & 1], fb[s & 1][g], acc[g]);
+#pragma unroll
+          for (int g = 0; g < NTW; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
+      __syncthreads();  // every wave has read its last fragment of this chunk
+      commit();
+      __syncthreads();
+    }
+
+    // ---- output tile of `cur` ----
+    {
+      const int z = cur.z0 + wave;
+      const int xg = cur.x0 + lx;
+      const bool lane_ok = z < D && xg < W;
+      if (ksplit == 1) {
+        float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * 4 + wave) * Cout * 2 : nullptr;
+        store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
+                                 cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, st);
+      } else {
+        store_conv_tile<NTW, GY>(acc, slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * S, nullptr,
+                                 nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, nullptr);
+      }
+    }
+    if (nit >= total) break;
+    it = nit;
+    cur = nxt;
+  }
+}
+
+template <int NTW, int GX, typename HT>
+static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias,
+                       const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
+                       int64_t ybs, hipStream_t st, float* stat, int* work_counter) {
+  const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
+  const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus();
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, slots));
+  const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
+                     (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
+                     p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter);
+}
+
+template <typename HT>
+static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, const float* w, bool transpose,
+                          int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin,
+                          int mout, int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st,
+                          float* stat) {
+  M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
+               "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
+  M355_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)in16 & 15) == 0 && (in16_bs % 8) == 0, M355_EINVALID_ARG,
+               "conv3d(16-bit operands): workspace / c8 input not 16B aligned");
+  M355_REQUIRE((int64_t)D * H * W * 32 < (1ll << 31) && (int64_t)mout * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
+               "conv3d(16-bit operands): volume exceeds the 32-bit offsets of a buffer descriptor");
+  M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG, "conv3d(16-bit operands): no fused statistics for a split-K plan");
+  HT* wpb = (HT*)ws;
+  float* slab = (float*)((char*)ws + p.wp_bytes);
+  int* work_counter = (int*)((char*)ws + p.wp_bytes - 256);  // last 256 B of the packed-weight region
+  {
+    const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(pack_w3_h16_kernel<HT>, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w, p.nchunks,
+                       p.mout_pad, transpose ? 1 : 0, work_counter);
+  }
+  const float* kb = p.ksplit == 1 ? bias : nullptr;
+  const float* ka = p.ksplit == 1 ? add : nullptr;
+#define M355_H16_CASE(NTW, GX)                                                                               \
+  if (p.ntw == NTW && p.gx == GX) {                                                                          \
+    launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st, stat, \
+                            work_counter);                                                                   \
+  } else
+  M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
+  M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
+  M355_H16_CASE(2, 8) M355_H16_CASE(1, 8) {
+    set_error("conv3d(16-bit operands): no kernel for ntw=%d gx=%d", p.ntw, p.gx);
+    return M355_EUNSUPPORTED;
+  }
+#undef M355_H16_CASE
+  if (p.ksplit > 1) {
+    const int64_t S = (int64_t)D * H * W;
+    const int64_t total = (int64_t)N * mout * S;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, bias, add, out, N, mout, S,
+                       p.ksplit, total, out_bs);
+  }
+  return check_launch("conv3d_h16");
+}
+
+int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
+                 int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
+                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat) {
+  if (compute == M355_COMPUTE_BF16)
+    return run_h16_conv_t<__bf16>(p, (const __bf16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin,
+                                  mout, D, H, W, out_bs, ws, ws_bytes, st, stat);
+  return run_h16_conv_t<_Float16>(p, (const _Float16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N,
+                                  kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat);
+}
+
+// ------------------------------------------------ bwd-weight, bf16 compute mode (W % 32 == 0)
+// dW[o,c,tap] = sum_v dy[o,v] * x[c,v+off(tap)] on v_mfma_f32_32x32x16_bf16: i = o, j = c,
+// k = 16 x-adjacent voxels (lane half h carries voxels 8h..8h+7 as ONE 16-byte fragment).
+// A tap's dx shift would misalign those 16-byte reads by 2 bytes, so the input tile is kept in
+// LDS three times, pre-shifted by dx = -1/0/+1 (built while staging with one lane shuffle each
+// way); dz/dy shifts are whole rows and stay aligned.  Tile = 2x2x32 voxels:
+//   dys[32 o][128 + 8]            (row stride 17 x 16 B: conflict-free b128 reads)
+//   xs3[3 dx][32 c][16 rows x 32 + 8]   (channel stride 65 x 16 B)
+// Memory-bound at this MFMA rate; the next tile is prefetched into registers during the MFMAs.
+template <typename HT>
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_h16_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
+    int64_t xbs, int64_t ybs) {
+  using hx8 = typename H16<HT>::x8;
+  constexpr int TZ = 2, TY = 2, TX = 32, NV = TZ * TY * TX;     // 128
+  constexpr int ROWS = (TZ + 2) * (TY + 2);                      // 16 halo rows per channel
+  constexpr int DROW = NV + 8;                                   // bf16 elements per dy row
+  constexpr int XCH = ROWS * TX + 8;                             // bf16 elements per channel per copy
+  constexpr int XCPY = 32 * XCH;                                 // bf16 elements per shifted copy
+  constexpr int XITEMS = 32 * ROWS * 8;                          // (c, row, q) float4 items
+  constexpr int XPER = XITEMS / 256;                             // 16
+  __shared__ __attribute__((aligned(16))) HT dys[32 * DROW];
+  __shared__ __attribute__((aligned(16))) HT xs3[3 * XCPY];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32, split = blockIdx.z;
+  const int iHW = H * W, iDHW = D * H * W;
+
+  // this wave's taps: element offsets of (dx copy, dz/dy row shift) inside xs3
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(wave * 7 + t, 26);
+    toff[t] = (tap % 3) * XCPY + ((tap / 9) * (TY + 2) + (tap / 3) % 3) * TX;
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging roles
+  const int q = tid & 7;                 // float4 column of an x item
+  const int so = tid >> 3, sseg = tid & 7;  // dy: output channel, 16-voxel segment
+  const int sz = sseg >> 2, sy = (sseg >> 1) & 1, sxh = sseg & 1;
+
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+
+  f32x4 xr[XPER];
+  float xh[XPER];
+  f32x4 dr[4];
+  unsigned mrow, mhalo, mdy;  // validity bits applied at commit
+  auto fetch = [&](int tile) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles;
+    const int tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    const float* xn = x + (int64_t)n * xbs;
+    const float* dn = dy + (int64_t)n * ybs;
+    mrow = 0u;
+    mhalo = 0u;
+    const int hx = q == 0 ? x0 - 1 : x0 + TX;       // only lanes q == 0 / q == 7 use their halo value
+    const bool hx_ok = (q == 0 || q == 7) && hx >= 0 && hx < W;
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+      const int rowi = (tid >> 3) + 32 * k;          // (c, halo row) index, 512 in all
+      const int c = rowi / ROWS, rr = rowi - c * ROWS;
+      const int zz = rr / (TY + 2), yy = rr - zz * (TY + 2);
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
+      const bool rok = gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
+      const int base = gc * iDHW + gz * iHW + gy * W;
+      xr[k] = *reinterpret_cast<const f32x4*>(xn + (rok ? base + x0 + 4 * q : 0));
+      xh[k] = xn[(rok && hx_ok) ? base + hx : 0];
+      mrow |= rok ? (1u << k) : 0u;
+      mhalo |= (rok && hx_ok) ? (1u << k) : 0u;
+    }
+    const int gz = z0 + sz, gy = y0 + sy;
+    const bool dok = o0 + so < Cout && gz < D && gy < H;
+    const int dbase = dok ? (o0 + so) * iDHW + gz * iHW + gy * W + x0 + 16 * sxh : 0;
+    mdy = dok ? 1u : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dr[u] = *reinterpret_cast<const f32x4*>(dn + dbase + 4 * u);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+      const bool rok = (mrow >> k) & 1u;
+      f32x4 v = xr[k];
+      if (!rok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float hv = ((mhalo >> k) & 1u) ? xh[k] : 0.f;
+      // neighbours inside the 8-lane row group
+      float left = __shfl_up(v[3], 1, 64), right = __shfl_down(v[0], 1, 64);
+      if (q == 0) left = hv;
+      if (q == 7) right = hv;
+      const int rowi = (tid >> 3) + 32 * k;
+      const int c = rowi / ROWS, rr = rowi - c * ROWS;
+      HT* dst = xs3 + c * XCH + rr * TX + 4 * q;
+      using bf16x4 = typename H16<HT>::x4;
+      bf16x4 m1, m0, p1;
+      m1[0] = (HT)left; m1[1] = (HT)v[0]; m1[2] = (HT)v[1]; m1[3] = (HT)v[2];   // x - 1
+      m0[0] = (HT)v[0]; m0[1] = (HT)v[1]; m0[2] = (HT)v[2]; m0[3] = (HT)v[3];   // x
+      p1[0] = (HT)v[1]; p1[1] = (HT)v[2]; p1[2] = (HT)v[3]; p1[3] = (HT)right;  // x + 1
+      *reinterpret_cast<bf16x4*>(dst) = m1;
+      *reinterpret_cast<bf16x4*>(dst + XCPY) = m0;
+      *reinterpret_cast<bf16x4*>(dst + 2 * XCPY) = p1;
+    }
+    hx8 d0, d1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      d0[u] = (HT)(mdy ? dr[0][u] : 0.f);
+      d0[4 + u] = (HT)(mdy ? dr[1][u] : 0.f);
+      d1[u] = (HT)(mdy ? dr[2][u] : 0.f);
+      d1[4 + u] = (HT)(mdy ? dr[3][u] : 0.f);
+    }
+    HT* dd = dys + so * DROW + sseg * 16;
+    *reinterpret_cast<hx8*>(dd) = d0;
+    *reinterpret_cast<hx8*>(dd + 8) = d1;
+  };
+
+  if (split < ntiles) {
+    fetch(split);
+    commit();
+  }
+  __syncthreads();
+  const HT* ab = dys + l32 * DROW + 8 * half;
+  const HT* bb = xs3 + l32 * XCH + 8 * half;
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    if (more) fetch(tile + nsplit);
+#pragma unroll
+    for (int zy = 0; zy < TZ * TY; ++zy) {
+      const int z = zy / TY, yy = zy % TY;
+#pragma unroll
+      for (int xk = 0; xk < 2; ++xk) {
+        const hx8 a = *reinterpret_cast<const hx8*>(ab + zy * TX + 16 * xk);
+        const HT* brow = bb + (z * (TY + 2) + yy) * TX + 16 * xk;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+          const hx8 b = *reinterpret_cast<const hx8*>(brow + toff[t]);
+          acc[t] = H16<HT>::mfma(a, b, acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) commit();
+    __syncthreads();
+  }
+  float* sl = slab + (int64_t)split * Cout * Cin * 27;
+  const int c = c0 + l32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave * 7 + t;
+    if (tap < 27 && c < Cin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
+      }
+    }
+  }
+}
+
+
+int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
+                   int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
+                   hipStream_t st) {
+  dim3 gb((unsigned)ctiles, (unsigned)otiles, (unsigned)nsplit);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<__bf16>, gb, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, tz2,
+                       ty2, tx2, nsplit, xbs, ybs);
+  else
+    hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<_Float16>, gb, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W,
+                       tz2, ty2, tx2, nsplit, xbs, ybs);
+  return check_launch("conv3_mfma_bww_h16");
+}
+
+}  // namespace m355

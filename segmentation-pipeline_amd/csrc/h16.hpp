@@ -1,0 +1,45 @@
+// 16-bit operand types of the bf16 / fp16 compute modes (M355_COMPUTE_BF16 / M355_COMPUTE_F16) and the
+// "c8" activation layout they read:
+//
+//   x16[n][cb][s][8]    cb = channel block (channels 8*cb .. 8*cb+7, zero-padded past C), s = voxel (D*H*W)
+//
+// i.e. the 8 channels of a voxel are one aligned 16-byte item.  That item IS the MFMA operand fragment of
+// v_mfma_f32_32x32x16_{bf16,f16} for a lane (voxel, k-half), so the convolution kernels move 16 bytes per
+// lane from HBM to LDS to the matrix core without touching them, a tap shift is a whole-item offset, and a
+// channel slice of a concat buffer that starts at a multiple of 8 channels is a contiguous run of blocks.
+#pragma once
+#include "common.hpp"
+
+namespace m355 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename HT>
+struct H16;
+template <>
+struct H16<__bf16> {
+  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct H16<_Float16> {
+  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+static inline int64_t c8_blocks(int64_t C) { return (C + 7) / 8; }
+
+// fp32 NCDHW -> c8 (round to nearest even) and back; implemented in conv3d_h16.hip
+int launch_pack_act16(const float* x, void* x16, int N, int C, int64_t S, int64_t xbs, int64_t x16bs, int compute,
+                      hipStream_t st);
+int launch_unpack_act16(const void* x16, float* x, int N, int C, int64_t S, int64_t x16bs, int64_t xbs, int compute,
+                        hipStream_t st);
+
+}  // namespace m355

@@ -85,6 +85,64 @@ class RawOps:
                                         self._stream()), "conv3d_fwd")
         return y
 
+    # ---- c8 tensors of the 16-bit compute modes (HIP library only; dtype: 1 = bf16, 2 = fp16) ----
+    def act16_pack(self, x, compute, pad_batch=0):
+        """fp32 [N,C,D,H,W] -> c8 tensor (torch 16-bit dtype, shape [N, CB (+pad), S, 8]); pad_batch > 0 leaves
+        that many unused channel blocks per sample (a non-dense batch stride)."""
+        x = self.to(x)
+        N, Cc = x.shape[:2]
+        S = x[0, 0].numel()
+        CB = (Cc + 7) // 8
+        dt = torch.bfloat16 if compute == 1 else torch.float16
+        x16 = torch.full((N, CB + pad_batch, S, 8), 7.0, dtype=dt, device=self.device)
+        self._chk(self.fn("act16_pack")(_p(x), _p(x16), N, Cc, S, 0, (CB + pad_batch) * S * 8, compute, self._stream()),
+                  "act16_pack")
+        return x16
+
+    def act16_unpack(self, x16, Cc, spatial, compute):
+        N, CBp, S, _ = x16.shape
+        x = self.empty(N, Cc, *spatial)
+        self._chk(self.fn("act16_unpack")(_p(x16), _p(x), N, Cc, S, CBp * S * 8, 0, compute, self._stream()), "act16_unpack")
+        return x
+
+    def conv3d_fwd_h16(self, x16, Cin, spatial, w, bias=None, add=None, compute=1, groups=None, eps=1e-5):
+        """forward on a c8 input; groups != None also returns the fused statistics (mean, rstd)"""
+        w, bias, add = map(self.to, (w, bias, add))
+        N, CBp, S, _ = x16.shape
+        Cout = w.shape[0]
+        d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 3, 1, 1, compute=compute)
+        y = self.empty(N, Cout, *spatial)
+        n = self.lib.m355_conv3d_h16_workspace(C.byref(d), 0)
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        part = None
+        if groups is not None:
+            slots = self.fn("conv3d_stats_slots")(C.byref(d))
+            assert slots > 0
+            part = self.empty(N, slots, Cout, 2)
+        self._chk(self.fn("conv3d_fwd_h16")(C.byref(d), _p(x16), CBp * S * 8, _p(w), _p(bias), _p(add), _p(y), _p(part),
+                                            _p(ws), ws.numel(), self._stream()), "conv3d_fwd_h16")
+        if groups is None:
+            return y
+        nd = NormDesc(N, Cout, S, groups, 0, eps, 0.01, 0, 0, 0)
+        ns = self.fn("norm_num_stats")(C.byref(nd))
+        mean, rstd = self.empty(ns), self.empty(ns)
+        nws = self._ws("norm_workspace", nd)
+        self._chk(self.fn("norm_stats_from_partials")(C.byref(nd), _p(part), slots, _p(mean), _p(rstd), None, None,
+                                                      0.1, _p(nws), nws.numel(), self._stream()),
+                  "norm_stats_from_partials")
+        return y, mean, rstd
+
+    def conv3d_bwd_data_h16(self, dy16, Cout, w, x_shape, compute=1):
+        w = self.to(w)
+        N, CBp, S, _ = dy16.shape
+        d = self.conv_desc(x_shape, Cout, 3, 1, 1, compute=compute)
+        dx = self.empty(*x_shape)
+        n = self.lib.m355_conv3d_h16_workspace(C.byref(d), 1)
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("conv3d_bwd_data_h16")(C.byref(d), _p(dy16), CBp * S * 8, _p(w), _p(dx), _p(ws), ws.numel(),
+                                                 self._stream()), "conv3d_bwd_data_h16")
+        return dx
+
     def conv3d_fwd_stats(self, x, w, bias=None, groups=0, eps=1e-5):
         """fused conv + statistics: returns (y, mean, rstd) of the normalisation that follows the conv, or
         None when this backend has no fused statistics for the shape"""

@@ -363,6 +363,57 @@ def test_conv3d_bf16_compute_mode(hip, oracle, case, compute):
           "bf16 bwd_data vs bf16 oracle")
 
 
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_act16_pack_unpack_roundtrip(hip, compute):
+    """fp32 NCDHW <-> c8 ([N][C/8][voxel][8] 16-bit): rounding == torch's cast (RNE, pinned for the oracle in
+    test_c_operand_rounding_matches_torch_casts), channel counts that are no multiple of 8 are zero-padded,
+    a non-dense batch stride leaves the gap untouched."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    for (N, Cc, D, H, W, pad) in [(1, 8, 3, 4, 5, 0), (2, 13, 4, 6, 7, 2), (1, 3, 2, 2, 33, 0)]:
+        x = rnd(N, Cc, D, H, W, seed=N + Cc) * 3.0
+        x16 = hip.act16_pack(x, compute, pad_batch=pad)
+        S, CB = D * H * W, (Cc + 7) // 8
+        ref = torch.zeros(N, CB * 8, S)
+        ref[:, :Cc] = x.reshape(N, Cc, S).to(dt).float()
+        got = x16[:, :CB].float().cpu().permute(0, 1, 3, 2).reshape(N, CB * 8, S)
+        assert torch.equal(got, ref)
+        if pad:
+            assert (x16[:, CB:].float() == 7.0).all()
+        assert torch.equal(hip.act16_unpack(x16, Cc, (D, H, W), compute).cpu(), x.to(dt).float())
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}, {"M355_CONV_SLOTS": "3", "M355_CONV_KSPLIT": "2"},
+                                 {"M355_CONV_NTW": "1"}, {"M355_CONV_NTW": "2", "M355_CONV_SLOTS": "7"}])
+def test_conv3d_h16_c8_input_persistent_and_fused_statistics(hip, oracle, compute, env, tuning):
+    """m355_conv3d_fwd_h16 / m355_conv3d_bwd_data_h16 on c8 tensors (the model path of the 16-bit modes): equal to
+    the oracle run with operands rounded to the same 16-bit type (only the fp32 accumulation order differs);
+    ragged volumes, N = 2, odd channel-block counts, strided batches, tiny residencies (every workgroup walks
+    many queue items), split-K, and the statistics of the following normalisation fused into the epilogue."""
+    tuning(**{"M355_CONV_KSPLIT": 1, **env})  # the planner would split K on volumes this small: no fused statistics
+    for (N, ci, co, D, H, W, groups) in [(2, 12, 40, 9, 10, 36, 8), (1, 24, 33, 6, 21, 16, None), (1, 8, 8, 12, 9, 8, 0),
+                                        (1, 40, 16, 8, 8, 32, 4)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
+        x16 = hip.act16_pack(x, compute, pad_batch=1)
+        yo = oracle.conv3d_fwd(x, w, b, compute=compute)
+        split = "M355_CONV_KSPLIT" in env
+        if groups is None or split:
+            close(hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute), yo, 3e-5, 3e-5, "h16 fwd")
+        else:
+            y, mean, rstd = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute, groups=groups)
+            close(y, yo, 3e-5, 3e-5, "h16 fwd (stats variant)")
+            m2, r2 = hip.norm_stats(y, groups)[:2]
+            close(mean, m2, 1e-5, 1e-6, "fused mean")
+            close(rstd, r2, 1e-5, 1e-6, "fused rstd")
+        dy = rnd(N, co, D, H, W, seed=5)
+        dy16 = hip.act16_pack(dy, compute)
+        close(hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute),
+              oracle.conv3d_bwd_data(dy, w, x.shape, compute=compute), 3e-5, 3e-5, "h16 bwd_data")
+    # bit-reproducible regardless of which workgroup takes which item
+    a = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute)
+    assert torch.equal(a, hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute))
+
+
 def test_fp16_precision_mode_end_to_end(golden):
     """cfg5-family precision mode ("mixed fp16 with MFMA channel-GEMM path"): fp16 operands, fp32 accumulate,
     on the small north-star model: 10 mantissa bits, so closer to the fp32 golden than bf16 (5e-3 / 2e-4)."""

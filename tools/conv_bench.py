@@ -36,7 +36,7 @@ def main():
     ops = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd", "bwd_data", "bwd_weight"]
     layers = QUICK if "--quick" in sys.argv else CFG2
     hip = RawOps("hip")
-    compute = 1 if "--bf16" in sys.argv else 0
+    compute = 1 if "--bf16" in sys.argv else (2 if "--fp16" in sys.argv else 0)
     tot = {o: [0.0, 0.0] for o in ops}
     print(f"{'layer':8s} {'Cin':>4s} {'Cout':>4s} {'S':>4s} " + " ".join(f"{o + ' ms':>14s} {'TF':>6s}" for o in ops))
     for name, ci, co, sp in layers:
@@ -45,8 +45,14 @@ def main():
         dy = torch.randn(1, co, sp, sp, sp, device="cuda")
         flops = 2.0 * 27 * ci * co * sp ** 3
         row = f"{name:8s} {ci:4d} {co:4d} {sp:4d} "
+        if compute and ci > 4:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
+            x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
         for o in ops:
-            if o == "fwd":
+            if o == "fwd" and compute and ci > 4:
+                ms = timeit(lambda: hip.conv3d_fwd_h16(x16, ci, (sp, sp, sp), w, compute=compute))
+            elif o == "bwd_data" and compute and ci > 4:
+                ms = timeit(lambda: hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
+            elif o == "fwd":
                 ms = timeit(lambda: hip.conv3d_fwd(x, w, compute=compute))
             elif o == "bwd_data":
                 ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
