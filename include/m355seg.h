@@ -217,6 +217,16 @@ int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
                       const float* beta, float* dx, float* dgamma, float* dbeta,
                       int training, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The passes that WRITE c8 tensors in the 16-bit modes (so that conv -> norm/act -> conv never converts):
+ * m355_norm_act_fwd with a c8 output y16 (the layout transposer: reads the fp32 NCDHW conv output) and,
+ * when y != NULL, the usual fp32 NCDHW output as well (desc->y_batch_stride) for non-conv consumers;
+ * nn.AvgPool3d(2, 2) (models/modular_unet.py:22,41,64,92) c8 -> c8 (fp32 sums, one rounding). */
+int m355_norm_act_fwd_h16(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, const float* add, float* y, void* y16,
+                          int64_t y16_batch_stride, int32_t compute, void* stream);
+int m355_avgpool3d_2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                              int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
+
 /* --------------------------------------------------------------- pooling
  * nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False)
  * (models/modular_unet.py:22,41,64,92).  Input D,H,W must be even.

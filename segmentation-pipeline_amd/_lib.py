@@ -55,6 +55,8 @@ SIGNATURES = {
     "m355_conv3d_h16_workspace": (_sz, [_CD, _i32]),
     "m355_conv3d_fwd_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _sz, _P]),
+    "m355_norm_act_fwd_h16": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _P]),
+    "m355_avgpool3d_2x_fwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_conv3d_plan": (C.c_int, [_CD, _i32, C.POINTER(C.c_int32)]),
     "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
     "m355_conv3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),

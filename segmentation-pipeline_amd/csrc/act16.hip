@@ -1,0 +1,154 @@
+// HBM-bound passes of the 16-bit compute modes that WRITE the c8 activation layout (h16.hpp) the
+// convolution kernels read: the normalise + activation pass after a convolution is the layout
+// transposer (it already owns one full read + write of the tensor), the 2x2x2 average pool works c8 -> c8.
+//
+// Reference ops replaced: normalization_class + activation_class inside Block3d
+// (models/components.py:52-55, + the residual sum :67-68) and nn.AvgPool3d(2, 2)
+// (models/modular_unet.py:22,41,64,92), for the data flow conv -> norm/act -> conv under BASELINE cfg3 / cfg5.
+#include "h16.hpp"
+
+namespace m355 {
+
+__device__ __forceinline__ float act16_fwd(float v, int act, float slope) {
+  if (act == M355_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == M355_ACT_LEAKY_RELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+
+// grid: (chunks over S, channel blocks, N).  x: fp32 NCDHW conv output; y16: c8; y32 (may be null): fp32
+// NCDHW copy for consumers that are not convolutions.  One thread = one voxel x 8 channels: eight plane
+// reads (each 256 B contiguous per wave), one 16-byte store.
+template <typename HT>
+__global__ __launch_bounds__(256) void norm_act_fwd_c8_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ add,
+    float* __restrict__ y32, HT* __restrict__ y16, int C, int64_t S, int groups, int act, float slope, int64_t xbs,
+    int64_t y32bs, int64_t abs_, int64_t y16bs) {
+  using hx8 = typename H16<HT>::x8;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const int c0 = cb * 8, nc = min(8, C - c0);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(c0 + j, C - 1);
+    const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+    const float m = mean[s], r = rstd[s];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    sc[j] = r * g;
+    sh[j] = b - m * sc[j];  // same expression as norm_act_fwd_kernel
+  }
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c0 * S;
+  const float* ap = add ? add + (int64_t)n * abs_ + (int64_t)c0 * S : nullptr;
+  float* yp = y32 ? y32 + (int64_t)n * y32bs + (int64_t)c0 * S : nullptr;
+  hx8* dst = reinterpret_cast<hx8*>(y16 + (int64_t)n * y16bs) + (int64_t)cb * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = j < nc ? xp[(int64_t)j * S + i] : 0.f;
+    if (ap) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = j < nc ? ap[(int64_t)j * S + i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act16_fwd(fmaf(v[j], sc[j], sh[j]), act, slope) + a[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act16_fwd(fmaf(v[j], sc[j], sh[j]), act, slope);
+    }
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (HT)(j < nc ? v[j] : 0.f);
+    dst[i] = o;
+    if (yp) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nc) yp[(int64_t)j * S + i] = v[j];
+    }
+  }
+}
+
+// c8 -> c8 average pool: one thread per output voxel and channel block; the 2x2x2 window is four 32-byte
+// runs (two x-adjacent items each).  Sums in fp32 in torch's (z, y, x) order, one rounding at the end.
+template <typename HT>
+__global__ __launch_bounds__(256) void avgpool2_c8_kernel(const HT* __restrict__ x16, HT* __restrict__ y16, int CB,
+                                                          int D, int H, int W, int64_t xbs, int64_t ybs, int N) {
+  using hx8 = typename H16<HT>::x8;
+  const int OD = D / 2, OH = H / 2, OW = W / 2;
+  const int64_t OS = (int64_t)OD * OH * OW, S = (int64_t)D * H * W;
+  const int64_t total = (int64_t)N * CB * OS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t ov = i % OS;
+    const int64_t r = i / OS;
+    const int cb = (int)(r % CB), n = (int)(r / CB);
+    const int ox = (int)(ov % OW), oy = (int)((ov / OW) % OH), oz = (int)(ov / ((int64_t)OW * OH));
+    const hx8* src = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs) + (int64_t)cb * S;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const hx8 v = src[((int64_t)(2 * oz + (q >> 2)) * H + 2 * oy + ((q >> 1) & 1)) * W + 2 * ox + (q & 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = q == 0 ? (float)v[j] : acc[j] + (float)v[j];
+    }
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (HT)(acc[j] * 0.125f);
+    (reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs) + (int64_t)cb * OS)[ov] = o;
+  }
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_norm_act_fwd_h16(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, const float* add, float* y,
+                                     void* y16, int64_t y16_batch_stride, int32_t compute, void* stream) {
+  M355_REQUIRE(d && x && mean && rstd && y16, M355_EINVALID_ARG, "norm_act_fwd_h16: null pointer");
+  M355_REQUIRE(d->N > 0 && d->C > 0 && d->S > 0 && d->N <= 65535 && c8_blocks(d->C) <= 65535, M355_EINVALID_ARG,
+               "norm_act_fwd_h16: bad shape");
+  M355_REQUIRE(d->groups >= 0 && (d->groups == 0 || d->C % d->groups == 0), M355_EINVALID_ARG,
+               "norm_act_fwd_h16: C=%d not divisible by groups=%d", d->C, d->groups);
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "norm_act_fwd_h16: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  const int64_t CS = (int64_t)d->C * d->S;
+  const int64_t xbs = dense_or(d->x_batch_stride, CS), ybs = dense_or(d->y_batch_stride, CS);
+  const int64_t abs_ = dense_or(d->add_batch_stride, CS);
+  const int64_t y16bs = dense_or(y16_batch_stride, c8_blocks(d->C) * d->S * 8);
+  M355_REQUIRE(((uintptr_t)y16 & 15) == 0 && y16bs % 8 == 0, M355_EINVALID_ARG, "norm_act_fwd_h16: c8 tensor not 16B aligned");
+  dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * 2), 2048)), (unsigned)c8_blocks(d->C),
+            (unsigned)d->N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(norm_act_fwd_c8_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
+                       beta, add, y, (__bf16*)y16, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_, y16bs);
+  else
+    hipLaunchKernelGGL(norm_act_fwd_c8_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
+                       beta, add, y, (_Float16*)y16, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_, y16bs);
+  return check_launch("norm_act_fwd_h16");
+}
+
+extern "C" int m355_avgpool3d_2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H,
+                                         int32_t W, int64_t x16_batch_stride, int64_t y16_batch_stride,
+                                         int32_t compute, void* stream) {
+  M355_REQUIRE(x16 && y16, M355_EINVALID_ARG, "avgpool3d_2x_fwd_h16: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, M355_EINVALID_ARG, "avgpool3d_2x_fwd_h16: bad shape");
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED,
+               "avgpool3d_2x_fwd_h16: odd spatial size (%d,%d,%d)", D, H, W);
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "avgpool3d_2x_fwd_h16: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  const int CB = (int)c8_blocks(C);
+  const int64_t S = (int64_t)D * H * W;
+  const int64_t xbs = dense_or(x16_batch_stride, CB * S * 8), ybs = dense_or(y16_batch_stride, CB * (S / 8) * 8);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)y16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "avgpool3d_2x_fwd_h16: c8 tensor not 16B aligned");
+  const int64_t total = (int64_t)N * CB * (S / 8);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), 8192));
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(avgpool2_c8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x16,
+                       (__bf16*)y16, CB, D, H, W, xbs, ybs, N);
+  else
+    hipLaunchKernelGGL(avgpool2_c8_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x16, (_Float16*)y16, CB, D, H, W, xbs, ybs, N);
+  return check_launch("avgpool3d_2x_fwd_h16");
+}

@@ -193,24 +193,25 @@ def wants_batch_stats(norm):
     return isinstance(norm, nn.BatchNorm3d) and (norm.training or norm.running_mean is None)
 
 
-def run_norm_act(norm, act, x, add=None, out=None, stats=None):
+def run_norm_act(norm, act, x, add=None, out=None, stats=None, c8=0):
     """normalization + activation (+ residual add) through the fused HIP passes.  `stats`: partial
-    sums emitted by the conv that produced `x` (saves the statistics pass over x)."""
+    sums emitted by the conv that produced `x` (saves the statistics pass over x).  `c8`: 16-bit compute
+    code -> the result is written only in the c8 layout the next convolution reads (ops.Act16)."""
     code, slope = _act_code(act)
     if norm is None:
         # activation only: identity statistics
         Cc = x.shape[1]
         cfg = ops.NormCfg(groups=0, eps=0.0, act=code, slope=slope, training=False,
                           running_mean=torch.zeros(Cc, device=x.device),
-                          running_var=torch.ones(Cc, device=x.device), out=out)
+                          running_var=torch.ones(Cc, device=x.device), out=out, c8=c8)
         return ops.norm_act(x, None, None, cfg, add=add)
     if isinstance(norm, nn.GroupNorm):
-        cfg = ops.NormCfg(groups=norm.num_groups, eps=norm.eps, act=code, slope=slope, out=out, stats=stats)
+        cfg = ops.NormCfg(groups=norm.num_groups, eps=norm.eps, act=code, slope=slope, out=out, stats=stats, c8=c8)
         return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
     if isinstance(norm, nn.InstanceNorm3d):
         if norm.track_running_stats:
             raise NotImplementedError("InstanceNorm3d(track_running_stats=True) has no HIP kernel")
-        cfg = ops.NormCfg(groups=x.shape[1], eps=norm.eps, act=code, slope=slope, out=out, stats=stats)
+        cfg = ops.NormCfg(groups=x.shape[1], eps=norm.eps, act=code, slope=slope, out=out, stats=stats, c8=c8)
         return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
     # BatchNorm3d: batch statistics in training mode (and whenever no running stats exist)
     training = norm.training or norm.running_mean is None
@@ -222,7 +223,7 @@ def run_norm_act(norm, act, x, add=None, out=None, stats=None):
     cfg = ops.NormCfg(groups=0, eps=norm.eps, act=code, slope=slope, training=training,
                       momentum=0.0 if momentum is None else momentum,
                       running_mean=norm.running_mean, running_var=norm.running_var, out=out,
-                      stats=stats if training else None)
+                      stats=stats if training else None, c8=c8)
     return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
 
 
@@ -282,10 +283,14 @@ class Block3d(nn.Module):
         if dropout_p != 0.0:
             self.dropout = nn.Dropout3d(p=dropout_p)
 
-    def forward(self, x, out: Optional[ops.OutSlot] = None):
+    def forward(self, x, out: Optional[ops.OutSlot] = None, c8_out: bool = False):
+        """`c8_out` (or an `out` slot of a c8 concat buffer): in a 16-bit precision mode under no_grad the
+        block's result is returned as an `ops.Act16`; the activations BETWEEN its convolutions always are."""
         res = run_conv(self.res_conv, x) if self.residual else None
         drop = self.dropout is not None and self.training and self.dropout.p > 0.0
         final_out = None if drop else out
+        flow = ops.h16_flow()
+        c8_out = bool(flow) and not drop and (c8_out or (out is not None and out.buf16 is not None))
 
         h = x
         for i in range(self._num_convs):
@@ -301,7 +306,8 @@ class Block3d(nn.Module):
                 # the conv epilogue emits the partial sums of the normalisation that follows
                 stats = {} if wants_batch_stats(norm) else None
                 h = run_conv(conv, h, stats=stats)
-                h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats)
+                c8 = flow if (not last or c8_out) else 0
+                h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats, c8=c8)
         if self._num_convs == 0 and res is not None:
             h = ops.add(res, h)
 

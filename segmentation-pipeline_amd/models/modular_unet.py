@@ -25,7 +25,7 @@ def _run_downsample(m, x):
             raise NotImplementedError("only AvgPool3d(kernel_size=2, stride=2) has a HIP kernel")
         return ops.avgpool3d_2x(x)
     if isinstance(m, BlurConv3d):
-        return m(x)
+        return m(ops.as_f32(x))
     if isinstance(m, nn.Conv3d):  # WSConv3d / strided nn.Conv3d
         return run_conv(m, x)
     raise NotImplementedError(f"downsample_class {type(m).__name__} has no HIP kernel")
@@ -137,22 +137,36 @@ class ModularUNet(nn.Module):
 
     def forward(self, x):
         f = self._filters
+        N, spatial = x.shape[0], tuple(x.shape[2:])
+        # 16-bit precision mode under no_grad: activations live only in the c8 layout the conv kernels read
+        # (ops.Act16); concat buffers are c8 buffers whose slots start at multiples of 8 channels
+        flow = ops.h16_flow()
+        ups = [_upsample_out_channels(self.upsampling[i], f[i + 1]) for i in range(self.depth - 1)]
+        if flow and any(c % 8 for c in list(f) + ups):
+            flow = 0
         skips = []
         for i in range(self.depth):
             if i != self.depth - 1:
                 # level-i concat buffer: [upsampled (f[i+1]) | skip (f[i])]
-                c_up = _upsample_out_channels(self.upsampling[i], f[i + 1])
-                buf = torch.empty((x.shape[0], c_up + f[i]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-                x = self.down_blocks[i](x, out=ops.OutSlot(buf, c_up, c_up + f[i]))
+                c_up = ups[i]
+                if flow:
+                    buf = ops.Act16.empty(N, c_up + f[i], spatial, flow, x.device)
+                    slot = ops.OutSlot(None, c_up, c_up + f[i], buf16=buf)
+                else:
+                    buf = torch.empty((N, c_up + f[i]) + spatial, dtype=torch.float32, device=x.device)
+                    slot = ops.OutSlot(buf, c_up, c_up + f[i])
+                x = self.down_blocks[i](x, out=slot)
                 skips.append((x, buf, c_up))
                 x = _run_downsample(self.downsampling[i], x)
+                spatial = tuple(x.shape[2:])
             else:
-                x = self.down_blocks[i](x)
+                x = self.down_blocks[i](x, c8_out=bool(flow))
 
         for i in reversed(range(self.depth - 1)):
             x_skip, buf, c_up = skips[i]
-            x_up = _run_upsample(self.upsampling[i], x, out=ops.OutSlot(buf, 0, c_up))
-            x = self.up_blocks[i](ops.Concat(buf, [x_up, x_skip]))
+            slot = ops.OutSlot(None, 0, c_up, buf16=buf) if flow else ops.OutSlot(buf, 0, c_up)
+            x_up = _run_upsample(self.upsampling[i], x, out=slot)
+            x = self.up_blocks[i](ops.Concat(buf, [x_up, x_skip]), c8_out=bool(flow))
 
         x = run_conv(self.out_conv, x)
-        return _run_hypothesis(self.hypothesis, x)
+        return _run_hypothesis(self.hypothesis, ops.as_f32(x))

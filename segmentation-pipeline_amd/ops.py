@@ -13,11 +13,14 @@ import torch
 from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 
-# Arithmetic of the 3x3x3 convolutions (forward and data gradient): "fp32" = exact fp32 MFMA
-# (default, the mode every 1e-4 parity claim refers to) or "bf16" = operands rounded to bf16 at
-# staging, fp32 accumulate (BASELINE cfg3 / cfg5 family).  Tensors stay fp32 in HBM either way and
-# the weight gradient always runs in exact fp32.
+# Arithmetic of the 3x3x3 convolutions: "fp32" = exact fp32 MFMA (default, the mode every 1e-4 parity
+# claim refers to), "bf16" / "fp16" = operands rounded to 16 bits, fp32 accumulate (BASELINE cfg3 / cfg5).
+# In the 16-bit modes the forward / data-gradient kernels read the c8 activation layout (include/m355seg.h);
+# the weight gradient takes the 16-bit MFMA kernel when W % 32 == 0 and both channel counts exceed 4, and
+# exact fp32 otherwise.  Under torch.no_grad() the activations between conv -> norm/act -> conv (-> pool)
+# live ONLY in c8 (`Act16`): no fp32 copy is written or read.
 _COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16}
+_DT16 = {_lib.COMPUTE_BF16: torch.bfloat16, _lib.COMPUTE_F16: torch.float16}
 _compute_mode = "fp32"
 
 
@@ -46,9 +49,14 @@ class precision:
         set_precision(self.prev)
 
 
-# Optional instrumentation used by bench.py: when set to a list, every conv
-# launch appends (tag, flops, start_event, end_event) recorded on the launch stream.
+# Optional instrumentation used by bench.py: when set to a list, every conv launch appends
+# (tag, flops, start_event, end_event, plan, algorithmic bytes) recorded on the launch stream.
 CONV_PROFILE: Optional[list] = None
+
+
+def _conv_bytes(N, Cin, Cout, voxels, taps, in_elem, out_elem):
+    """algorithmic HBM bytes of one conv launch: input once + output once + weights once"""
+    return float(N) * voxels * (Cin * in_elem + Cout * out_elem) + 4.0 * Cin * Cout * taps
 
 
 # ----------------------------------------------------------------- helpers
@@ -98,18 +106,24 @@ class OutSlot:
     CopySlices nodes) and return a fresh tensor aliasing the slice.
     """
 
-    def __init__(self, buf: torch.Tensor, c0: int, c1: int):
-        self.buf, self.c0, self.c1 = buf, c0, c1
+    def __init__(self, buf: Optional[torch.Tensor], c0: int, c1: int, buf16=None):
+        # buf16: the c8 twin of the buffer (an `Act16` spanning all its channels) in the 16-bit no-grad flow;
+        # `buf` may then be None (nothing is kept in fp32)
+        self.buf, self.c0, self.c1, self.buf16 = buf, c0, c1, buf16
 
     def view(self):
         return self.buf[:, self.c0:self.c1]
+
+    def act16(self):
+        return None if self.buf16 is None else self.buf16.slot(self.c0, self.c1)
 
 
 class Concat:
     """Channel concatenation of tensors that already live in adjacent slices of
     `buf` (models/modular_unet.py:97: torch.cat([x_up, x_skip], dim=1))."""
 
-    def __init__(self, buf: torch.Tensor, parts: Sequence[torch.Tensor]):
+    def __init__(self, buf, parts: Sequence):
+        # buf: the fp32 concat buffer, or an `Act16` (c8 flow of the 16-bit modes under no_grad)
         self.buf, self.parts = buf, list(parts)
         assert sum(p.shape[1] for p in self.parts) == buf.shape[1]
 
@@ -126,6 +140,106 @@ def _alloc_out(out: Optional[OutSlot], shape, like):
         raise _lib.M355Error(f"output slot shape {tuple(v.shape)} != op output shape {tuple(shape)}")
     # fresh tensor object aliasing the slice (see OutSlot)
     return torch.as_strided(out.buf, v.shape, v.stride(), v.storage_offset())
+
+
+# ----------------------------------------------------- c8 activations (16-bit modes)
+def h16_flow() -> int:
+    """The 16-bit compute code when activations should flow in the c8 layout (a 16-bit precision mode and
+    no autograd recording), else 0."""
+    c = _COMPUTE[_compute_mode]
+    return c if (c != _lib.COMPUTE_F32 and not torch.is_grad_enabled()) else 0
+
+
+class Act16:
+    """An activation in the c8 layout: `data` is [N, CB_total, S, 8] (bf16 / fp16); this activation
+    occupies the channel blocks [cb0, cb0 + ceil(C / 8)) of it (a slot of a concat buffer, or all of it)."""
+
+    def __init__(self, data: torch.Tensor, C: int, spatial, compute: int, cb0: int = 0):
+        self.data, self.C, self.spatial, self.compute, self.cb0 = data, int(C), tuple(spatial), compute, cb0
+
+    @staticmethod
+    def empty(N, C, spatial, compute, device):
+        S = spatial[0] * spatial[1] * spatial[2]
+        return Act16(torch.empty((N, (C + 7) // 8, S, 8), dtype=_DT16[compute], device=device), C, spatial, compute)
+
+    @property
+    def shape(self):
+        return (self.data.shape[0], self.C) + self.spatial
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def S(self):
+        return self.data.shape[2]
+
+    def ptr(self):
+        return C.c_void_p(self.data.data_ptr() + self.cb0 * self.S * 16)
+
+    def batch_stride(self):
+        return self.data.shape[1] * self.S * 8
+
+    def slot(self, c0, c1):
+        if c0 % 8:
+            raise _lib.M355Error(f"a c8 slot must start at a multiple of 8 channels (got {c0})")
+        return Act16(self.data, c1 - c0, self.spatial, self.compute, self.cb0 + c0 // 8)
+
+    def to_f32(self):
+        N = self.data.shape[0]
+        x = torch.empty((N, self.C) + self.spatial, dtype=torch.float32, device=self.device)
+        check(_lib.lib().m355_act16_unpack(self.ptr(), _p(x), N, self.C, self.S, self.batch_stride(), 0, self.compute,
+                                           _stream()), "act16_unpack")
+        return x
+
+
+def pack_act16(x: torch.Tensor, compute: int, out: Optional[Act16] = None) -> Act16:
+    """fp32 NCDHW tensor -> c8 (into `out`, a slot of matching shape, or a fresh buffer)."""
+    _require(x)
+    x, xbs = _dense_channels(x)
+    N, Cc = x.shape[:2]
+    if out is None:
+        out = Act16.empty(N, Cc, x.shape[2:], compute, x.device)
+    elif out.shape != tuple(x.shape):
+        raise _lib.M355Error(f"c8 slot shape {out.shape} != tensor shape {tuple(x.shape)}")
+    check(_lib.lib().m355_act16_pack(_p(x), out.ptr(), N, Cc, out.S, xbs, out.batch_stride(), compute, _stream()),
+          "act16_pack")
+    return out
+
+
+def as_f32(x):
+    """fp32 NCDHW view of an activation (c8 activations are converted: the fallback for ops without a c8 kernel)."""
+    return x.to_f32() if isinstance(x, Act16) else x
+
+
+def _conv3d_act16(x16: Act16, weight, bias, add, stats):
+    """3x3x3 / s1 / p1 forward on a c8 input (no autograd: the c8 flow only exists under no_grad)."""
+    L = _lib.lib()
+    _require(weight, bias, add)
+    weight = weight.contiguous()
+    N, Cin, D, H, W = x16.shape
+    Cout = weight.shape[0]
+    y = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x16.device)
+    if add is not None:
+        add = add.contiguous()
+    d = _conv_desc(N, Cin, Cout, D, H, W, 3, 1, 1, 0, 0, compute=x16.compute)
+    ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0), x16.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    part = None
+    slots = L.m355_conv3d_stats_slots(C.byref(d)) if stats is not None else 0
+    if slots > 0:
+        part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x16.device)
+        stats["partials"], stats["slots"] = part, slots
+    check(L.m355_conv3d_fwd_h16(C.byref(d), x16.ptr(), x16.batch_stride(), _p(weight), _p(bias), _p(add), _p(y),
+                                _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16")
+    if prof is not None:
+        e1.record()
+        prof.append(("conv3d_fwd", 2.0 * 27 * Cin * Cout * N * D * H * W, e0, e1, conv_plan(d, 0),
+                     _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 4)))
+    return y
 
 
 # ------------------------------------------------------------------ conv3d
@@ -191,7 +305,8 @@ class _Conv3dFn(torch.autograd.Function):
         if prof is not None:
             e1.record()
             flops = 2.0 * k ** 3 * Cin * Cout * N * oshape[2] * oshape[3] * oshape[4]
-            prof.append(("conv3d_fwd", flops, e0, e1, conv_plan(d, 0)))
+            prof.append(("conv3d_fwd", flops, e0, e1, conv_plan(d, 0),
+                         _conv_bytes(N, Cin, Cout, oshape[2] * oshape[3] * oshape[4], k ** 3, 4, 4)))
         ctx.meta, ctx.desc = meta, d
         ctx.has_bias, ctx.has_add = bias is not None, add is not None
         ctx.part_channels = [p.shape[1] for p in parts]
@@ -223,7 +338,9 @@ class _Conv3dFn(torch.autograd.Function):
                                            _stream()), "conv3d_bwd_weight")
             if prof is not None:
                 e1.record()
-                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1, None))
+                vox = dy.shape[2] * dy.shape[3] * dy.shape[4]
+                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * vox, e0, e1, None,
+                             _conv_bytes(d.N, d.Cin, d.Cout, vox, d.k ** 3, 4, 4)))
         if need_x:
             # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part
             dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
@@ -236,7 +353,9 @@ class _Conv3dFn(torch.autograd.Function):
                                          _stream()), "conv3d_bwd_data")
             if prof is not None:
                 e1.record()
-                prof.append(("conv3d_bwd_data", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * dy.shape[2] * dy.shape[3] * dy.shape[4], e0, e1, conv_plan(dd, 1)))
+                vox = dy.shape[2] * dy.shape[3] * dy.shape[4]
+                prof.append(("conv3d_bwd_data", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * vox, e0, e1, conv_plan(dd, 1),
+                             _conv_bytes(d.N, d.Cin, d.Cout, vox, d.k ** 3, 4, 4)))
             c0 = 0
             for i, cc in enumerate(ctx.part_channels):
                 if ctx.needs_input_grad[4 + i]:
@@ -256,6 +375,14 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
     k = weight.shape[2]
     if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
         raise NotImplementedError("only cubic kernels are supported")
+    if isinstance(x, Concat) and isinstance(x.buf, Act16):
+        x = x.buf
+    if out is not None and out.buf16 is not None:   # c8 flow: the destination slot only exists in c8
+        return pack_act16(conv3d(x, weight, bias, add, stride, padding, None, stats), out.buf16.compute, out.act16())
+    if isinstance(x, Act16):
+        if k == 3 and stride == 1 and padding == 1:
+            return _conv3d_act16(x, weight, bias, add, stats)
+        x = x.to_f32()
     if isinstance(x, Concat):
         meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats)
         return _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
@@ -312,6 +439,9 @@ class _ConvT3dFn(torch.autograd.Function):
 def conv_transpose3d(x, weight, bias=None, stride=2, padding=0, output_padding=0, out: Optional[OutSlot] = None):
     """nn.ConvTranspose3d forward (cubic kernel, weight [Cin, Cout, k, k, k])."""
     k = weight.shape[2]
+    if isinstance(x, Act16):
+        y = _ConvT3dFn.apply(x.to_f32(), weight, bias, (k, stride, padding, output_padding, None))
+        return _into_c8_slot(y, out, x.compute)
     return _ConvT3dFn.apply(x, weight, bias, (k, stride, padding, output_padding, out))
 
 
@@ -328,6 +458,59 @@ class NormCfg:
     running_var: Optional[torch.Tensor] = None
     out: Optional[OutSlot] = None
     stats: Optional[dict] = None   # partial sums from the producing conv (ops.conv3d(..., stats=...))
+    c8: int = 0                    # 16-bit no-grad flow: emit the result ONLY in the c8 layout (compute code)
+
+
+def _norm_statistics(L, d, x, cfg, N, Cc):
+    """mean / rstd of the normalisation: from the conv epilogue partials, from x, or from BN running stats."""
+    ns = L.m355_norm_num_stats(C.byref(d))
+    mean = torch.empty(ns, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
+    use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
+    fused = cfg.stats.get("partials") if cfg.stats else None
+    if fused is not None and tuple(fused.shape) != (N, cfg.stats["slots"], Cc, 2):
+        raise _lib.M355Error(f"norm_act: statistics partials {tuple(fused.shape)} do not belong to this tensor")
+    upd = cfg.groups == 0 and cfg.training and use_batch
+    if use_batch and fused is not None:
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+        check(L.m355_norm_stats_from_partials(C.byref(d), _p(fused), int(cfg.stats["slots"]), _p(mean), _p(rstd),
+                                              _p(cfg.running_mean) if upd else None,
+                                              _p(cfg.running_var) if upd else None,
+                                              float(cfg.momentum), _p(ws), ws.numel(), _stream()),
+              "norm_stats_from_partials")
+    elif use_batch:
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+        check(L.m355_norm_stats(C.byref(d), _p(x), _p(mean), _p(rstd),
+                                _p(cfg.running_mean) if upd else None,
+                                _p(cfg.running_var) if upd else None,
+                                float(cfg.momentum), _p(ws), ws.numel(), _stream()), "norm_stats")
+    else:
+        check(L.m355_norm_stats_from_running(C.byref(d), _p(cfg.running_mean), _p(cfg.running_var),
+                                             _p(mean), _p(rstd), _stream()), "norm_stats_from_running")
+    return mean, rstd, use_batch
+
+
+def _norm_act_c8(x, gamma, beta, add, cfg: NormCfg) -> Act16:
+    """norm + activation (+ residual) whose ONLY output is c8 (16-bit no-grad flow): reads the fp32 conv
+    output once, writes 2 bytes per element."""
+    L = _lib.lib()
+    _require(x, gamma, beta, add)
+    x, xbs = _dense_channels(x)
+    N, Cc = x.shape[0], x.shape[1]
+    S = x.shape[2] * x.shape[3] * x.shape[4]
+    abs_ = 0
+    if add is not None:
+        add, abs_ = _dense_channels(add)
+    out16 = cfg.out.act16() if cfg.out is not None else None
+    if out16 is None:
+        out16 = Act16.empty(N, Cc, x.shape[2:], cfg.c8, x.device)
+    elif out16.shape != tuple(x.shape):
+        raise _lib.M355Error(f"c8 slot shape {out16.shape} != op output shape {tuple(x.shape)}")
+    d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, 0, abs_)
+    mean, rstd, _ = _norm_statistics(L, d, x, cfg, N, Cc)
+    check(L.m355_norm_act_fwd_h16(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), None,
+                                  out16.ptr(), out16.batch_stride(), cfg.c8, _stream()), "norm_act_fwd_h16")
+    return out16
 
 
 class _NormActFn(torch.autograd.Function):
@@ -346,31 +529,7 @@ class _NormActFn(torch.autograd.Function):
         if add is not None:
             add, abs_ = _dense_channels(add)
         d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs, abs_)
-        ns = L.m355_norm_num_stats(C.byref(d))
-        mean = torch.empty(ns, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
-        use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
-        fused = cfg.stats.get("partials") if cfg.stats else None
-        if fused is not None and tuple(fused.shape) != (N, cfg.stats["slots"], Cc, 2):
-            raise _lib.M355Error(f"norm_act: statistics partials {tuple(fused.shape)} do not belong to this tensor")
-        if use_batch and fused is not None:
-            upd = cfg.groups == 0 and cfg.training
-            ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
-            check(L.m355_norm_stats_from_partials(C.byref(d), _p(fused), int(cfg.stats["slots"]), _p(mean), _p(rstd),
-                                                  _p(cfg.running_mean) if upd else None,
-                                                  _p(cfg.running_var) if upd else None,
-                                                  float(cfg.momentum), _p(ws), ws.numel(), _stream()),
-                  "norm_stats_from_partials")
-        elif use_batch:
-            ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
-            upd = cfg.groups == 0 and cfg.training
-            check(L.m355_norm_stats(C.byref(d), _p(x), _p(mean), _p(rstd),
-                                    _p(cfg.running_mean) if upd else None,
-                                    _p(cfg.running_var) if upd else None,
-                                    float(cfg.momentum), _p(ws), ws.numel(), _stream()), "norm_stats")
-        else:
-            check(L.m355_norm_stats_from_running(C.byref(d), _p(cfg.running_mean), _p(cfg.running_var),
-                                                 _p(mean), _p(rstd), _stream()), "norm_stats_from_running")
+        mean, rstd, use_batch = _norm_statistics(L, d, x, cfg, N, Cc)
         check(L.m355_norm_act_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
                                   _stream()), "norm_act_fwd")
         ctx.desc, ctx.batch_stats, ctx.has_add = d, use_batch, add is not None
@@ -398,8 +557,11 @@ class _NormActFn(torch.autograd.Function):
 
 def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
     """normalization_class + activation_class of Block3d (components.py:52-55), optionally
-    fused with the residual sum (components.py:67-68): act(norm(x)) + add."""
-    return _NormActFn.apply(x, gamma, beta, add, cfg)
+    fused with the residual sum (components.py:67-68): act(norm(x)) + add.  With `cfg.c8` set (16-bit
+    precision mode under no_grad) the result is an `Act16` and nothing is written in fp32."""
+    if cfg.c8 and not torch.is_grad_enabled():
+        return _norm_act_c8(as_f32(x), gamma, beta, as_f32(add) if add is not None else None, cfg)
+    return _NormActFn.apply(as_f32(x), gamma, beta, as_f32(add) if add is not None else None, cfg)
 
 
 # ------------------------------------------------------------- pool / upsample
@@ -427,7 +589,15 @@ class _AvgPoolFn(torch.autograd.Function):
 
 
 def avgpool3d_2x(x, out: Optional[OutSlot] = None):
-    """nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False)"""
+    """nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False); c8 -> c8 in the 16-bit no-grad flow."""
+    if isinstance(x, Act16):
+        N, Cc, D, H, W = x.shape
+        y16 = out.act16() if out is not None else None
+        if y16 is None:
+            y16 = Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        check(_lib.lib().m355_avgpool3d_2x_fwd_h16(x.ptr(), y16.ptr(), N, Cc, D, H, W, x.batch_stride(),
+                                                   y16.batch_stride(), x.compute, _stream()), "avgpool3d_2x_fwd_h16")
+        return y16
     return _AvgPoolFn.apply(x, out)
 
 
@@ -456,8 +626,16 @@ class _UpsampleFn(torch.autograd.Function):
         return dx, None
 
 
+def _into_c8_slot(y32, out: Optional[OutSlot], compute):
+    """c8 flow: a producer without a c8 epilogue (conv-transpose, trilinear upsampling) computed `y32`
+    densely; pack it into its slot of the c8 concat buffer."""
+    return pack_act16(y32, compute, out.act16() if out is not None else None)
+
+
 def upsample_trilinear2x(x, out: Optional[OutSlot] = None):
     """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)"""
+    if isinstance(x, Act16):
+        return _into_c8_slot(_UpsampleFn.apply(x.to_f32(), None), out, x.compute)
     return _UpsampleFn.apply(x, out)
 
 
@@ -490,7 +668,7 @@ class _SoftmaxFn(torch.autograd.Function):
 
 def softmax_channels(x, inner=1, diag_bias=0.0):
     """nn.Softmax(dim=1); inner=C gives StochasticMatrix's reshape+eye-bias+softmax."""
-    return _SoftmaxFn.apply(x, inner, diag_bias)
+    return _SoftmaxFn.apply(as_f32(x), inner, diag_bias)
 
 
 # ----------------------------------------------------------------------- loss
@@ -563,7 +741,7 @@ class _ChannelScaleFn(torch.autograd.Function):
 
 def channel_scale(x, scale):
     """y[n,c,...] = x[n,c,...] * scale[n,c]  (Dropout3d with a pre-drawn mask)."""
-    return _ChannelScaleFn.apply(x, scale.contiguous().view(-1))
+    return _ChannelScaleFn.apply(as_f32(x), scale.contiguous().view(-1))
 
 
 class _AddFn(torch.autograd.Function):
@@ -582,7 +760,7 @@ class _AddFn(torch.autograd.Function):
 
 
 def add(a, b):
-    return _AddFn.apply(a, b)
+    return _AddFn.apply(as_f32(a), as_f32(b))
 
 
 class _CopyIntoFn(torch.autograd.Function):
@@ -607,7 +785,9 @@ class _CopyIntoFn(torch.autograd.Function):
 
 
 def copy_into(x, out: OutSlot):
-    return _CopyIntoFn.apply(x, out)
+    if out.buf16 is not None:   # c8 flow: the slot lives in the c8 twin of the concat buffer
+        return pack_act16(as_f32(x), out.buf16.compute, out.act16())
+    return _CopyIntoFn.apply(as_f32(x), out)
 
 
 class _S2DFn(torch.autograd.Function):
@@ -648,11 +828,13 @@ class _S2DFn(torch.autograd.Function):
 
 def space_to_depth2(x):
     """[N, C, D, H, W] -> [N, 8C, D/2, H/2, W/2], channel c*8 + (pz*4 + py*2 + px)."""
-    return _S2DFn.apply(x, True, None)
+    return _S2DFn.apply(as_f32(x), True, None)
 
 
 def depth_to_space2(x, out: Optional[OutSlot] = None):
-    return _S2DFn.apply(x, False, out)
+    if out is not None and out.buf16 is not None:
+        return pack_act16(_S2DFn.apply(as_f32(x), False, None), out.buf16.compute, out.act16())
+    return _S2DFn.apply(as_f32(x), False, out)
 
 
 class _BlurWeightFn(torch.autograd.Function):

@@ -247,6 +247,28 @@ class RawOps:
                                           _p(y), self._stream()), "norm_act_fwd")
         return y
 
+    def norm_act_fwd_h16(self, x, mean, rstd, gamma, beta, groups, act, compute, add=None, want_f32=False, eps=1e-5,
+                         slope=0.01):
+        """c8 output (torch 16-bit tensor [N, CB, S, 8]) and optionally the fp32 NCDHW output as well"""
+        x, mean, rstd, gamma, beta, add = map(self.to, (x, mean, rstd, gamma, beta, add))
+        d = self.norm_desc(x, groups, act, eps, slope)
+        N, Cc = x.shape[:2]
+        S = x[0, 0].numel()
+        y16 = torch.empty((N, (Cc + 7) // 8, S, 8), dtype=torch.bfloat16 if compute == 1 else torch.float16,
+                          device=self.device)
+        y = torch.empty_like(x) if want_f32 else None
+        self._chk(self.fn("norm_act_fwd_h16")(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
+                                              _p(y16), 0, compute, self._stream()), "norm_act_fwd_h16")
+        return y16, y
+
+    def avgpool_fwd_h16(self, x16, Cc, spatial, compute):
+        N, CB, S, _ = x16.shape
+        D, H, W = spatial
+        y16 = torch.empty((N, CB, S // 8, 8), dtype=x16.dtype, device=self.device)
+        self._chk(self.fn("avgpool3d_2x_fwd_h16")(_p(x16), _p(y16), N, Cc, D, H, W, 0, 0, compute, self._stream()),
+                  "avgpool3d_2x_fwd_h16")
+        return y16
+
     def norm_act_bwd(self, x, dy, mean, rstd, gamma, beta, groups, act, training=1, eps=1e-5, slope=0.01):
         x, dy, mean, rstd, gamma, beta = map(self.to, (x, dy, mean, rstd, gamma, beta))
         d = self.norm_desc(x, groups, act, eps, slope)

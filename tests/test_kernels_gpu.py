@@ -414,6 +414,70 @@ def test_conv3d_h16_c8_input_persistent_and_fused_statistics(hip, oracle, comput
     assert torch.equal(a, hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute))
 
 
+def _c8_to_ncdhw(x16, Cc, spatial):
+    N, CB, S, _ = x16.shape
+    return x16.float().cpu().permute(0, 1, 3, 2).reshape(N, CB * 8, S)[:, :Cc].reshape(N, Cc, *spatial)
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_norm_act_and_avgpool_c8_outputs(hip, oracle, compute):
+    """m355_norm_act_fwd_h16 == the fp32 pass followed by one rounding to the 16-bit type (GroupNorm and BatchNorm
+    geometry, residual add, channel counts that are no multiple of 8, optional fp32 twin output);
+    m355_avgpool3d_2x_fwd_h16 == the fp32 pool of the 16-bit values followed by one rounding."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    for (N, Cc, D, H, W, groups, act, with_add) in [(2, 16, 4, 6, 8, 4, 1, False), (1, 12, 2, 4, 6, 0, 2, True),
+                                                    (1, 40, 4, 4, 32, 8, 1, True)]:
+        x = rnd(N, Cc, D, H, W, seed=1)
+        gamma, beta = rnd(Cc, seed=2) * 0.5 + 1.0, rnd(Cc, seed=3) * 0.1
+        add = rnd(N, Cc, D, H, W, seed=4) if with_add else None
+        mean, rstd = oracle.norm_stats(x, groups)[:2]
+        ref = oracle.norm_act_fwd(x, mean, rstd, gamma, beta, groups, act, add)
+        y16, y32 = hip.norm_act_fwd_h16(x, mean, rstd, gamma, beta, groups, act, compute, add=add, want_f32=True)
+        close(y32, ref, 1e-5, 1e-5, "fp32 twin")
+        got = _c8_to_ncdhw(y16, Cc, (D, H, W))
+        # one rounding of (a value within 1e-5 of) the fp32 result: at most one 16-bit ulp apart
+        ulp = (2.0 ** -8 if compute == 1 else 2.0 ** -11)
+        assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + 2e-5).all()
+        assert torch.equal(got, y32.cpu().to(dt).float()), "c8 output must be the rounding of the fp32 output"
+        if Cc % 8:
+            assert (y16[:, -1, :, Cc % 8:].float() == 0).all(), "padded channels of the last block must be zero"
+        p16 = hip.avgpool_fwd_h16(y16, Cc, (D, H, W), compute)
+        pref = torch.nn.functional.avg_pool3d(got, 2, 2).to(dt).float()
+        pg = _c8_to_ncdhw(p16, Cc, (D // 2, H // 2, W // 2))
+        assert ((pg - pref).abs() <= ulp * pref.abs() * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", ["unet_gn_convt.npz", "unet_default_bn.npz", "unet_res_blur.npz"])
+def test_c8_inference_flow_matches_fp32_golden_and_autograd_path(golden, mode, name):
+    """Under no_grad in a 16-bit precision mode the activations between conv -> norm/act -> conv -> pool flow only
+    in c8 (ops.Act16; trilinear / conv-transpose / Blur convs through their fp32 fallbacks): the result stays within
+    the mode's tolerance of the fp32 reference golden and close to the same mode's autograd-recording path."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd import ops
+    from test_model_gpu import BUILDERS
+    g = golden(name)
+    model = BUILDERS[name][0]()
+    model.load_state_dict(g.state_dict("m.sd."))
+    model = model.cuda().eval()
+    x = g.t("x").cuda()
+    tol = 2e-2 if mode == "bf16" else 5e-3
+    with sp.precision(mode):
+        with torch.no_grad():
+            assert ops.h16_flow() != 0
+            p_flow = model(x)
+        assert ops.h16_flow() == 0
+        p_grad = model(x).detach()
+    with torch.no_grad():
+        p32 = model(x)                       # exact fp32 mode (itself pinned to the golden by test_model_gpu.py)
+    if name == "unet_gn_convt.npz":          # BatchNorm goldens were taken after a training step moved the statistics
+        assert (p32.cpu() - g.t("m.probs_eval")).abs().max().item() <= 1e-4
+    assert (p_flow - p32).abs().max().item() <= 2 * tol
+    assert (p_flow - p_grad).abs().max().item() <= tol
+    assert (p_flow.sum(dim=1) - 1).abs().max().item() <= 1e-5
+    assert (p_flow - p_grad).abs().max().item() > 0 or name != "unet_gn_convt.npz"   # really a different data path
+
+
 def test_fp16_precision_mode_end_to_end(golden):
     """cfg5-family precision mode ("mixed fp16 with MFMA channel-GEMM path"): fp16 operands, fp32 accumulate,
     on the small north-star model: 10 mantissa bits, so closer to the fp32 golden than bf16 (5e-3 / 2e-4)."""
