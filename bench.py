@@ -26,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "3D patches/sec (128³, 4ch) train+infer at 1/2/4/8 MI355X; Dice vs CPU ref"
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md: dense MFMA peaks (fp32: v_mfma_f32_32x32x2_f32; bf16 / fp16: v_mfma_f32_32x32x16_*), HBM3E
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
+HBM_PEAK_GBS = 8000.0
+# m355_conv3d_plan(): kernel family -> kernel name
+PLAN_KERNEL = {1: "conv3_mfma_fwd_kernel", 3: "conv3_mfma_fwd_p_kernel", 2: "conv3_valu_smallcout_kernel",
+               4: "conv3_h16_kernel", 0: "conv3d_direct_kernel"}
 WORKLOADS = {
     # name: (in_ch, out_ch, filters, depth, patch)
     "cfg2": (4, 3, [32, 64, 128, 256, 320], 5, (128, 128, 128)),
@@ -51,19 +56,83 @@ def build_model(cfg):
                        upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
 
 
+def source_hash():
+    """sha1 over the kernel sources: PMC traffic recorded for other code is not quoted"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "segmentation-pipeline_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of a kernel from the PMC passes of this same command (tools/pmc_collect.sh ->
+    profiles/r02_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).  PMC
+    counters cannot be read inside the run; the committed figure is only quoted when it was collected on
+    exactly these kernel sources (source_hash), otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
-            data = json.load(f)["kernels"]
-        for name, rec in data.items():
+            doc = json.load(f)
+        if doc.get("source_hash") != source_hash():
+            return None
+        for name, rec in doc["kernels"].items():
             if kernel_substr in name:
                 return rec["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def roofline_of(prof, precision):
+    """Roofline object of the dominant conv kernel of a timed region.  prof: ops.CONV_PROFILE entries
+    (tag, flops, e0, e1, plan, bytes).  Kernels are grouped by (kernel name, tile variant); the group with
+    the most accumulated time is the dominant kernel.  bound = whichever of algorithmic-bytes / 8 TB/s and
+    flops / dense-MFMA-peak is larger over the group's launches; achieved / peak are reported in that unit."""
+    groups = {}
+    for (tag, flops, e0, e1, plan, nbytes) in prof:
+        if tag == "conv3d_bwd_weight":
+            key = ("conv3_mfma_bww2_kernel" if precision == "fp32" else "conv3_mfma_bww_h16_kernel", "")
+        elif plan is None:
+            continue
+        else:
+            key = (PLAN_KERNEL.get(plan[0], "conv3d"), f"<{plan[1]},{plan[2]}>" + (f" split-K {plan[3]}" if plan[3] > 1 else ""))
+        g = groups.setdefault(key, [0.0, 0.0, 0.0, 0])
+        g[0] += flops
+        g[1] += nbytes
+        g[2] += e0.elapsed_time(e1)
+        g[3] += 1
+    if not groups:
+        return None
+    key = max(groups, key=lambda k: groups[k][2])
+    flops, nbytes, ms, n = groups[key]
+    peak_tf = PEAK_TFLOPS[precision]
+    t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+    kname = key[0] + key[1]
+    if t_mfma >= t_hbm:
+        ach = flops / (ms * 1e-3) / 1e12
+        out = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+    else:
+        ach = nbytes / (ms * 1e-3) / 1e9
+        out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", ")), "kernel": kname, "launches": n,
+                "avg_launch_ms": ms / n, "avg_gflop_per_launch": flops / n / 1e9,
+                "avg_algorithmic_mb_per_launch": nbytes / n / 1e6,
+                "time_share_of_conv": ms / sum(g[2] for g in groups.values())})
+    return out
 
 
 def cpu_baseline(cfg, batch):
@@ -96,7 +165,8 @@ def cpu_baseline(cfg, batch):
     ld["loss"].backward()
     opt.step()
     t_train = time.time() - t0
-    return {"value": batch / t_train, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": batch / t_train, "unit": "patches/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
+            "kind": "port",
             "sample": f"1 no-grad forward ({t_inf:.2f} s) + 1 train step ({t_train:.2f} s) of the same "
                       f"{batch}x{cin}x{'x'.join(map(str, patch))} workload, torch-CPU restatement of the reference",
             "infer_value": batch / t_inf, "dice_loss": float(ld["dice_loss"]), "loss": float(ld["loss"]),
@@ -111,7 +181,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1, help="patches per rank per step")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
-                    help="arithmetic of the 3x3x3 conv fwd / data gradient (default: exact fp32, the BASELINE cfg2 mode)")
+                    help="arithmetic of the 3x3x3 convolutions (default: exact fp32, the BASELINE cfg2 mode; bf16 / fp16: "
+                         "16-bit operands, fp32 accumulate -- BASELINE cfg3 / cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -187,18 +258,20 @@ def main():
     phases = {k: v / 2 * 1e3 for k, v in timer.timestamps.items()}
 
     # ---- inference: K no-grad forwards ----
-    infer = None
+    infer, prof_inf = None, None
     if not args.no_infer:
         model.eval()
         with torch.no_grad():
             for _ in range(max(1, args.warmup)):
                 model(x)
+            ops.CONV_PROFILE = [] if rank == 0 else None
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 model(x)
             barrier()
             ti = time.perf_counter() - t0
+            prof_inf, ops.CONV_PROFILE = ops.CONV_PROFILE, None
         ti_t = torch.tensor([ti], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(ti_t, op=dist.ReduceOp.MAX)
@@ -206,26 +279,12 @@ def main():
         infer = {"value": world * args.batch * args.steps / ti, "unit": "patches/s", "ms_per_step": ti / args.steps * 1e3}
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: conv3_mfma_fwd_p_kernel<4,32> (fp32 MFMA implicit GEMM),
-        # all launches of that variant in the timed region (forward convs and data gradients) ----
-        # the kernel variant (NTW, GX) that accumulates the most time is the dominant kernel
-        per_plan = {}
-        for (tag, f, e0, e1, plan) in prof:
-            if plan is not None and plan[0] in (1, 3) and plan[3] == 1:
-                per_plan.setdefault((plan[0], plan[1], plan[2]), []).append((f, e0.elapsed_time(e1)))
-        dom = max(per_plan, key=lambda p: sum(ms for _, ms in per_plan[p])) if per_plan else None
-        sel = per_plan.get(dom, [])
-        roofline = None
-        if sel:
-            kname = "conv3_mfma_fwd_p_kernel" if dom[0] == 3 else "conv3_mfma_fwd_kernel"  # 3: persistent variant
-            tot_f, tot_ms = sum(f for f, _ in sel), sum(ms for _, ms in sel)
-            ach = tot_f / (tot_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(f"{kname}<{dom[1]}, {dom[2]}>"),
-                        "kernel": f"{kname}<{dom[1]},{dom[2]}>", "launches": len(sel),
-                        "avg_launch_ms": tot_ms / len(sel), "avg_gflop_per_launch": tot_f / len(sel) / 1e9}
+        # ---- roofline of the dominant conv kernel of the timed train region (and of the inference region) ----
+        roofline = roofline_of(prof, args.precision)
+        if infer is not None and prof_inf:
+            infer["roofline"] = roofline_of(prof_inf, args.precision)
         by_tag = {}
-        for tag, f, e0, e1, plan in prof:
+        for tag, f, e0, e1, plan, _nb in prof:
             a = by_tag.setdefault(tag, [0.0, 0.0, 0])
             a[0] += f
             a[1] += e0.elapsed_time(e1)

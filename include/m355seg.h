@@ -84,8 +84,21 @@ typedef struct m355_conv3d_desc {
   int64_t x_batch_stride;   /* elements; 0 = dense */
   int64_t y_batch_stride;   /* elements; 0 = dense */
   int32_t compute;          /* M355_COMPUTE_* (3x3x3 / s1 / p1 only; ignored elsewhere) */
-  int32_t reserved;         /* must be 0 */
+  int32_t flags;            /* M355_CONV_* bits, 0 by default */
 } m355_conv3d_desc;
+
+/* desc->flags */
+enum {
+  /* the `w` argument of m355_conv3d_fwd(_stats|_h16) / m355_conv3d_bwd_data(_h16) points at weights packed by
+   * m355_conv3d_pack for THIS descriptor (same shapes, compute mode and direction) instead of the torch-layout
+   * filter: the per-launch repacking kernel is skipped.  Weights only change at optimizer.step, so a caller
+   * packs once per parameter version.  The buffer also holds the work-queue state of the persistent kernels
+   * (reset by the kernel itself when it drains): it must not be shared by two launches that run concurrently. */
+  M355_CONV_W_PACKED = 1
+};
+/* which: 0 = forward, 1 = data gradient.  0 bytes = this descriptor has no packed form (generic direct kernels). */
+size_t m355_conv3d_packed_bytes(const m355_conv3d_desc* d, int32_t which);
+int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const float* w, void* packed, void* stream);
 
 size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d);
 int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,
@@ -121,6 +134,11 @@ size_t m355_conv3d_h16_workspace(const m355_conv3d_desc* d, int32_t which);
 int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const float* w,
                         const float* bias, const float* add, float* y, float* stat_partials, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* forward whose OUTPUT is c8 as well (written by the epilogue: lanes exchange channel halves and store whole
+ * 16-byte items): the pre-norm tensor of conv -> norm/act -> conv never exists in fp32.  No fused `add`. */
+int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const float* w,
+                           const float* bias, void* y16, int64_t y16_batch_stride, float* stat_partials,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride, const float* w,
                              float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -163,6 +181,13 @@ int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const float* dy, c
 int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
                                      float* dw, float* dbias,
                                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.ConvTranspose3d(kernel_size=2, stride=2) c8 -> c8 for the 16-bit modes (fp32 weights and arithmetic: the op
+ * is HBM-bound): the output lands directly in its slot of the decoder's c8 concat buffer
+ * (models/modular_unet.py:96-97).  Other geometries: M355_EUNSUPPORTED (unpack / fp32 / pack instead). */
+int m355_conv_transpose3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                  const float* w, const float* bias, void* y16, int64_t y16_batch_stride,
+                                  int32_t compute, void* stream);
 
 /* --------------------------------------------------- normalisation (+ act)
  * Replaces normalization_class(out_channels) + activation_class() inside
@@ -224,6 +249,16 @@ int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
 int m355_norm_act_fwd_h16(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, const float* add, float* y, void* y16,
                           int64_t y16_batch_stride, int32_t compute, void* stream);
+/* normalise + activation (+ residual add16) c8 -> c8, for a pre-norm tensor produced by m355_conv3d_fwd_h16_c8;
+ * statistics of such a tensor when its conv had none fused (split-K plans): per-channel (sum, sum of squares)
+ * partials [N][P][C][2], P = m355_act16_partials_slots(S), fed to m355_norm_stats_from_partials. */
+int m355_norm_act_fwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, const void* add16,
+                         int64_t add16_batch_stride, void* y16, int64_t y16_batch_stride, int32_t compute,
+                         void* stream);
+int64_t m355_act16_partials_slots(int64_t S);
+int m355_act16_channel_partials(const void* x16, int64_t x16_batch_stride, int32_t N, int32_t C, int64_t S,
+                                int32_t compute, float* stat_partials, void* stream);
 int m355_avgpool3d_2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                               int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
 

@@ -8,11 +8,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm355seg.so")
+# M355_LIB_PATH: load another build of the SAME library (the diagnostic build with in-kernel cycle stamps,
+# build.py --stamps); never a fallback -- a missing file fails exactly like a missing product library.
+LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(_HERE, "libm355seg.so")
 
 M355_OK = 0
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+CONV_W_PACKED = 1
 
 
 class ConvDesc(C.Structure):
@@ -22,7 +25,7 @@ class ConvDesc(C.Structure):
         ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("out_pad", C.c_int32),
         ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64),
-        ("compute", C.c_int32), ("reserved", C.c_int32),
+        ("compute", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -45,6 +48,8 @@ SIGNATURES = {
     "m355_version": (C.c_int, []),
     "m355_last_error": (C.c_char_p, []),
     "m355_reload_tuning": (None, []),
+    "m355_conv3d_packed_bytes": (_sz, [_CD, _i32]),
+    "m355_conv3d_pack": (C.c_int, [_CD, _i32, _P, _P, _P]),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
     "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_stats_slots": (_i64, [_CD]),
@@ -54,8 +59,12 @@ SIGNATURES = {
     "m355_act16_unpack": (C.c_int, [_P, _P, _i32, _i32, _i64, _i64, _i64, _i32, _P]),
     "m355_conv3d_h16_workspace": (_sz, [_CD, _i32]),
     "m355_conv3d_fwd_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_fwd_h16_c8": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _i64, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _sz, _P]),
     "m355_norm_act_fwd_h16": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _P]),
+    "m355_norm_act_fwd_c8": (C.c_int, [_ND, _P, _i64, _P, _P, _P, _P, _P, _i64, _P, _i64, _i32, _P]),
+    "m355_act16_partials_slots": (_i64, [_i64]),
+    "m355_act16_channel_partials": (C.c_int, [_P, _i64, _i32, _i32, _i64, _i32, _P, _P]),
     "m355_avgpool3d_2x_fwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_conv3d_plan": (C.c_int, [_CD, _i32, C.POINTER(C.c_int32)]),
     "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
@@ -66,6 +75,7 @@ SIGNATURES = {
     "m355_conv_transpose3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv_transpose3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),
     "m355_conv_transpose3d_bwd_weight": (C.c_int, [_CD, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv_transpose3d_fwd_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _i64, _i32, _P]),
     "m355_norm_num_stats": (_i64, [_ND]),
     "m355_norm_workspace": (_sz, [_ND]),
     "m355_norm_stats": (C.c_int, [_ND, _P, _P, _P, _P, _P, _f32, _P, _sz, _P]),

@@ -32,9 +32,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force=False, verbose=True):
-    """Compile every HIP source to an object (in parallel) and link the shared library."""
-    objdir = os.path.join(HERE, "build")
+def build_native(force=False, verbose=True, stamps=False):
+    """Compile every HIP source to an object (in parallel) and link the shared library.
+    stamps=True: the diagnostic build libm355seg_dbg.so (-DM355_H16_STAMPS: in-kernel cycle stamps of the 16-bit
+    conv kernel, tools/h16_stamps.py; loaded instead of the product library through M355_LIB_PATH)."""
+    objdir = os.path.join(HERE, "build_dbg" if stamps else "build")
+    lib = os.path.join(HERE, "libm355seg_dbg.so") if stamps else LIB
+    flags = FLAGS + (["-DM355_H16_STAMPS"] if stamps else [])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -44,7 +48,7 @@ def build_native(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -58,10 +62,10 @@ def build_native(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv))
+    print(build_native(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -16,9 +16,8 @@ __device__ __forceinline__ float act16_fwd(float v, int act, float slope) {
 }
 
 // grid: (chunks over S, channel blocks, N).  x: fp32 NCDHW conv output; y16: c8; y32 (may be null): fp32
-// NCDHW copy for consumers that are not convolutions.  One thread = one voxel x 8 channels: eight plane
-// reads (each 256 B contiguous per wave), one 16-byte store.
-template <typename HT>
+// NCDHW copy for consumers that are not convolutions.
+template <typename HT, bool VEC>
 __global__ __launch_bounds__(256) void norm_act_fwd_c8_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ add,
@@ -41,28 +40,51 @@ __global__ __launch_bounds__(256) void norm_act_fwd_c8_kernel(
   const float* ap = add ? add + (int64_t)n * abs_ + (int64_t)c0 * S : nullptr;
   float* yp = y32 ? y32 + (int64_t)n * y32bs + (int64_t)c0 * S : nullptr;
   hx8* dst = reinterpret_cast<hx8*>(y16 + (int64_t)n * y16bs) + (int64_t)cb * S;
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
-    float v[8];
+  // Each lane reads one voxel of each of the 8 planes (a wave: 256 contiguous bytes per plane) and writes one
+  // 16-byte item (a wave: 1 KiB contiguous).  U voxels per thread, a whole grid stride apart, are in flight
+  // together (8*U independent loads).  (Four ADJACENT voxels per thread -- 16-byte plane loads -- was tried:
+  // its item stores are 64 bytes apart across lanes and the pass ran 1.9x slower.)
+  constexpr int U = VEC ? 4 : 1;
+  const int64_t stride = gridDim.x * 256ll;
+  for (int64_t i0 = blockIdx.x * 256ll + threadIdx.x; i0 < S; i0 += stride * U) {
+    float v[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = j < nc ? xp[(int64_t)j * S + i] : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = min(i0 + u * stride, S - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[u][j] = j < nc ? xp[(int64_t)j * S + i] : 0.f;
+    }
     if (ap) {
-      float a[8];
+      float a[U][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = j < nc ? ap[(int64_t)j * S + i] : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = min(i0 + u * stride, S - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act16_fwd(fmaf(v[j], sc[j], sh[j]), act, slope) + a[j];
+        for (int j = 0; j < 8; ++j) a[u][j] = j < nc ? ap[(int64_t)j * S + i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = act16_fwd(fmaf(v[u][j], sc[j], sh[j]), act, slope) + a[u][j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act16_fwd(fmaf(v[j], sc[j], sh[j]), act, slope);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = act16_fwd(fmaf(v[u][j], sc[j], sh[j]), act, slope);
     }
-    hx8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (HT)(j < nc ? v[j] : 0.f);
-    dst[i] = o;
-    if (yp) {
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= S) break;
+      hx8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < nc) yp[(int64_t)j * S + i] = v[j];
+      for (int j = 0; j < 8; ++j) o[j] = (HT)(j < nc ? v[u][j] : 0.f);
+      dst[i] = o;
+      if (yp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nc) yp[(int64_t)j * S + i] = v[u][j];
+      }
     }
   }
 }
@@ -98,6 +120,104 @@ __global__ __launch_bounds__(256) void avgpool2_c8_kernel(const HT* __restrict__
   }
 }
 
+// c8 -> c8 normalise + activation (+ residual, also c8): the pre-norm tensor was written by the conv epilogue as
+// c8 (m355_conv3d_fwd_h16_c8), so the pass is purely elementwise on 16-byte items: 2 + 2 bytes per element
+// instead of 4 + 4 for the fp32 pass.  U items per thread, a grid stride apart, in flight together.
+template <typename HT>
+__global__ __launch_bounds__(256) void norm_act_c8c8_kernel(
+    const HT* __restrict__ x16, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const HT* __restrict__ add16,
+    HT* __restrict__ y16, int C, int64_t S, int groups, int act, float slope, int64_t xbs16, int64_t abs16,
+    int64_t ybs16) {
+  using hx8 = typename H16<HT>::x8;
+  constexpr int U = 4;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const int c0 = cb * 8, nc = min(8, C - c0);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(c0 + j, C - 1);
+    const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+    const float m = mean[s], r = rstd[s];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    sc[j] = r * g;
+    sh[j] = b - m * sc[j];
+  }
+  const hx8* src = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs16) + (int64_t)cb * S;
+  const hx8* asrc = add16 ? reinterpret_cast<const hx8*>(add16 + (int64_t)n * abs16) + (int64_t)cb * S : nullptr;
+  hx8* dst = reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs16) + (int64_t)cb * S;
+  const int64_t stride = gridDim.x * 256ll;
+  for (int64_t i0 = blockIdx.x * 256ll + threadIdx.x; i0 < S; i0 += stride * U) {
+    hx8 v[U], a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[min(i0 + u * stride, S - 1)];
+    if (asrc) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = asrc[min(i0 + u * stride, S - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= S) break;
+      hx8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = act16_fwd(fmaf((float)v[u][j], sc[j], sh[j]), act, slope);
+        if (asrc) t += (float)a[u][j];
+        o[j] = (HT)(j < nc ? t : 0.f);
+      }
+      dst[i] = o;
+    }
+  }
+}
+
+// (sum, sum of squares) per channel of a c8 tensor, in the format of the conv epilogue partials
+// part[n][slot][C][2] (consumed by m355_norm_stats_from_partials): the statistics of a pre-norm tensor whose
+// producing conv had no fused statistics (split-K plans on the small levels).  grid (slots, CB, N).
+template <typename HT>
+__global__ __launch_bounds__(256) void act16_channel_partials_kernel(const HT* __restrict__ x16,
+                                                                     float* __restrict__ part, int C, int64_t S,
+                                                                     int64_t xbs16, int slots) {
+  using hx8 = typename H16<HT>::x8;
+  __shared__ float red[4][16];
+  const int slot = blockIdx.x, cb = blockIdx.y, n = blockIdx.z;
+  const int64_t chunk = (S + slots - 1) / slots;
+  const int64_t begin = (int64_t)slot * chunk, end = min(S, begin + chunk);
+  const hx8* src = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs16) + (int64_t)cb * S;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+    const hx8 v = src[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = (float)v[j];
+      s1[j] += t;
+      s2[j] = fmaf(t, t, s2[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = wave_sum(s1[j]);
+    s2[j] = wave_sum(s2[j]);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[w][j] = s1[j];
+      red[w][8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x & 7, k = threadIdx.x >> 3;
+    const float t = ((red[0][k * 8 + j] + red[1][k * 8 + j]) + red[2][k * 8 + j]) + red[3][k * 8 + j];
+    const int c = cb * 8 + j;
+    if (c < C) part[(((int64_t)n * slots + slot) * C + c) * 2 + k] = t;
+  }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -117,14 +237,20 @@ extern "C" int m355_norm_act_fwd_h16(const m355_norm_desc* d, const float* x, co
   const int64_t abs_ = dense_or(d->add_batch_stride, CS);
   const int64_t y16bs = dense_or(y16_batch_stride, c8_blocks(d->C) * d->S * 8);
   M355_REQUIRE(((uintptr_t)y16 & 15) == 0 && y16bs % 8 == 0, M355_EINVALID_ARG, "norm_act_fwd_h16: c8 tensor not 16B aligned");
-  dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * 2), 2048)), (unsigned)c8_blocks(d->C),
-            (unsigned)d->N);
-  if (compute == M355_COMPUTE_BF16)
-    hipLaunchKernelGGL(norm_act_fwd_c8_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
-                       beta, add, y, (__bf16*)y16, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_, y16bs);
-  else
-    hipLaunchKernelGGL(norm_act_fwd_c8_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
-                       beta, add, y, (_Float16*)y16, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_, y16bs);
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  (void)al16;
+  const bool vec = d->S >= 4096;   // large tensors: four voxels per thread in flight
+  dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * (vec ? 4 : 1)), 2048)),
+            (unsigned)c8_blocks(d->C), (unsigned)d->N);
+#define M355_NA16(HT, V)                                                                                             \
+  hipLaunchKernelGGL((norm_act_fwd_c8_kernel<HT, V>), grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, \
+                     beta, add, y, (HT*)y16, d->C, d->S, d->groups, d->act, d->act_slope, xbs, ybs, abs_, y16bs)
+  if (compute == M355_COMPUTE_BF16) {
+    if (vec) M355_NA16(__bf16, true); else M355_NA16(__bf16, false);
+  } else {
+    if (vec) M355_NA16(_Float16, true); else M355_NA16(_Float16, false);
+  }
+#undef M355_NA16
   return check_launch("norm_act_fwd_h16");
 }
 
@@ -151,4 +277,63 @@ extern "C" int m355_avgpool3d_2x_fwd_h16(const void* x16, void* y16, int32_t N, 
     hipLaunchKernelGGL(avgpool2_c8_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)x16, (_Float16*)y16, CB, D, H, W, xbs, ybs, N);
   return check_launch("avgpool3d_2x_fwd_h16");
+}
+
+static int check_c8_args(const char* who, const m355_norm_desc* d, int32_t compute) {
+  M355_REQUIRE(d, M355_EINVALID_ARG, "%s: null descriptor", who);
+  M355_REQUIRE(d->N > 0 && d->C > 0 && d->S > 0 && d->N <= 65535 && c8_blocks(d->C) <= 65535, M355_EINVALID_ARG,
+               "%s: bad shape", who);
+  M355_REQUIRE(d->groups >= 0 && (d->groups == 0 || d->C % d->groups == 0), M355_EINVALID_ARG,
+               "%s: C=%d not divisible by groups=%d", who, d->C, d->groups);
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "%s: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16", who);
+  return M355_OK;
+}
+
+extern "C" int m355_norm_act_fwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    const void* add16, int64_t add16_batch_stride, void* y16,
+                                    int64_t y16_batch_stride, int32_t compute, void* stream) {
+  if (int rc = check_c8_args("norm_act_fwd_c8", d, compute)) return rc;
+  M355_REQUIRE(x16 && mean && rstd && y16, M355_EINVALID_ARG, "norm_act_fwd_c8: null pointer");
+  const int64_t dense = c8_blocks(d->C) * d->S * 8;
+  const int64_t xbs = dense_or(x16_batch_stride, dense), abs_ = dense_or(add16_batch_stride, dense);
+  const int64_t ybs = dense_or(y16_batch_stride, dense);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)y16 | (uintptr_t)add16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0 &&
+                   abs_ % 8 == 0, M355_EINVALID_ARG, "norm_act_fwd_c8: c8 tensor not 16B aligned");
+  dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * 4), 2048)), (unsigned)c8_blocks(d->C),
+            (unsigned)d->N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(norm_act_c8c8_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x16, mean,
+                       rstd, gamma, beta, (const __bf16*)add16, (__bf16*)y16, d->C, d->S, d->groups, d->act,
+                       d->act_slope, xbs, abs_, ybs);
+  else
+    hipLaunchKernelGGL(norm_act_c8c8_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x16,
+                       mean, rstd, gamma, beta, (const _Float16*)add16, (_Float16*)y16, d->C, d->S, d->groups, d->act,
+                       d->act_slope, xbs, abs_, ybs);
+  return check_launch("norm_act_fwd_c8");
+}
+
+extern "C" int64_t m355_act16_partials_slots(int64_t S) {
+  return S <= 0 ? 0 : std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 4096), 1024));
+}
+
+extern "C" int m355_act16_channel_partials(const void* x16, int64_t x16_batch_stride, int32_t N, int32_t C, int64_t S,
+                                           int32_t compute, float* stat_partials, void* stream) {
+  M355_REQUIRE(x16 && stat_partials, M355_EINVALID_ARG, "act16_channel_partials: null pointer");
+  M355_REQUIRE(N > 0 && C > 0 && S > 0 && N <= 65535 && c8_blocks(C) <= 65535, M355_EINVALID_ARG,
+               "act16_channel_partials: bad shape");
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "act16_channel_partials: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  const int64_t xbs = dense_or(x16_batch_stride, c8_blocks(C) * S * 8);
+  M355_REQUIRE(((uintptr_t)x16 & 15) == 0 && xbs % 8 == 0, M355_EINVALID_ARG, "act16_channel_partials: c8 tensor not 16B aligned");
+  const int slots = (int)m355_act16_partials_slots(S);
+  dim3 grid((unsigned)slots, (unsigned)c8_blocks(C), (unsigned)N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(act16_channel_partials_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x16, stat_partials, C, S, xbs, slots);
+  else
+    hipLaunchKernelGGL(act16_channel_partials_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x16, stat_partials, C, S, xbs, slots);
+  return check_launch("act16_channel_partials");
 }

@@ -26,7 +26,7 @@ __global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ 
                                int Cin, int kin_pad, int mout_pad, int transpose, int* __restrict__ counter) {
   // logical conv being run: K-channels = kin (padded to kin_pad), M-channels = mout_pad
   const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
-  if (counter && blockIdx.x == 0 && threadIdx.x < 8) counter[threadIdx.x] = 0;  // work queues of the persistent conv kernel
+  if (counter && blockIdx.x == 0 && threadIdx.x < 16) counter[threadIdx.x] = 0;  // work queues of the persistent conv kernel
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i % mout_pad);
@@ -336,9 +336,15 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
   auto region_size = [&](int r) { return max(0, min(cpx, total - r * cpx)); };
   auto region_static = [&](int r) { return min(region_size(r), (G - r + 7) >> 3); };  // workgroups starting there
   auto steal = [&]() {  // thread 0; `total` = nothing left anywhere
+    // One 32-byte read of all eight ticket counters first: when every region is drained (what every
+    // workgroup finds once, at the end of its life) that is one memory round trip instead of seven
+    // dependent atomics (~15-40k cycles, a quarter of the lifetime of a short 16-bit launch).
+    int seen[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) seen[r] = __hip_atomic_load(work_counter + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int a = 1; a < 8; ++a) {
       const int r = (xl + a) & 7;
-      if (region_static(r) >= region_size(r)) continue;  // nothing dynamic in that region
+      if (region_static(r) + seen[r] >= region_size(r)) continue;  // nothing dynamic left there (counters only grow)
       const int k = region_static(r) + atomicAdd(work_counter + r, 1);
       if (k < region_size(r)) return r * cpx + k;
     }
@@ -354,7 +360,10 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     __syncthreads();
     it = next_item_s;
     __syncthreads();
-    if (it >= total) return;
+    if (it >= total) {
+      queue_leave(work_counter);
+      return;
+    }
   }
   Item cur = decode(it);
   compute_goff(cur);
@@ -441,6 +450,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     it = nit;
     cur = nxt;
   }
+  queue_leave(work_counter);
 }
 
 // A 32-row MFMA tile would carry only Cout useful rows.  z-Toeplitz packing fills the rows
@@ -1696,11 +1706,21 @@ static size_t act16_staging_bytes(int N, int C, int D, int H, int W) {
   return (size_t)round_up((int64_t)N * c8_blocks(C) * D * H * W * 16, 256);
 }
 
+static void launch_pack_w3(const FwdPlan& p, const float* w, float* wp, int Cout_w, int Cin_w, bool transpose,
+                           hipStream_t st) {
+  const int64_t total = (int64_t)p.kin_pad * 27 * p.mout_pad;
+  const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+  hipLaunchKernelGGL(pack_w3_kernel, dim3(blocks), dim3(256), 0, st, w, wp, Cout_w, Cin_w, p.kin_pad, p.mout_pad,
+                     transpose ? 1 : 0, (int*)((char*)wp + p.wp_bytes - 256));
+}
+
 static int run_mfma_conv(const float* in, const float* w, bool transpose, int Cout_w, int Cin_w,
                          const float* bias, const float* add, float* out, int N, int kin,
                          int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
                          size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32, float* stat = nullptr,
-                         const void* in16 = nullptr, int64_t in16_bs = 0) {
+                         const void* in16 = nullptr, int64_t in16_bs = 0, const void* prepacked = nullptr,
+                         bool out16 = false) {
+  // prepacked: weights already packed for this plan by m355_conv3d_pack (M355_CONV_W_PACKED); `w` is then unused
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
   M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
@@ -1718,20 +1738,15 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
       in16 = stage;
     }
     return run_h16_conv(p, compute, in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W,
-                        out_bs, ws, ws_bytes, st, stat);
+                        out_bs, ws, ws_bytes, st, stat, prepacked, out16);
   }
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
-  float* wp = (float*)ws;
+  float* wp = prepacked ? (float*)prepacked : (float*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
-  int* work_counter = (int*)((char*)ws + p.wp_bytes - 256);  // last 256 B of the packed-weight region
-  {
-    const int64_t total = (int64_t)p.kin_pad * 27 * p.mout_pad;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
-    hipLaunchKernelGGL(pack_w3_kernel, dim3(blocks), dim3(256), 0, st, w, wp, Cout_w, Cin_w,
-                       p.kin_pad, p.mout_pad, transpose ? 1 : 0, work_counter);
-  }
+  int* work_counter = (int*)((char*)wp + p.wp_bytes - 256);  // last 256 B of the packed-weight region
+  if (!prepacked) launch_pack_w3(p, w, wp, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
 #define M355_FWD_CASE(NTW, GX)                                                              \
@@ -1849,6 +1864,18 @@ static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
 }
 extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }
 
+static void launch_pack_smallcout(const m355_conv3d_desc* d, const float* w, float* wpz, hipStream_t st) {
+  if (tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
+    hipLaunchKernelGGL(pack_w3_valu_kernel, dim3((unsigned)ceil_div(d->Cin * 27 * 4, 256)), dim3(256), 0, st, w, wpz,
+                       d->Cout, d->Cin);
+  } else {
+    const int kin_pad = (int)round_up(d->Cin, 2);
+    const int64_t total = (int64_t)kin_pad * TZ_K * 32;
+    hipLaunchKernelGGL(pack_w3_toeplitz_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256),
+                       0, st, w, wpz, d->Cout, d->Cin, kin_pad);
+  }
+}
+
 static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const float* w, const float* bias,
                            const float* add, float* y, float* stat, void* workspace, size_t workspace_bytes,
                            void* stream) {
@@ -1866,11 +1893,11 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
     M355_REQUIRE(workspace && workspace_bytes >= small_cout_ws(d), M355_EWORKSPACE,
                  "conv3d_fwd: workspace too small (%zu < %zu)", workspace_bytes, small_cout_ws(d));
     M355_REQUIRE(((uintptr_t)workspace & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
-    float* wpz = (float*)workspace;
+    const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+    float* wpz = packed ? (float*)w : (float*)workspace;
     if (tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
       // packed-FMA kernel (see conv3_valu_smallcout_kernel); the workspace of the MFMA variant is larger
-      hipLaunchKernelGGL(pack_w3_valu_kernel, dim3((unsigned)ceil_div(d->Cin * 27 * 4, 256)), dim3(256), 0, st, w, wpz,
-                         d->Cout, d->Cin);
+      if (!packed) launch_pack_smallcout(d, w, wpz, st);
       const int tyv = (int)ceil_div(d->H, VS_TY), txv = (int)ceil_div(d->W, VS_TX);
       dim3 gv((unsigned)(ceil_div(d->D, VS_TZ) * tyv * txv), (unsigned)d->N);
       hipLaunchKernelGGL(conv3_valu_smallcout_kernel, gv, dim3(256), 0, st, x, wpz, bias, add, y, d->Cin, d->Cout,
@@ -1878,11 +1905,7 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
       return check_launch("conv3_valu_smallcout");
     }
     const int kin_pad = (int)round_up(d->Cin, 2);
-    {
-      const int64_t total = (int64_t)kin_pad * TZ_K * 32;
-      hipLaunchKernelGGL(pack_w3_toeplitz_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)),
-                         dim3(256), 0, st, w, wpz, d->Cout, d->Cin, kin_pad);
-    }
+    if (!packed) launch_pack_smallcout(d, w, wpz, st);
     const int tyt = (int)ceil_div(d->H, 8), txt = (int)ceil_div(d->W, 32);
     dim3 grid((unsigned)(ceil_div(d->D, 8) * tyt * txt), (unsigned)d->N);
     hipLaunchKernelGGL(conv3_mfma_fwd_smallcout_kernel, grid, dim3(256), 0, st, x, wpz, bias, add, y, d->Cin,
@@ -1890,9 +1913,12 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
     return check_launch("conv3_mfma_fwd_smallcout");
   }
   if (is_k3s1p1(d)) {
-    return run_mfma_conv(x, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
-                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute, stat);
+    const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+    return run_mfma_conv(x, packed ? nullptr : w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
+                         d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute, stat, nullptr, 0,
+                         packed ? w : nullptr);
   }
+  M355_REQUIRE(!(d->flags & M355_CONV_W_PACKED), M355_EINVALID_ARG, "conv3d_fwd: this descriptor has no packed weights");
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
   const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
   hipLaunchKernelGGL(conv3d_direct_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, add, y,
@@ -1912,6 +1938,34 @@ extern "C" int m355_conv3d_fwd_stats(const m355_conv3d_desc* d, const float* x, 
                                      void* workspace, size_t workspace_bytes, void* stream) {
   M355_REQUIRE(stat_partials, M355_EINVALID_ARG, "conv3d_fwd_stats: null statistics buffer");
   return conv3d_fwd_impl(d, x, w, bias, add, y, stat_partials, workspace, workspace_bytes, stream);
+}
+
+// ---- packed weights (M355_CONV_W_PACKED) ----
+extern "C" size_t m355_conv3d_packed_bytes(const m355_conv3d_desc* d, int32_t which) {
+  if (!d || !is_k3s1p1(d) || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+  if (which == 0 && small_cout_fwd(d)) return small_cout_ws(d);
+  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
+                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
+  return p.wp_bytes;
+}
+
+extern "C" int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const float* w, void* packed, void* stream) {
+  if (int rc = validate_conv(d, "conv3d_pack")) return rc;
+  M355_REQUIRE(w && packed && ((uintptr_t)packed & 15) == 0, M355_EINVALID_ARG, "conv3d_pack: null / unaligned pointer");
+  M355_REQUIRE(is_k3s1p1(d) && (which == 0 || which == 1), M355_EUNSUPPORTED,
+               "conv3d_pack: only the 3x3x3 / stride 1 / pad 1 kernels have packed weights");
+  hipStream_t st = (hipStream_t)stream;
+  if (which == 0 && small_cout_fwd(d)) {
+    launch_pack_smallcout(d, w, (float*)packed, st);
+    return check_launch("conv3d_pack");
+  }
+  const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
+                               : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
+  if (d->compute == M355_COMPUTE_F32)
+    launch_pack_w3(p, w, (float*)packed, d->Cout, d->Cin, which == 1, st);
+  else
+    launch_pack_w3_h16(p, d->compute, w, packed, d->Cout, d->Cin, which == 1, st);
+  return check_launch("conv3d_pack");
 }
 
 // ---- 16-bit operand modes with c8 tensors handed over by the caller (h16.hpp) ----
@@ -1966,10 +2020,26 @@ extern "C" int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, i
   M355_REQUIRE(!stat_partials || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
                "conv3d_fwd_h16: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
   const int64_t S = (int64_t)d->D * d->H * d->W;
-  return run_mfma_conv(nullptr, w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D, d->H, d->W, 0,
-                       dense_or(d->y_batch_stride, (int64_t)d->Cout * S), workspace, workspace_bytes,
+  const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+  return run_mfma_conv(nullptr, packed ? nullptr : w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
+                       d->H, d->W, 0, dense_or(d->y_batch_stride, (int64_t)d->Cout * S), workspace, workspace_bytes,
                        (hipStream_t)stream, d->compute, stat_partials, x16,
-                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8));
+                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8), packed ? w : nullptr);
+}
+
+extern "C" int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                      const float* w, const float* bias, void* y16, int64_t y16_batch_stride,
+                                      float* stat_partials, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_h16(d, "conv3d_fwd_h16_c8")) return rc;
+  M355_REQUIRE(x16 && w && y16 && workspace, M355_EINVALID_ARG, "conv3d_fwd_h16_c8: null pointer");
+  M355_REQUIRE(!stat_partials || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
+               "conv3d_fwd_h16_c8: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+  return run_mfma_conv(nullptr, packed ? nullptr : w, false, d->Cout, d->Cin, bias, nullptr, (float*)y16, d->N, d->Cin,
+                       d->Cout, d->D, d->H, d->W, 0, dense_or(y16_batch_stride, c8_blocks(d->Cout) * S * 8), workspace,
+                       workspace_bytes, (hipStream_t)stream, d->compute, stat_partials, x16,
+                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8), packed ? w : nullptr, true);
 }
 
 extern "C" int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride,
@@ -1978,10 +2048,11 @@ extern "C" int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* d
   if (int rc = validate_h16(d, "conv3d_bwd_data_h16")) return rc;
   M355_REQUIRE(dy16 && w && dx && workspace, M355_EINVALID_ARG, "conv3d_bwd_data_h16: null pointer");
   const int64_t S = (int64_t)d->D * d->H * d->W;
-  return run_mfma_conv(nullptr, w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin, d->D, d->H, d->W,
-                       0, dense_or(d->x_batch_stride, (int64_t)d->Cin * S), workspace, workspace_bytes,
+  const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+  return run_mfma_conv(nullptr, packed ? nullptr : w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin,
+                       d->D, d->H, d->W, 0, dense_or(d->x_batch_stride, (int64_t)d->Cin * S), workspace, workspace_bytes,
                        (hipStream_t)stream, d->compute, nullptr, dy16,
-                       dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8));
+                       dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8), packed ? w : nullptr);
 }
 
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
@@ -2014,9 +2085,12 @@ extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, 
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   if (is_k3s1p1(d)) {
     // dx = conv(dy, flipped/transposed w): K-channels = Cout, M-channels = Cin
-    return run_mfma_conv(dy, w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin,
-                         d->D, d->H, d->W, ybs, xbs, workspace, workspace_bytes, st, d->compute);
+    const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+    return run_mfma_conv(dy, packed ? nullptr : w, true, d->Cout, d->Cin, nullptr, nullptr, dx, d->N, d->Cout, d->Cin,
+                         d->D, d->H, d->W, ybs, xbs, workspace, workspace_bytes, st, d->compute, nullptr, nullptr, 0,
+                         packed ? w : nullptr);
   }
+  M355_REQUIRE(!(d->flags & M355_CONV_W_PACKED), M355_EINVALID_ARG, "conv3d_bwd_data: this descriptor has no packed weights");
   const int64_t total = (int64_t)d->N * d->Cin * d->D * d->H * d->W;
   const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 65535);
   hipLaunchKernelGGL(conv3d_direct_bwd_data_kernel, dim3(blocks), dim3(256), 0, st, dy, w, dx,

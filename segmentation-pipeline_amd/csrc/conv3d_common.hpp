@@ -14,6 +14,18 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// Work-queue state of the persistent kernels: counter[0..7] = tickets of the eight item regions, counter[8] =
+// workgroups that have left.  The LAST workgroup to leave zeroes the state, so a packed-weight buffer (which
+// holds it) can be reused launch after launch without a memset; the weight-pack kernels zero it initially.
+__device__ __forceinline__ void queue_leave(int* __restrict__ counter) {
+  if (threadIdx.x == 0) {
+    if (atomicAdd(counter + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) counter[r] = 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------ MFMA fwd kernel
 template <int NTW, int GX>
 struct FwdTile {
@@ -135,7 +147,10 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M
 // samples; out: fp32 NCDHW.  Workspace: p.wp_bytes (packed weights + work queue) + p.slab_bytes.
 int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
-                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat);
+                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
+                 const void* prepacked = nullptr, bool out16 = false);
+void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
+                        hipStream_t st);
 // weight gradient on the 16-bit MFMA (fp32 NCDHW operands rounded while staged; W % 32 == 0)
 int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
                    int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,

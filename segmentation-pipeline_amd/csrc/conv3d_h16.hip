@@ -91,7 +91,7 @@ template <typename HT>
 __global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
                                    int Cin, int nchunks, int mout_pad, int transpose, int* __restrict__ counter) {
   const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
-  if (counter && blockIdx.x == 0 && threadIdx.x < 8) counter[threadIdx.x] = 0;
+  if (counter && blockIdx.x == 0 && threadIdx.x < 16) counter[threadIdx.x] = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7);
@@ -112,13 +112,135 @@ __global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__
   }
 }
 
+// ---- c8 epilogue: the output tile of one wave as c8 items (the next pass reads the tensor in c8 anyway) ----
+// C/D layout: lane = voxel (l32) x channel-half: registers 4q..4q+3 of a lane are channels 8q + 4*half + 0..3 of
+// its voxel.  One v_permlane32_swap per dword hands the lower lanes the upper lanes' half of block q and the
+// upper lanes the lower lanes' half of block q+1, so every lane owns ONE complete 8-channel item (lower
+// lanes: block q, upper lanes: block q+1) and stores it with a single 16-byte instruction: 8 store
+// instructions per lane and tile (NTW = 4) instead of the 64 dword stores of the fp32 NCDHW epilogue, which
+// was the largest fixed cost of a short-K item (store-issue bound, ~9k cycles of a ~24k-cycle item).
+template <int NTW, int GY, typename HT>
+__device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT* __restrict__ dst16,
+                                                   const float* __restrict__ bias, int o0, int Cout, int z, int y0,
+                                                   int xg, int ly, int half, int H, int W, int64_t S, bool lane_ok,
+                                                   float* __restrict__ stat) {
+  using hx4 = typename H16<HT>::x4;
+  const int iHW = H * W;
+  const int ob = o0 + 4 * half;
+  float bb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = ob + (r & 3) + 8 * (r >> 2);
+    bb[r] = (bias && o < Cout) ? bias[o] : 0.f;     // padded channels of the last block stay exactly zero
+  }
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+  const int CBout = (Cout + 7) >> 3;
+  uint4* base = reinterpret_cast<uint4*>(dst16);
+#pragma unroll
+  for (int g = 0; g < NTW; ++g) {
+    const int yg = y0 + g * GY + ly;
+    const bool ok = lane_ok && yg < H;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
+    if (stat) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ok ? v[r] : 0.f;
+        s1[r] += t;
+        s2[r] = fmaf(t, t, s2[r]);
+      }
+    }
+    const int64_t vox = (int64_t)z * iHW + (int64_t)yg * W + xg;
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {  // block pairs (0, 1) and (2, 3) of the 32-channel tile
+      hx4 lo, hi;                     // this lane's 4 channels of block 2qp and of block 2qp + 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = (HT)v[8 * qp + j];
+        hi[j] = (HT)v[8 * qp + 4 + j];
+      }
+      uint2 X = __builtin_bit_cast(uint2, lo), Y = __builtin_bit_cast(uint2, hi);
+      auto r0 = __builtin_amdgcn_permlane32_swap(X.x, Y.x, false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(X.y, Y.y, false, false);
+      // lower lanes: (own block 2qp ch 0-3 | partner's ch 4-7); upper lanes: (partner's block 2qp+1 ch 0-3 | own ch 4-7)
+      const uint4 item = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      const int cb = (o0 >> 3) + 2 * qp + half;
+      if (ok && cb < CBout) base[(int64_t)cb * S + vox] = item;
+    }
+  }
+  if (stat) {
+    float a[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a[r] = s1[r];
+      a[16 + r] = s2[r];
+    }
+    const int l32 = threadIdx.x & 31;
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+      const bool up = (l32 & h) != 0;
+#pragma unroll
+      for (int i = 0; i < h; ++i) {
+        const float send = up ? a[i] : a[i + h];
+        const float keep = up ? a[i + h] : a[i];
+        a[i] = keep + __shfl_xor(send, h, 64);
+      }
+    }
+    const int r = l32 & 15, q = l32 >> 4;
+    const int o = ob + (r & 3) + 8 * (r >> 2);
+    if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
+  }
+}
+
+// c8 output of a split-K plan: y16[n][cb][s] = bias + sum_ks slab[ks][n][o][s] (fixed order), rounded once
+template <typename HT>
+__global__ __launch_bounds__(256) void splitk_reduce_c8_kernel(const float* __restrict__ slab,
+                                                               const float* __restrict__ bias, HT* __restrict__ y16,
+                                                               int Cout, int64_t S, int ksplit, int64_t slab_stride,
+                                                               int64_t ybs16) {
+  using hx8 = typename H16<HT>::x8;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const int c0 = cb * 8, nc = min(8, Cout - c0);
+  const float* sp = slab + ((int64_t)n * Cout + c0) * S;
+  hx8* dst = reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs16) + (int64_t)cb * S;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = (bias && j < nc) ? bias[c0 + j] : 0.f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = j < nc ? sp[(int64_t)j * S + i] : 0.f;
+    for (int k = 1; k < ksplit; ++k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nc) v[j] += sp[(int64_t)k * slab_stride + (int64_t)j * S + i];
+    }
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (HT)(j < nc ? v[j] + bv[j] : 0.f);
+    dst[i] = o;
+  }
+}
+
 // ------------------------------------------------------------------ the kernel
-template <int NTW, int GX, typename HT>
+#ifdef M355_H16_STAMPS
+// Diagnostic build only (tools/h16_stamps.py): per-workgroup cycle sums of the phases of a chunk, wave 0.
+__device__ unsigned long long m355_h16_stamps[1024][8];
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
+// OUT16: the output tile is written as c8 items into y16 (ybs in ELEMENTS of it); otherwise fp32 NCDHW into y.
+template <int NTW, int GX, typename HT, bool OUT16>
 __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
     int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int nchunks, int ksplit, int nbatch,
-    int64_t xbs16, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int* __restrict__ work_counter) {
+    int64_t xbs16, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int* __restrict__ work_counter,
+    int stagger) {
   using T = FwdTile<NTW, GX>;
   using hx8 = typename H16<HT>::x8;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
@@ -200,17 +322,21 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     const int idc = idx < WI ? idx : WI - 1;  // clamp: keeps the array fully scalarised
     wr[k] = wsrc[(int64_t)(idc >> 5) * cout_pad + (idc & 31)];
   };
-  // prefetch items issued during MFMA step s: the halo items (HBM latency) from the first step on, the
-  // weight items (L2-resident, short latency) during the last steps, where no fragment prefetch competes
-  // for registers
-  constexpr int WSTEPS = NSTEP < 4 ? NSTEP : 4;
+  // Prefetch items issued during MFMA step s.  ALL of them go out in the first quarter of the chunk (halo items
+  // first: HBM / L2 latency; then the L2-resident weight items): a load issued late in the chunk lands a
+  // full memory round trip after the last MFMA, and with one LDS buffer the commit (and so the next chunk) waits
+  // for it -- spreading the loads over the whole chunk, as the 16x longer fp32 chunks can afford, made every
+  // chunk cost MFMA time + memory latency (measured: 43 % of the MFMA rate on 12-chunk items).
+  constexpr int ESTEPS = NSTEP / 4 > 0 ? NSTEP / 4 : 1;          // steps that carry halo loads (and as many for weights)
+  constexpr int XPS = (XPER + ESTEPS - 1) / ESTEPS, WPS = (WPER + ESTEPS - 1) / ESTEPS;
+  constexpr int VPS = XPS > WPS ? XPS : WPS;                     // most prefetch loads in one step
   auto fetch_step = [&](int s) {
 #pragma unroll
     for (int k = 0; k < XPER; ++k)
-      if (k % NSTEP == s) fetch_x(k);
+      if (k / XPS == s) fetch_x(k);
 #pragma unroll
     for (int k = 0; k < WPER; ++k)
-      if (NSTEP - 1 - (k % WSTEPS) == s) fetch_w(k);
+      if (ESTEPS + k / WPS == s) fetch_w(k);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -229,9 +355,15 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
   auto region_size = [&](int r) { return max(0, min(cpx, total - r * cpx)); };
   auto region_static = [&](int r) { return min(region_size(r), (G - r + 7) >> 3); };
   auto steal = [&]() {  // thread 0; `total` = nothing left anywhere
+    // One 32-byte read of all eight ticket counters first: when every region is drained (what every
+    // workgroup finds once, at the end of its life) that is one memory round trip instead of seven
+    // dependent atomics (~15-40k cycles, a quarter of the lifetime of a short 16-bit launch).
+    int seen[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) seen[r] = __hip_atomic_load(work_counter + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int a = 1; a < 8; ++a) {
       const int r = (xl + a) & 7;
-      if (region_static(r) >= region_size(r)) continue;
+      if (region_static(r) + seen[r] >= region_size(r)) continue;  // nothing dynamic left there (counters only grow)
       const int k = region_static(r) + atomicAdd(work_counter + r, 1);
       if (k < region_size(r)) return r * cpx + k;
     }
@@ -247,7 +379,10 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     __syncthreads();
     it = next_item_s;
     __syncthreads();
-    if (it >= total) return;
+    if (it >= total) {
+      queue_leave(work_counter);
+      return;
+    }
   }
   Item cur = decode(it);
   compute_goff(cur);
@@ -260,6 +395,21 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
   const hx8* xb = xs + half * HV + wave * PS + ly * RS + lx;
   const hx8* wb = ws + half * 32 + l32;
 
+  // Two workgroups share a CU (one wave of each per SIMD) and start together with identical work: left alone they
+  // run in lockstep -- both in their MFMA phase (sharing the matrix pipe), then both at the barriers / LDS commit
+  // with the pipe idle (SQ counters: pipe busy 54 %, and a wave's non-MFMA time never overlapped its partner's
+  // MFMAs).  The workgroup in the odd hardware wave slot starts half a chunk late; equal periods keep the offset.
+  if (stagger > 0) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.WAVE_ID
+    if (wave_slot & 1u) {
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);               // 16 x 64 cycles each
+    }
+  }
+
+#ifdef M355_H16_STAMPS
+  unsigned long long ph_mfma = 0, ph_b1 = 0, ph_commit = 0, ph_b2 = 0, ph_epi = 0, ph_n = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   f32x16 acc[NTW];
   while (true) {
     int pending = 0;
@@ -284,6 +434,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
         compute_goff(nxt);
         chunk_setup(nxt, nxt.ch_begin, live);
       }
+      STAMP(t0);
       if constexpr (REUSE) {
         // step s = (dx, dz): rows j = 0 .. NTW+1 of plane wave + dz at column offset dx; MFMA (g, dy) uses
         // row g + dy and the weights of tap (dz, dy, dx).  MFMAs run row by row, so a row fragment dies early;
@@ -318,13 +469,13 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
               const int g = j - dy;
               if (g >= 0 && g < NTW) acc[g] = H16<HT>::mfma(fa[s & 1][dy], fb[s & 1][j], acc[g]);
             }
-          if (BARE > 0) __builtin_amdgcn_sched_group_barrier(0x008, BARE, 0);
 #pragma unroll
-          for (int m = 0; m < NM - BARE; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM - BARE - 1) / (NM - BARE), 0);  // DS read
+          for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       // MFMA
+            if (m >= BARE) __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM - BARE - 1) / (NM - BARE), 0);  // DS read
+            if (m < VPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          // one prefetch load
           }
-          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // VMEM reads of the prefetch
+          __builtin_amdgcn_sched_group_barrier(0x020, VPS, 0);  // (more loads than MFMAs in a step: tiny tiles)
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -346,16 +497,26 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
           for (int g = 0; g < NTW; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x020, (VPS + NTW - 1) / NTW, 0);  // prefetch loads
           }
-          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
+      STAMP(t1);
       __syncthreads();  // every wave has read its last fragment of this chunk
+      STAMP(t2);
       commit();
+      STAMP(t3);
       __syncthreads();
+#ifdef M355_H16_STAMPS
+      {
+        STAMP(t4);
+        ph_mfma += t1 - t0; ph_b1 += t2 - t1; ph_commit += t3 - t2; ph_b2 += t4 - t3; ph_n += 1;
+      }
+#endif
     }
+    STAMP(te0);
 
     // ---- output tile of `cur` ----
     {
@@ -364,37 +525,75 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
       const bool lane_ok = z < D && xg < W;
       if (ksplit == 1) {
         float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * 4 + wave) * Cout * 2 : nullptr;
-        store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
-                                 cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, st);
+        if constexpr (OUT16)
+          store_conv_tile_c8<NTW, GY, HT>(acc, reinterpret_cast<HT*>(y) + (int64_t)cur.n * ybs, bias, cur.o0, Cout, z,
+                                          cur.y0, xg, ly, half, H, W, (int64_t)S, lane_ok, st);
+        else
+          store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
+                                   cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, st);
       } else {
         store_conv_tile<NTW, GY>(acc, slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * S, nullptr,
                                  nullptr, cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, nullptr);
       }
     }
+#ifdef M355_H16_STAMPS
+    ph_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
     if (nit >= total) break;
     it = nit;
     cur = nxt;
   }
+#ifdef M355_H16_STAMPS
+  if (tid == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = m355_h16_stamps[blockIdx.x];
+    o[0] = ph_mfma; o[1] = ph_b1; o[2] = ph_commit; o[3] = ph_b2; o[4] = ph_epi; o[5] = ph_n;
+    o[6] = __builtin_amdgcn_s_memtime() - t_begin;
+    o[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+  }
+#endif
+  queue_leave(work_counter);
 }
 
 template <int NTW, int GX, typename HT>
 static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
-                       int64_t ybs, hipStream_t st, float* stat, int* work_counter) {
+                       int64_t ybs, hipStream_t st, float* stat, int* work_counter, bool out16) {
   const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
   const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus();
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, slots));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
-  hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
-                     (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                     p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter);
+  if (out16 && p.ksplit == 1)
+    hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
+                       (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger);
+  else
+    hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
+                       (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger);
+}
+
+template <typename HT>
+static void pack_w3_h16_t(const FwdPlan& p, const float* w, HT* wpb, int Cout_w, int Cin_w, bool transpose, hipStream_t st) {
+  const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
+  const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+  hipLaunchKernelGGL(pack_w3_h16_kernel<HT>, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w, p.nchunks,
+                     p.mout_pad, transpose ? 1 : 0, (int*)((char*)wpb + p.wp_bytes - 256));
+}
+
+void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
+                        hipStream_t st) {
+  if (compute == M355_COMPUTE_BF16)
+    pack_w3_h16_t<__bf16>(p, w, (__bf16*)wp, Cout_w, Cin_w, transpose, st);
+  else
+    pack_w3_h16_t<_Float16>(p, w, (_Float16*)wp, Cout_w, Cin_w, transpose, st);
 }
 
 template <typename HT>
 static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, const float* w, bool transpose,
                           int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin,
                           int mout, int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st,
-                          float* stat) {
+                          float* stat, const void* prepacked, bool out16) {
+  // out16: `out` is a c8 tensor of the same 16-bit type (out_bs in elements of it); `add` must be null
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)in16 & 15) == 0 && (in16_bs % 8) == 0, M355_EINVALID_ARG,
@@ -402,21 +601,18 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
   M355_REQUIRE((int64_t)D * H * W * 32 < (1ll << 31) && (int64_t)mout * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
                "conv3d(16-bit operands): volume exceeds the 32-bit offsets of a buffer descriptor");
   M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG, "conv3d(16-bit operands): no fused statistics for a split-K plan");
-  HT* wpb = (HT*)ws;
+  M355_REQUIRE(!out16 || (!add && ((uintptr_t)out & 15) == 0 && out_bs % 8 == 0), M355_EINVALID_ARG,
+               "conv3d(16-bit operands): a c8 output takes no fused `add` and must be 16B aligned");
+  HT* wpb = prepacked ? (HT*)prepacked : (HT*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
-  int* work_counter = (int*)((char*)ws + p.wp_bytes - 256);  // last 256 B of the packed-weight region
-  {
-    const int64_t total = (int64_t)p.nchunks * 27 * 2 * p.mout_pad * 8;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
-    hipLaunchKernelGGL(pack_w3_h16_kernel<HT>, dim3(blocks), dim3(256), 0, st, w, wpb, Cout_w, Cin_w, p.nchunks,
-                       p.mout_pad, transpose ? 1 : 0, work_counter);
-  }
+  int* work_counter = (int*)((char*)wpb + p.wp_bytes - 256);  // last 256 B of the packed-weight region
+  if (!prepacked) pack_w3_h16_t<HT>(p, w, wpb, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
 #define M355_H16_CASE(NTW, GX)                                                                               \
   if (p.ntw == NTW && p.gx == GX) {                                                                          \
     launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st, stat, \
-                            work_counter);                                                                   \
+                            work_counter, out16);                                                            \
   } else
   M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
   M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
@@ -425,7 +621,13 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
     return M355_EUNSUPPORTED;
   }
 #undef M355_H16_CASE
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && out16) {
+    const int64_t S = (int64_t)D * H * W;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256), 2048)), (unsigned)c8_blocks(mout),
+              (unsigned)N);
+    hipLaunchKernelGGL(splitk_reduce_c8_kernel<HT>, grid, dim3(256), 0, st, slab, bias, (HT*)out, mout, S, p.ksplit,
+                       (int64_t)N * mout * S, out_bs);
+  } else if (p.ksplit > 1) {
     const int64_t S = (int64_t)D * H * W;
     const int64_t total = (int64_t)N * mout * S;
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
@@ -437,12 +639,13 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
 
 int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
-                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat) {
+                 int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
+                 const void* prepacked, bool out16) {
   if (compute == M355_COMPUTE_BF16)
     return run_h16_conv_t<__bf16>(p, (const __bf16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin,
-                                  mout, D, H, W, out_bs, ws, ws_bytes, st, stat);
+                                  mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16);
   return run_h16_conv_t<_Float16>(p, (const _Float16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N,
-                                  kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat);
+                                  kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16);
 }
 
 // ------------------------------------------------ bwd-weight, bf16 compute mode (W % 32 == 0)
@@ -630,4 +833,11 @@ int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, in
   return check_launch("conv3_mfma_bww_h16");
 }
 
+#ifdef M355_H16_STAMPS
+}  // namespace m355
+extern "C" int m355_debug_h16_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(m355::m355_h16_stamps), sizeof(m355::m355_h16_stamps)) == hipSuccess ? 0 : -3;
+}
+namespace m355 {
+#endif
 }  // namespace m355

@@ -10,7 +10,7 @@
 // flop/B in fp32 -> HBM-bound.  The three k2s2 ops run as
 // fp32-MFMA GEMMs with the voxel on the lane (coalesced x reads, float2-coalesced
 // y / dy accesses); any other geometry takes the generic direct kernels below.
-#include "common.hpp"
+#include "h16.hpp"
 
 namespace m355 {
 
@@ -140,6 +140,131 @@ __global__ __launch_bounds__(256) void convt_k2s2_fwd_mfma_kernel(
       }
     }
     mt += 4;
+  }
+}
+
+// ---- c8 -> c8 variant (16-bit precision modes under no_grad, ops.Act16): the same fp32-MFMA GEMM (the op is
+// HBM-bound, the weights stay exact fp32), but x arrives as c8 items (16 B = 8 channels of a voxel, converted to
+// fp32 while staged) and the output is written as c8 straight into its slot of the decoder's concat buffer:
+// a wave owns TWO adjacent m-tiles (8 output channels), so a lane holds the 8 channels of each of its output
+// voxels (a = lane half, (b, c) on the registers) and stores them as one 16-byte item.  No fp32 round trip
+// (unpack -> conv-transpose -> pack cost 3 extra passes over the largest decoder tensors).
+template <int NVT, typename HT>
+__global__ __launch_bounds__(256) void convt_k2s2_fwd_c8_kernel(
+    const HT* __restrict__ x16, const float* __restrict__ w, const float* __restrict__ bias, HT* __restrict__ y16,
+    int Cin, int Cout, int D, int H, int W, int64_t xbs16, int64_t ybs16, int mp_per_wg) {
+  using hx8 = typename H16<HT>::x8;
+  extern __shared__ float xs[];  // [Cin2][NVT] fp32, rows >= Cin are zero
+  constexpr int NG = NVT / 32, P = 256 / NVT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int v0 = blockIdx.x * NVT;
+  const int n = blockIdx.z;
+  constexpr int KC = 8;
+  const int Cin2 = (Cin + 2 * KC - 1) / (2 * KC) * (2 * KC);
+  const int CBin = (Cin + 7) / 8;
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t OS = (int64_t)S * 8;
+  {
+    const int sv = tid % NVT, part = tid / NVT;
+    const bool vin = v0 + sv < S;
+    const hx8* xp = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs16) + (vin ? v0 + sv : 0);
+    for (int cb = part; cb < Cin2 / 8; cb += P) {
+      const bool ok = vin && cb < CBin;
+      const hx8 v = xp[ok ? (int64_t)cb * S : 0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xs[(cb * 8 + j) * NVT + sv] = (ok && cb * 8 + j < Cin) ? (float)v[j] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int mtiles = (Cout + 3) / 4, mpairs = (mtiles + 1) / 2;
+  const int mp_begin = blockIdx.y * mp_per_wg, mp_end = min(mpairs, mp_begin + mp_per_wg);
+  const int wrow = Cout * 8;
+  int64_t obase[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int v = min(v0 + g * 32 + l32, S - 1);
+    const int ix = v % W, iy = (v / W) % H, iz = v / (W * H);
+    obase[g] = ((int64_t)(2 * iz + half) * OH + 2 * iy) * OW + 2 * ix;
+  }
+  float a_cur[2][KC], a_nxt[2][KC];
+  auto wload = [&](int mp, int k0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = min((2 * mp + t) * 32 + l32, Cout * 8 - 1);
+#pragma unroll
+      for (int j = 0; j < KC; ++j) a_nxt[t][j] = w[min(k0 + 2 * j + half, Cin - 1) * wrow + col];
+    }
+  };
+  auto wmask = [&](int mp, int k0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool ook = (2 * mp + t) * 4 + (l32 >> 3) < Cout;
+#pragma unroll
+      for (int j = 0; j < KC; ++j) a_cur[t][j] = (ook && k0 + 2 * j + half < Cin) ? a_nxt[t][j] : 0.f;
+    }
+  };
+  const float* xb = xs + half * NVT + l32;
+  int mp = mp_begin + wave;
+  if (mp < mp_end) {
+    wload(mp, 0);
+    wmask(mp, 0);
+  }
+  hx8* yn = reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs16);
+  while (mp < mp_end) {
+    f32x16 acc[2][NG];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.f;
+    for (int k0 = 0; k0 < Cin2; k0 += 2 * KC) {
+      const bool last = k0 + 2 * KC >= Cin2;
+      const int nmp = last ? mp + 4 : mp, nk0 = last ? 0 : k0 + 2 * KC;
+      if (nmp < mp_end) wload(nmp, nk0);
+      float bq[2][NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bq[0][g] = xb[k0 * NVT + g * 32];
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        if (j + 1 < KC) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) bq[(j + 1) & 1][g] = xb[(k0 + 2 * j + 2) * NVT + g * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][j], bq[j & 1][g], acc[t][g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wmask(nmp, nk0);
+    }
+    // 8 output channels o0 .. o0+7 = channel block mp of the c8 output
+    const int o0 = mp * 8;
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = (bias && o0 + q < Cout) ? bias[o0 + q] : 0.f;
+    hx8* yo = yn + (int64_t)mp * OS;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (v0 + g * 32 + l32 >= S) continue;
+#pragma unroll
+      for (int bc = 0; bc < 4; ++bc) {  // (b, c) = output y / x parity
+        hx8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = (HT)(acc[0][g][q * 4 + bc] + bv[q]);
+          o[4 + q] = (HT)(acc[1][g][q * 4 + bc] + bv[4 + q]);
+        }
+        yo[obase[g] + (int64_t)(bc >> 1) * OW + (bc & 1)] = o;
+      }
+    }
+    mp += 4;
   }
 }
 
@@ -674,6 +799,40 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
   hipLaunchKernelGGL(convt_direct_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, d->N,
                      d->Cin, d->Cout, d->D, d->H, d->W, OD, OH, OW, d->k, d->stride, d->pad, xbs, ybs);
   return check_launch("convt_direct_fwd");
+}
+
+extern "C" int m355_conv_transpose3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                             const float* w, const float* bias, void* y16, int64_t y16_batch_stride,
+                                             int32_t compute, void* stream) {
+  if (int rc = validate_convt(d, "conv_transpose3d_fwd_h16")) return rc;
+  M355_REQUIRE(x16 && w && y16, M355_EINVALID_ARG, "conv_transpose3d_fwd_h16: null pointer");
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "conv_transpose3d_fwd_h16: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  const int nvt = std::min(convt_fwd_nvt(d), 64);  // two m-tiles per wave: 64 voxels keep two workgroups per CU
+  M355_REQUIRE(is_k2s2(d) && nvt && convt_fits_i32(d), M355_EUNSUPPORTED,
+               "conv_transpose3d_fwd_h16: only kernel_size 2 / stride 2 / padding 0 has a c8 kernel");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t xbs = dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8);
+  const int64_t ybs = dense_or(y16_batch_stride, c8_blocks(d->Cout) * S * 8 * 8);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)y16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "conv_transpose3d_fwd_h16: c8 tensor not 16B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t vox_tiles = ceil_div(S, nvt) * d->N;
+  const int mpairs = (int)ceil_div(ceil_div(d->Cout, 4), 2);
+  const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, vox_tiles), ceil_div(mpairs, 4)));
+  const int mp_per_wg = (int)round_up(ceil_div(mpairs, groups), 4);
+  dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)ceil_div(mpairs, mp_per_wg), (unsigned)d->N);
+  const size_t lds = (size_t)round_up(d->Cin, 16) * nvt * 4;
+#define M355_CONVT_C8(NVT, HT)                                                                                       \
+  hipLaunchKernelGGL((convt_k2s2_fwd_c8_kernel<NVT, HT>), grid, dim3(256), lds, st, (const HT*)x16, w, bias, (HT*)y16, \
+                     d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, mp_per_wg)
+  if (compute == M355_COMPUTE_BF16) {
+    if (nvt == 64) M355_CONVT_C8(64, __bf16); else M355_CONVT_C8(32, __bf16);
+  } else {
+    if (nvt == 64) M355_CONVT_C8(64, _Float16); else M355_CONVT_C8(32, _Float16);
+  }
+#undef M355_CONVT_C8
+  return check_launch("convt_k2s2_fwd_c8");
 }
 
 extern "C" int m355_conv_transpose3d_bwd_data(const m355_conv3d_desc* d, const float* dy,

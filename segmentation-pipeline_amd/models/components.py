@@ -156,14 +156,14 @@ def _check_conv_module(m):
     _uniform_int(m.padding, "padding")
 
 
-def run_conv(m, x, add=None, out=None, stats=None):
+def run_conv(m, x, add=None, out=None, stats=None, c8_out=False):
     """Execute an nn.Conv3d-like parameter container with the HIP conv kernels."""
     if hasattr(m, "effective"):
         weight, bias = m.effective()
     else:
         weight, bias = m.weight, m.bias
     return ops.conv3d(x, weight, bias, add=add, stride=_uniform_int(m.stride, "stride"),
-                      padding=_uniform_int(m.padding, "padding"), out=out, stats=stats)
+                      padding=_uniform_int(m.padding, "padding"), out=out, stats=stats, c8_out=c8_out)
 
 
 def _act_code(m):
@@ -286,11 +286,14 @@ class Block3d(nn.Module):
     def forward(self, x, out: Optional[ops.OutSlot] = None, c8_out: bool = False):
         """`c8_out` (or an `out` slot of a c8 concat buffer): in a 16-bit precision mode under no_grad the
         block's result is returned as an `ops.Act16`; the activations BETWEEN its convolutions always are."""
-        res = run_conv(self.res_conv, x) if self.residual else None
         drop = self.dropout is not None and self.training and self.dropout.p > 0.0
         final_out = None if drop else out
         flow = ops.h16_flow()
         c8_out = bool(flow) and not drop and (c8_out or (out is not None and out.buf16 is not None))
+        last_norm = (getattr(self.layers, f'norm{self._num_convs - 1}', None) is not None or
+                     getattr(self.layers, f'activation{self._num_convs - 1}', None) is not None) if self._num_convs else False
+        # the residual branch is added inside the last norm/act pass: in the c8 flow it is a c8 tensor too
+        res = run_conv(self.res_conv, x, c8_out=c8_out and last_norm) if self.residual else None
 
         h = x
         for i in range(self._num_convs):
@@ -305,8 +308,8 @@ class Block3d(nn.Module):
             else:
                 # the conv epilogue emits the partial sums of the normalisation that follows
                 stats = {} if wants_batch_stats(norm) else None
-                h = run_conv(conv, h, stats=stats)
                 c8 = flow if (not last or c8_out) else 0
+                h = run_conv(conv, h, stats=stats, c8_out=bool(c8))   # c8 flow: the pre-norm tensor is c8 as well
                 h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats, c8=c8)
         if self._num_convs == 0 and res is not None:
             h = ops.add(res, h)

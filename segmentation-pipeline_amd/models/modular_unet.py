@@ -144,6 +144,8 @@ class ModularUNet(nn.Module):
         ups = [_upsample_out_channels(self.upsampling[i], f[i + 1]) for i in range(self.depth - 1)]
         if flow and any(c % 8 for c in list(f) + ups):
             flow = 0
+        if flow:
+            x = ops.pack_act16(x, flow)   # the (few-channel) network input joins the c8 flow: its conv writes c8 too
         skips = []
         for i in range(self.depth):
             if i != self.depth - 1:

@@ -212,17 +212,70 @@ def as_f32(x):
     return x.to_f32() if isinstance(x, Act16) else x
 
 
-def _conv3d_act16(x16: Act16, weight, bias, add, stats):
-    """3x3x3 / s1 / p1 forward on a c8 input (no autograd: the c8 flow only exists under no_grad)."""
+# Packed weights are cached per parameter VERSION: the kernels want the filter re-laid-out ([c][tap][o], 16-bit for
+# the 16-bit modes, flipped / transposed for the data gradient) and the library used to repack before every
+# launch (234 launches per profiled run).  Weights only change at optimizer.step(), which bumps `_version`.
+PACK_CACHE = True
+
+
+def _packed_weight(weight, d, which):
+    """-> (pointer argument, flags) for a conv entry point: the cached packed form of `weight` for descriptor
+    `d` (which: 0 forward, 1 data gradient) with M355_CONV_W_PACKED, or the plain weight with flags 0."""
+    if not PACK_CACHE:
+        return weight, 0
+    L = _lib.lib()
+    ver, ptr = weight._version, weight.data_ptr()
+    cache = getattr(weight, "_m355_packed", None)
+    if cache is None or cache[0] != ver or cache[1] != ptr:
+        cache = (ver, ptr, {})
+        try:
+            weight._m355_packed = cache
+        except (AttributeError, RuntimeError):
+            return weight, 0
+    key = (which, d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.compute)
+    buf = cache[2].get(key)
+    if buf is None:
+        nbytes = L.m355_conv3d_packed_bytes(C.byref(d), which)
+        if nbytes == 0:
+            return weight, 0
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=weight.device)
+        check(L.m355_conv3d_pack(C.byref(d), which, _p(weight), _p(buf), _stream()), "conv3d_pack")
+        cache[2][key] = buf
+    return buf, _lib.CONV_W_PACKED
+
+
+def _with_flags(d, flags):
+    if flags == d.flags:
+        return d
+    return ConvDesc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.out_pad, d.x_batch_stride,
+                    d.y_batch_stride, d.compute, flags)
+
+
+def _c8_channel_partials(x16: Act16, stats: dict):
+    """statistics partials of a c8 tensor (pre-norm output of a conv without fused statistics)"""
+    L = _lib.lib()
+    N, Cc = x16.shape[:2]
+    slots = int(L.m355_act16_partials_slots(x16.S))
+    part = torch.empty((N, slots, Cc, 2), dtype=torch.float32, device=x16.device)
+    check(L.m355_act16_channel_partials(x16.ptr(), x16.batch_stride(), N, Cc, x16.S, x16.compute, _p(part), _stream()),
+          "act16_channel_partials")
+    stats["partials"], stats["slots"] = part, slots
+
+
+def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False):
+    """3x3x3 / s1 / p1 forward on a c8 input (no autograd: the c8 flow only exists under no_grad).  c8_out: the
+    result (a pre-norm tensor) is written by the conv epilogue as c8 too and returned as an Act16."""
     L = _lib.lib()
     _require(weight, bias, add)
     weight = weight.contiguous()
     N, Cin, D, H, W = x16.shape
     Cout = weight.shape[0]
-    y = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x16.device)
+    c8_out = c8_out and add is None
     if add is not None:
         add = add.contiguous()
     d = _conv_desc(N, Cin, Cout, D, H, W, 3, 1, 1, 0, 0, compute=x16.compute)
+    wbuf, flags = _packed_weight(weight, d, 0)
+    d = _with_flags(d, flags)
     ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0), x16.device)
     prof = CONV_PROFILE
     if prof is not None:
@@ -233,12 +286,20 @@ def _conv3d_act16(x16: Act16, weight, bias, add, stats):
     if slots > 0:
         part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x16.device)
         stats["partials"], stats["slots"] = part, slots
-    check(L.m355_conv3d_fwd_h16(C.byref(d), x16.ptr(), x16.batch_stride(), _p(weight), _p(bias), _p(add), _p(y),
-                                _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16")
+    if c8_out:
+        y = Act16.empty(N, Cout, (D, H, W), x16.compute, x16.device)
+        check(L.m355_conv3d_fwd_h16_c8(C.byref(d), x16.ptr(), x16.batch_stride(), _p(wbuf), _p(bias), y.ptr(),
+                                       y.batch_stride(), _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16_c8")
+    else:
+        y = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x16.device)
+        check(L.m355_conv3d_fwd_h16(C.byref(d), x16.ptr(), x16.batch_stride(), _p(wbuf), _p(bias), _p(add), _p(y),
+                                    _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16")
     if prof is not None:
         e1.record()
         prof.append(("conv3d_fwd", 2.0 * 27 * Cin * Cout * N * D * H * W, e0, e1, conv_plan(d, 0),
-                     _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 4)))
+                     _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 2 if c8_out else 4)))
+    if c8_out and stats is not None and slots == 0:
+        _c8_channel_partials(y, stats)
     return y
 
 
@@ -287,6 +348,8 @@ class _Conv3dFn(torch.autograd.Function):
                     raise _lib.M355Error("conv3d: a fused `add` needs the output's batch stride (write to a dense "
                                          "tensor and copy_into the slot instead)")
         d = _conv_desc(N, Cin, Cout, D, H, W, k, meta.stride, meta.pad, xbs, ybs, compute=_COMPUTE[_compute_mode])
+        wbuf, flags = _packed_weight(weight, d, 0)
+        dk = _with_flags(d, flags)
         ws = _workspace(L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
         prof = CONV_PROFILE
         if prof is not None:
@@ -296,11 +359,11 @@ class _Conv3dFn(torch.autograd.Function):
         if slots > 0:
             # statistics of the following normalisation fused into the conv epilogue (per-wave partials)
             part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x.device)
-            check(L.m355_conv3d_fwd_stats(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(part), _p(ws),
+            check(L.m355_conv3d_fwd_stats(C.byref(dk), _p(x), _p(wbuf), _p(bias), _p(add), _p(y), _p(part), _p(ws),
                                           ws.numel(), _stream()), "conv3d_fwd_stats")
             meta.stats["partials"], meta.stats["slots"] = part, slots
         else:
-            check(L.m355_conv3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(add), _p(y), _p(ws),
+            check(L.m355_conv3d_fwd(C.byref(dk), _p(x), _p(wbuf), _p(bias), _p(add), _p(y), _p(ws),
                                     ws.numel(), _stream()), "conv3d_fwd")
         if prof is not None:
             e1.record()
@@ -345,11 +408,13 @@ class _Conv3dFn(torch.autograd.Function):
             # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part
             dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
             dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, d.y_batch_stride, compute=d.compute)
+            wbuf, flags = _packed_weight(weight, dd, 1)
             ws = _workspace(L.m355_conv3d_bwd_data_workspace(C.byref(dd)), x.device)
+            dd = _with_flags(dd, flags)
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(L.m355_conv3d_bwd_data(C.byref(dd), _p(dy), _p(weight), _p(dx), _p(ws), ws.numel(),
+            check(L.m355_conv3d_bwd_data(C.byref(dd), _p(dy), _p(wbuf), _p(dx), _p(ws), ws.numel(),
                                          _stream()), "conv3d_bwd_data")
             if prof is not None:
                 e1.record()
@@ -367,11 +432,12 @@ class _Conv3dFn(torch.autograd.Function):
 
 
 def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[OutSlot] = None,
-           stats: Optional[dict] = None):
+           stats: Optional[dict] = None, c8_out: bool = False):
     """nn.Conv3d forward (cubic kernel).  `x` is a tensor or a `Concat`; `add` is fused
     into the epilogue (y = conv(x) + bias + add).  `stats`: an empty dict asks the kernel to also
     emit the partial sums the following normalisation needs (filled in when the kernel variant
-    supports it; pass it on as `NormCfg.stats`)."""
+    supports it; pass it on as `NormCfg.stats`).  `c8_out`: in the c8 flow (x is an `Act16`) return the result
+    as an `Act16` written by the conv epilogue (for the normalisation pass that follows)."""
     k = weight.shape[2]
     if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
         raise NotImplementedError("only cubic kernels are supported")
@@ -381,7 +447,7 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
         return pack_act16(conv3d(x, weight, bias, add, stride, padding, None, stats), out.buf16.compute, out.act16())
     if isinstance(x, Act16):
         if k == 3 and stride == 1 and padding == 1:
-            return _conv3d_act16(x, weight, bias, add, stats)
+            return _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out)
         x = x.to_f32()
     if isinstance(x, Concat):
         meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats)
@@ -440,6 +506,18 @@ def conv_transpose3d(x, weight, bias=None, stride=2, padding=0, output_padding=0
     """nn.ConvTranspose3d forward (cubic kernel, weight [Cin, Cout, k, k, k])."""
     k = weight.shape[2]
     if isinstance(x, Act16):
+        if k == 2 and stride == 2 and padding == 0 and output_padding == 0:   # c8 -> c8 kernel
+            _require(weight, bias)
+            N, Cin, D, H, W = x.shape
+            Cout = weight.shape[1]
+            y16 = out.act16() if (out is not None and out.buf16 is not None) else None
+            if y16 is None:
+                y16 = Act16.empty(N, Cout, (2 * D, 2 * H, 2 * W), x.compute, x.device)
+            d = _conv_desc(N, Cin, Cout, D, H, W, 2, 2, 0, 0, 0)
+            check(_lib.lib().m355_conv_transpose3d_fwd_h16(C.byref(d), x.ptr(), x.batch_stride(), _p(weight.contiguous()),
+                                                           _p(bias), y16.ptr(), y16.batch_stride(), x.compute, _stream()),
+                  "conv_transpose3d_fwd_h16")
+            return y16
         y = _ConvT3dFn.apply(x.to_f32(), weight, bias, (k, stride, padding, output_padding, None))
         return _into_c8_slot(y, out, x.compute)
     return _ConvT3dFn.apply(x, weight, bias, (k, stride, padding, output_padding, out))
@@ -461,18 +539,19 @@ class NormCfg:
     c8: int = 0                    # 16-bit no-grad flow: emit the result ONLY in the c8 layout (compute code)
 
 
-def _norm_statistics(L, d, x, cfg, N, Cc):
+def _norm_statistics(L, d, x, cfg, N, Cc, device=None):
     """mean / rstd of the normalisation: from the conv epilogue partials, from x, or from BN running stats."""
+    device = x.device if device is None else device
     ns = L.m355_norm_num_stats(C.byref(d))
-    mean = torch.empty(ns, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(ns, dtype=torch.float32, device=x.device)
+    mean = torch.empty(ns, dtype=torch.float32, device=device)
+    rstd = torch.empty(ns, dtype=torch.float32, device=device)
     use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
     fused = cfg.stats.get("partials") if cfg.stats else None
     if fused is not None and tuple(fused.shape) != (N, cfg.stats["slots"], Cc, 2):
         raise _lib.M355Error(f"norm_act: statistics partials {tuple(fused.shape)} do not belong to this tensor")
     upd = cfg.groups == 0 and cfg.training and use_batch
     if use_batch and fused is not None:
-        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), device)
         check(L.m355_norm_stats_from_partials(C.byref(d), _p(fused), int(cfg.stats["slots"]), _p(mean), _p(rstd),
                                               _p(cfg.running_mean) if upd else None,
                                               _p(cfg.running_var) if upd else None,
@@ -491,22 +570,42 @@ def _norm_statistics(L, d, x, cfg, N, Cc):
 
 
 def _norm_act_c8(x, gamma, beta, add, cfg: NormCfg) -> Act16:
-    """norm + activation (+ residual) whose ONLY output is c8 (16-bit no-grad flow): reads the fp32 conv
-    output once, writes 2 bytes per element."""
+    """norm + activation (+ residual) whose ONLY output is c8 (16-bit no-grad flow).  x: the fp32 conv output
+    (read once, 2 bytes per element written) or the c8 pre-norm tensor of m355_conv3d_fwd_h16_c8 (2 + 2 bytes)."""
     L = _lib.lib()
-    _require(x, gamma, beta, add)
-    x, xbs = _dense_channels(x)
-    N, Cc = x.shape[0], x.shape[1]
-    S = x.shape[2] * x.shape[3] * x.shape[4]
-    abs_ = 0
-    if add is not None:
-        add, abs_ = _dense_channels(add)
+    _require(gamma, beta)
+    x_c8 = isinstance(x, Act16)
+    if x_c8:
+        N, Cc, spatial, S, xbs = x.shape[0], x.C, x.spatial, x.S, 0
+    else:
+        _require(x)
+        x, xbs = _dense_channels(x)
+        N, Cc, spatial = x.shape[0], x.shape[1], tuple(x.shape[2:])
+        S = spatial[0] * spatial[1] * spatial[2]
     out16 = cfg.out.act16() if cfg.out is not None else None
     if out16 is None:
-        out16 = Act16.empty(N, Cc, x.shape[2:], cfg.c8, x.device)
-    elif out16.shape != tuple(x.shape):
-        raise _lib.M355Error(f"c8 slot shape {out16.shape} != op output shape {tuple(x.shape)}")
+        out16 = Act16.empty(N, Cc, spatial, cfg.c8, gamma.device if gamma is not None else (x.device))
+    elif out16.shape != (N, Cc) + tuple(spatial):
+        raise _lib.M355Error(f"c8 slot shape {out16.shape} != op output shape {(N, Cc) + tuple(spatial)}")
+    abs_ = 0
+    if add is not None and not x_c8:
+        add, abs_ = _dense_channels(as_f32(add))
+        _require(add)
     d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, 0, abs_)
+    if x_c8:
+        use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
+        if use_batch and not (cfg.stats and cfg.stats.get("partials") is not None):
+            cfg.stats = {} if cfg.stats is None else cfg.stats
+            _c8_channel_partials(x, cfg.stats)
+        mean, rstd, _ = _norm_statistics(L, d, None, cfg, N, Cc, device=x.device)
+        add16 = None
+        if add is not None:
+            add16 = add if isinstance(add, Act16) else pack_act16(add, cfg.c8)
+        check(L.m355_norm_act_fwd_c8(C.byref(d), x.ptr(), x.batch_stride(), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                     add16.ptr() if add16 is not None else None,
+                                     add16.batch_stride() if add16 is not None else 0, out16.ptr(),
+                                     out16.batch_stride(), cfg.c8, _stream()), "norm_act_fwd_c8")
+        return out16
     mean, rstd, _ = _norm_statistics(L, d, x, cfg, N, Cc)
     check(L.m355_norm_act_fwd_h16(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), None,
                                   out16.ptr(), out16.batch_stride(), cfg.c8, _stream()), "norm_act_fwd_h16")
@@ -560,7 +659,7 @@ def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
     fused with the residual sum (components.py:67-68): act(norm(x)) + add.  With `cfg.c8` set (16-bit
     precision mode under no_grad) the result is an `Act16` and nothing is written in fp32."""
     if cfg.c8 and not torch.is_grad_enabled():
-        return _norm_act_c8(as_f32(x), gamma, beta, as_f32(add) if add is not None else None, cfg)
+        return _norm_act_c8(x, gamma, beta, add, cfg)
     return _NormActFn.apply(as_f32(x), gamma, beta, as_f32(add) if add is not None else None, cfg)
 
 

@@ -74,10 +74,29 @@ class RawOps:
         N, Cin, D, H, W = x_shape
         return ConvDesc(N, Cin, Cout, D, H, W, k, stride, pad, out_pad, xbs, ybs, compute, 0)
 
-    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0):
+    def pack_weights(self, w, x_shape, which, compute=0):
+        """m355_conv3d_pack: (packed buffer, descriptor flags) -- HIP library only"""
+        w = self.to(w)
+        d = self.conv_desc(x_shape, w.shape[0], w.shape[2], 1, 1, compute=compute)
+        n = self.lib.m355_conv3d_packed_bytes(C.byref(d), which)
+        assert n > 0
+        buf = torch.empty(int(n), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.m355_conv3d_pack(C.byref(d), which, _p(w), _p(buf), self._stream()), "conv3d_pack")
+        return buf
+
+    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0, packed=None):
+        """packed: buffer from pack_weights(w, x.shape, 0) -> the call uses M355_CONV_W_PACKED"""
         x, w, bias, add = map(self.to, (x, w, bias, add))
         k = w.shape[2]
         d = self.conv_desc(x.shape, w.shape[0], k, stride, pad, compute=compute)
+        if packed is not None:
+            d.flags = _lib.CONV_W_PACKED
+            od = lambda n: (n + 2 * pad - k) // stride + 1
+            y = self.empty(x.shape[0], w.shape[0], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
+            ws = self._ws("conv3d_fwd_workspace", d)
+            self._chk(self.fn("conv3d_fwd")(C.byref(d), _p(x), _p(packed), _p(bias), _p(add), _p(y), _p(ws), ws.numel(),
+                                            self._stream()), "conv3d_fwd(packed)")
+            return y
         od = lambda n: (n + 2 * pad - k) // stride + 1
         y = self.empty(x.shape[0], w.shape[0], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
         ws = self._ws("conv3d_fwd_workspace", d)
@@ -132,6 +151,41 @@ class RawOps:
                   "norm_stats_from_partials")
         return y, mean, rstd
 
+    def conv3d_fwd_h16_c8(self, x16, Cin, spatial, w, bias=None, compute=1, with_stats=False):
+        """forward with c8 input AND c8 output; with_stats -> (y16, partials [N, P, Cout, 2])"""
+        w, bias = self.to(w), self.to(bias)
+        N, CBp, S, _ = x16.shape
+        Cout = w.shape[0]
+        d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 3, 1, 1, compute=compute)
+        y16 = torch.zeros((N, (Cout + 7) // 8, S, 8), dtype=x16.dtype, device=self.device)
+        n = self.lib.m355_conv3d_h16_workspace(C.byref(d), 0)
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        part = None
+        if with_stats:
+            slots = self.fn("conv3d_stats_slots")(C.byref(d))
+            assert slots > 0
+            part = self.empty(N, slots, Cout, 2)
+        self._chk(self.fn("conv3d_fwd_h16_c8")(C.byref(d), _p(x16), CBp * S * 8, _p(w), _p(bias), _p(y16), 0, _p(part),
+                                               _p(ws), ws.numel(), self._stream()), "conv3d_fwd_h16_c8")
+        return (y16, part) if with_stats else y16
+
+    def norm_act_fwd_c8(self, x16, Cc, mean, rstd, gamma, beta, groups, act, compute, add16=None, eps=1e-5, slope=0.01):
+        mean, rstd, gamma, beta = map(self.to, (mean, rstd, gamma, beta))
+        N, CB, S, _ = x16.shape
+        d = NormDesc(N, Cc, S, groups, act, eps, slope, 0, 0, 0)
+        y16 = torch.empty_like(x16)
+        self._chk(self.fn("norm_act_fwd_c8")(C.byref(d), _p(x16), 0, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add16), 0,
+                                             _p(y16), 0, compute, self._stream()), "norm_act_fwd_c8")
+        return y16
+
+    def act16_channel_partials(self, x16, Cc, compute):
+        N, CB, S, _ = x16.shape
+        slots = int(self.lib.m355_act16_partials_slots(S))
+        part = self.empty(N, slots, Cc, 2)
+        self._chk(self.fn("act16_channel_partials")(_p(x16), 0, N, Cc, S, compute, _p(part), self._stream()),
+                  "act16_channel_partials")
+        return part
+
     def conv3d_bwd_data_h16(self, dy16, Cout, w, x_shape, compute=1):
         w = self.to(w)
         N, CBp, S, _ = dy16.shape
@@ -142,6 +196,17 @@ class RawOps:
         self._chk(self.fn("conv3d_bwd_data_h16")(C.byref(d), _p(dy16), CBp * S * 8, _p(w), _p(dx), _p(ws), ws.numel(),
                                                  self._stream()), "conv3d_bwd_data_h16")
         return dx
+
+    def conv_transpose3d_fwd_h16(self, x16, Cin, spatial, w, bias, compute):
+        """k2 s2 conv-transpose c8 -> c8; returns the c8 output [N, CBout, 8S, 8]"""
+        w, bias = self.to(w), self.to(bias)
+        N, CB, S, _ = x16.shape
+        Cout = w.shape[1]
+        d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 2, 2, 0)
+        y16 = torch.empty((N, (Cout + 7) // 8, 8 * S, 8), dtype=x16.dtype, device=self.device)
+        self._chk(self.fn("conv_transpose3d_fwd_h16")(C.byref(d), _p(x16), 0, _p(w), _p(bias), _p(y16), 0, compute,
+                                                      self._stream()), "conv_transpose3d_fwd_h16")
+        return y16
 
     def conv3d_fwd_stats(self, x, w, bias=None, groups=0, eps=1e-5):
         """fused conv + statistics: returns (y, mean, rstd) of the normalisation that follows the conv, or
@@ -168,11 +233,13 @@ class RawOps:
                   "norm_stats_from_partials")
         return y, mean, rstd
 
-    def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1, compute=0):
+    def conv3d_bwd_data(self, dy, w, x_shape, stride=1, pad=1, compute=0, packed=None):
         dy, w = self.to(dy), self.to(w)
         d = self.conv_desc(x_shape, w.shape[0], w.shape[2], stride, pad, compute=compute)
         dx = self.empty(*x_shape)
         ws = self._ws("conv3d_bwd_data_workspace", d)
+        if packed is not None:
+            d.flags, w = _lib.CONV_W_PACKED, packed
         self._chk(self.fn("conv3d_bwd_data")(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel(), self._stream()),
                   "conv3d_bwd_data")
         return dx

@@ -108,6 +108,57 @@ def test_conv3d_fused_statistics(hip, oracle, env, tuning):
         close(rstd, r2, 1e-5, 1e-6, "rstd vs norm_stats")
 
 
+@pytest.mark.parametrize("compute", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}])
+def test_conv3d_packed_weights_reused_across_launches(hip, compute, env, tuning):
+    """M355_CONV_W_PACKED: weights packed once by m355_conv3d_pack and reused launch after launch give the very bits
+    of the repack-per-launch path; the work-queue state inside the packed buffer is reset by the draining kernel,
+    so the 2nd, 3rd ... launch on the same buffer see fresh queues (persistent kernels, tiny residency, small-Cout
+    VALU kernel, data gradient)."""
+    tuning(**env)
+    for (N, ci, co, D, H, W) in [(2, 12, 40, 9, 10, 36), (1, 16, 3, 8, 8, 32), (1, 32, 32, 8, 16, 64)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+        ref = hip.conv3d_fwd(x, w, b, compute=compute)
+        pk = hip.pack_weights(w, x.shape, 0, compute)
+        for _ in range(3):
+            assert torch.equal(hip.conv3d_fwd(x, w, b, compute=compute, packed=pk), ref)
+        dy = rnd(N, co, D, H, W, seed=5)
+        refd = hip.conv3d_bwd_data(dy, w, x.shape, compute=compute)
+        pkd = hip.pack_weights(w, x.shape, 1, compute)
+        for _ in range(3):
+            assert torch.equal(hip.conv3d_bwd_data(dy, w, x.shape, compute=compute, packed=pkd), refd)
+
+
+def test_model_packed_weight_cache_follows_parameter_versions(golden):
+    """ops caches the packed weights per parameter version: same results as with the cache off, re-packed after an
+    optimizer step (SGD trajectory golden stays green in test_model_gpu.py), and keyed by the data pointer."""
+    from functools import partial
+    from torch import nn
+    from segmentation_pipeline_amd import ops
+    from segmentation_pipeline_amd.models import ModularUNet
+    g = golden("unet_gn_convt.npz")
+    model = ModularUNet(4, 3, [8, 16, 32], 3, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                        upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+    model.load_state_dict(g.state_dict("m.sd."))
+    model = model.cuda().train()
+    x = g.t("x").cuda()
+    w = model.down_blocks[1].layers.conv0.weight
+    p1 = model(x)
+    assert w._m355_packed[0] == w._version and len(w._m355_packed[2]) >= 1
+    p1.sum().backward()
+    assert any(k[0] == 1 for k in w._m355_packed[2]), "data-gradient packing cached on the parameter"
+    try:
+        ops.PACK_CACHE = False
+        p2 = model(x)
+    finally:
+        ops.PACK_CACHE = True
+    assert torch.equal(p1, p2)
+    with torch.no_grad():
+        w.mul_(0.5)
+    p3 = model(x)
+    assert w._m355_packed[0] == w._version and not torch.equal(p3, p1)
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
@@ -445,6 +496,64 @@ def test_norm_act_and_avgpool_c8_outputs(hip, oracle, compute):
         pref = torch.nn.functional.avg_pool3d(got, 2, 2).to(dt).float()
         pg = _c8_to_ncdhw(p16, Cc, (D // 2, H // 2, W // 2))
         assert ((pg - pref).abs() <= ulp * pref.abs() * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("env", [{"M355_CONV_KSPLIT": "1"}, {"M355_CONV_KSPLIT": "2", "M355_CONV_SLOTS": "5"},
+                                 {"M355_CONV_KSPLIT": "1", "M355_CONV_NTW": "1"}])
+def test_conv3d_h16_c8_output_and_c8_norm(hip, oracle, compute, env, tuning):
+    """m355_conv3d_fwd_h16_c8: the epilogue writes c8 (lanes exchange channel halves with v_permlane32_swap) ==
+    the fp32-output kernel's result rounded once; statistics fused (fp32, before rounding) or taken from the c8
+    tensor (m355_act16_channel_partials, split-K plans); m355_norm_act_fwd_c8 (c8 -> c8, residual in c8)."""
+    tuning(**env)
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    ulp = 2.0 ** -8 if compute == 1 else 2.0 ** -11
+    for (N, ci, co, D, H, W, groups) in [(2, 16, 40, 9, 10, 36, 8), (1, 24, 13, 6, 21, 16, 0), (1, 32, 64, 8, 8, 32, 8)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
+        x16 = hip.act16_pack(x, compute)
+        y32 = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute).cpu()
+        fused = env["M355_CONV_KSPLIT"] == "1"
+        if fused:
+            y16, part = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
+        else:
+            y16 = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute)
+            part = hip.act16_channel_partials(y16, co, compute)
+        got = _c8_to_ncdhw(y16, co, (D, H, W))
+        assert torch.equal(got, y32.to(dt).float()), "c8 output == the fp32 output rounded once"
+        if co % 8:
+            assert (y16[:, -1, :, co % 8:].float() == 0).all()
+        # per-channel sums from the partials: of the fp32 values when fused, of the rounded values otherwise
+        src = y32 if fused else got
+        s1 = part[..., 0].sum(dim=1).cpu().double()
+        s2 = part[..., 1].sum(dim=1).cpu().double()
+        torch.testing.assert_close(s1, src.double().sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(s2, (src.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
+        # c8 -> c8 normalise + activation + residual
+        gamma, beta = rnd(co, seed=4) * 0.5 + 1.0, rnd(co, seed=5) * 0.1
+        mean, rstd = oracle.norm_stats(got, groups)[:2]
+        res = rnd(N, co, D, H, W, seed=6)
+        res16 = hip.act16_pack(res, compute)
+        a16 = hip.norm_act_fwd_c8(y16, co, mean, rstd, gamma, beta, groups, 1, compute, add16=res16)
+        ref = oracle.norm_act_fwd(got, mean, rstd, gamma, beta, groups, 1, res.to(dt).float())
+        ga = _c8_to_ncdhw(a16, co, (D, H, W))
+        assert ((ga - ref).abs() <= ulp * ref.abs() * 1.01 + 2e-5).all()
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_conv_transpose3d_c8(hip, oracle, compute):
+    """m355_conv_transpose3d_fwd_h16 (k2 s2, c8 -> c8, exact fp32 arithmetic inside) == the oracle on the 16-bit
+    input values, rounded once to the 16-bit type; ragged channel counts and voxel tiles."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    ulp = 2.0 ** -8 if compute == 1 else 2.0 ** -11
+    for (N, ci, co, D, H, W) in [(1, 64, 64, 4, 4, 8), (2, 24, 40, 3, 5, 6), (1, 320, 48, 2, 2, 2), (1, 8, 13, 4, 4, 4)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(ci, co, 2, 2, 2, seed=2) * 0.2, rnd(co, seed=3)
+        x16 = hip.act16_pack(x, compute)
+        ref = oracle.convt_fwd(x.to(dt).float(), w, b, 2, 0, 0)
+        y16 = hip.conv_transpose3d_fwd_h16(x16, ci, (D, H, W), w, b, compute)
+        got = _c8_to_ncdhw(y16, co, (2 * D, 2 * H, 2 * W))
+        assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + 2e-5).all()
+        if co % 8:
+            assert (y16[:, -1, :, co % 8:].float() == 0).all()
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])

@@ -48,8 +48,11 @@ def main():
         if compute and ci > 4:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
             x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
         for o in ops:
-            if o == "fwd" and compute and ci > 4:
-                ms = timeit(lambda: hip.conv3d_fwd_h16(x16, ci, (sp, sp, sp), w, compute=compute))
+            if o == "fwd" and compute and ci > 4:   # c8 in, c8 out (the inference flow); --f32out: fp32 NCDHW output
+                if "--f32out" in sys.argv:
+                    ms = timeit(lambda: hip.conv3d_fwd_h16(x16, ci, (sp, sp, sp), w, compute=compute))
+                else:
+                    ms = timeit(lambda: hip.conv3d_fwd_h16_c8(x16, ci, (sp, sp, sp), w, compute=compute))
             elif o == "bwd_data" and compute and ci > 4:
                 ms = timeit(lambda: hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
             elif o == "fwd":

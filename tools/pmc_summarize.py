@@ -39,9 +39,16 @@ def calib(root, ctr):
     return out
 
 
+def source_hash():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash as h
+    return h()
+
+
 def main():
     root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-    out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
+    out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
     fetch = load(f"{root}/bench_FETCH_SIZE/**/*counter_collection.csv")
     write = load(f"{root}/bench_WRITE_SIZE/**/*counter_collection.csv")
     kernels = {}
@@ -57,6 +64,7 @@ def main():
                      "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer`; bytes = (2*FETCH_SIZE + "
                      "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads 1/2 for coalesced streams -- calibrated with "
                      "tools/pmc_calib.py)",
+           "source_hash": source_hash(),   # bench.py quotes these figures only for exactly these kernel sources
            "calibration": {"FETCH_SIZE": calib(root, "FETCH_SIZE"), "WRITE_SIZE": calib(root, "WRITE_SIZE")},
            "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
