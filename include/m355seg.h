@@ -388,6 +388,25 @@ int m355_patch_finalize(const float* accum, const float* count, float* out,
 int m355_argmax_confusion(const float* prob, const int32_t* target, int32_t* argmax_out,
                           int64_t* counts, int32_t N, int32_t C, int64_t S, void* stream);
 
+/* ------------------------------------------------- test-time ensembles
+ * EnsembleFlips / EnsembleOrientations / EnsembleModels (models/ensemble.py:38-103): a member predicts on
+ * x.permute(0, 1, *perm).flip(f) and the reference maps the prediction back with .flip(f).permute(inverse) before
+ * apply_strategy (:16-35) stacks all members and takes the mean, or argmax -> mode -> one_hot.
+ * size3 = canonical spatial size; perm3[j] in {0,1,2} = canonical axis of member axis j; flip_mask bit j = member
+ * axis j is reversed (identity: perm3 = {0,1,2}, flip_mask = 0).
+ *   m355_flip_permute        member input [N,C,size3[perm]] from x [N,C,size3], one gather pass
+ *   m355_ensemble_accumulate reads a member prediction THROUGH the inverse transform (it is never mapped back or
+ *                            stacked): mode 0: acc[N,C,S] (+)= pred; mode 1: votes[N,C,S] (int32) += 1 at the
+ *                            member's argmax class (first maximum, as torch.argmax); first != 0 initialises
+ *   m355_ensemble_finalize   mode 0: mean_out = acc / members; mode 1: onehot_out[N,C,S] (int64) of the class with
+ *                            the most votes, ties -> the smallest class index (torch.mode on the CPU) */
+int m355_flip_permute(const float* x, float* member, int32_t N, int32_t C, const int32_t* size3, const int32_t* perm3,
+                      int32_t flip_mask, void* stream);
+int m355_ensemble_accumulate(const float* pred, float* acc, int32_t* votes, int32_t N, int32_t C, const int32_t* size3,
+                             const int32_t* perm3, int32_t flip_mask, int32_t mode, int32_t first, void* stream);
+int m355_ensemble_finalize(const float* acc, const int32_t* votes, float* mean_out, int64_t* onehot_out, int32_t N,
+                           int32_t C, int64_t S, int32_t members, int32_t mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -956,3 +956,73 @@ int m355o_argmax_confusion(const float* prob, const int32_t* target, int32_t* ar
     }
   return 0;
 }
+
+/* ------------------------------------------------- test-time ensembles
+ * models/ensemble.py:16-35 (apply_strategy: stack -> mean, or argmax -> mode -> one_hot) and :50-103 (members run
+ * on x.permute(perm).flip(f) and are mapped back with .flip(f).permute(inverse)).  perm3[j] = canonical axis of
+ * member axis j, flip bit j = member axis j reversed. */
+static int64_t member_offset(const int32_t* size, const int32_t* perm, int flip, int i0, int i1, int i2) {
+  const int idx[3] = {i0, i1, i2};
+  int msize[3], a[3];
+  for (int j = 0; j < 3; ++j) {
+    msize[j] = size[perm[j]];
+    a[j] = ((flip >> j) & 1) ? msize[j] - 1 - idx[perm[j]] : idx[perm[j]];
+  }
+  return ((int64_t)a[0] * msize[1] + a[1]) * msize[2] + a[2];
+}
+int m355o_flip_permute(const float* x, float* member, int32_t N, int32_t C, const int32_t* size3, const int32_t* perm3,
+                       int32_t flip_mask, void* stream) {
+  (void)stream;
+  const int64_t S = (int64_t)size3[0] * size3[1] * size3[2];
+  for (int64_t nc = 0; nc < (int64_t)N * C; ++nc)
+    for (int i0 = 0; i0 < size3[0]; ++i0)
+      for (int i1 = 0; i1 < size3[1]; ++i1)
+        for (int i2 = 0; i2 < size3[2]; ++i2)
+          member[nc * S + member_offset(size3, perm3, flip_mask, i0, i1, i2)] =
+              x[nc * S + ((int64_t)i0 * size3[1] + i1) * size3[2] + i2];
+  return 0;
+}
+int m355o_ensemble_accumulate(const float* pred, float* acc, int32_t* votes, int32_t N, int32_t C, const int32_t* size3,
+                              const int32_t* perm3, int32_t flip_mask, int32_t mode, int32_t first, void* stream) {
+  (void)stream;
+  const int64_t S = (int64_t)size3[0] * size3[1] * size3[2];
+  for (int n = 0; n < N; ++n)
+    for (int i0 = 0; i0 < size3[0]; ++i0)
+      for (int i1 = 0; i1 < size3[1]; ++i1)
+        for (int i2 = 0; i2 < size3[2]; ++i2) {
+          const int64_t v = ((int64_t)i0 * size3[1] + i1) * size3[2] + i2;
+          const float* p = pred + (int64_t)n * C * S + member_offset(size3, perm3, flip_mask, i0, i1, i2);
+          if (mode == 0) {
+            for (int c = 0; c < C; ++c) {
+              float* a = acc + ((int64_t)n * C + c) * S + v;
+              *a = first ? p[(int64_t)c * S] : *a + p[(int64_t)c * S];
+            }
+          } else {
+            int best = 0;
+            for (int c = 1; c < C; ++c)
+              if (p[(int64_t)c * S] > p[(int64_t)best * S]) best = c;
+            for (int c = 0; c < C; ++c) {
+              int32_t* q = votes + ((int64_t)n * C + c) * S + v;
+              if (first) *q = c == best ? 1 : 0;
+              else if (c == best) *q += 1;
+            }
+          }
+        }
+  return 0;
+}
+int m355o_ensemble_finalize(const float* acc, const int32_t* votes, float* mean_out, int64_t* onehot_out, int32_t N,
+                            int32_t C, int64_t S, int32_t members, int32_t mode, void* stream) {
+  (void)stream;
+  if (mode == 0) {
+    for (int64_t i = 0; i < (int64_t)N * C * S; ++i) mean_out[i] = acc[i] * (1.0f / (float)members);
+    return 0;
+  }
+  for (int n = 0; n < N; ++n)
+    for (int64_t v = 0; v < S; ++v) {
+      int best = 0;
+      for (int c = 1; c < C; ++c)
+        if (votes[((int64_t)n * C + c) * S + v] > votes[((int64_t)n * C + best) * S + v]) best = c;
+      for (int c = 0; c < C; ++c) onehot_out[((int64_t)n * C + c) * S + v] = c == best ? 1 : 0;
+    }
+  return 0;
+}

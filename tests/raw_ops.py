@@ -425,6 +425,38 @@ class RawOps:
                                                     self._stream()), "weight_standardize_bwd")
         return dw
 
+    # ---------------------------------------------------------------- ensembles
+    @staticmethod
+    def _i3(v):
+        return (C.c_int32 * 3)(*[int(a) for a in v])
+
+    def flip_permute(self, x, perm, flip_mask):
+        x = self.to(x)
+        N, Cc = x.shape[:2]
+        sp = x.shape[2:]
+        y = self.empty(N, Cc, *[sp[p] for p in perm])
+        self._chk(self.fn("flip_permute")(_p(x), _p(y), N, Cc, self._i3(sp), self._i3(perm), flip_mask, self._stream()),
+                  "flip_permute")
+        return y
+
+    def ensemble(self, preds, transforms, canonical_spatial, strategy):
+        """preds[e]: member prediction in member orientation; transforms[e] = (perm, flip_mask) -> (result, votes)"""
+        mode = 0 if strategy == "mean" else 1
+        N, Cc = preds[0].shape[:2]
+        shape = (N, Cc) + tuple(canonical_spatial)
+        acc = self.empty(*shape) if mode == 0 else self.empty(*shape, dtype=torch.int32)
+        for e, (p, (perm, fm)) in enumerate(zip(preds, transforms)):
+            p = self.to(p)
+            self._chk(self.fn("ensemble_accumulate")(_p(p), _p(acc) if mode == 0 else None, _p(acc) if mode == 1 else None,
+                                                     N, Cc, self._i3(canonical_spatial), self._i3(perm), fm, mode,
+                                                     1 if e == 0 else 0, self._stream()), "ensemble_accumulate")
+        S = shape[2] * shape[3] * shape[4]
+        out = self.empty(*shape) if mode == 0 else self.empty(*shape, dtype=torch.int64)
+        self._chk(self.fn("ensemble_finalize")(_p(acc) if mode == 0 else None, _p(acc) if mode == 1 else None,
+                                               _p(out) if mode == 0 else None, _p(out) if mode == 1 else None, N, Cc, S,
+                                               len(preds), mode, self._stream()), "ensemble_finalize")
+        return out, acc
+
     def softmax_fwd(self, x, inner=1, diag_bias=0.0):
         x = self.to(x)
         N, Ct = x.shape[:2]

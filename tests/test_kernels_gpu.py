@@ -381,6 +381,24 @@ def test_patches_roundtrip_and_confusion(hip, oracle):
     assert torch.equal(amo.long(), prob.argmax(dim=1))
 
 
+def test_ensemble_kernels_match_oracle(hip, oracle):
+    """flip/permute gather, accumulate through the inverse transform, finalize (mean / majority): bit-exact for the
+    index and vote arithmetic, fp32 running sums in member order."""
+    import itertools
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 4, 6, 5, 8), generator=g)
+    members = [(perm, fm) for perm in itertools.permutations((0, 1, 2)) for fm in range(8)]
+    preds = []
+    for perm, fm in members:
+        xm = hip.flip_permute(x, perm, fm)
+        assert torch.equal(xm.cpu(), oracle.flip_permute(x, perm, fm))
+        preds.append(torch.softmax(xm.cpu() * (1.0 + 0.03 * len(preds)), dim=1))
+    for strategy in ("mean", "majority"):
+        out_h, acc_h = hip.ensemble(preds, members, x.shape[2:], strategy)
+        out_o, acc_o = oracle.ensemble(preds, members, x.shape[2:], strategy)
+        assert torch.equal(out_h.cpu(), out_o) and torch.equal(acc_h.cpu(), acc_o)
+
+
 def test_error_paths_gpu(hip):
     from segmentation_pipeline_amd import _lib
     L = hip.lib

@@ -221,6 +221,51 @@ def test_c_weight_standardize_matches_torch_autograd(oracle):
     torch.testing.assert_close(dw.double(), w.grad, rtol=1e-4, atol=1e-5)
 
 
+def _orientation_members(x):
+    """the 48 (perm, flip) members of EnsembleOrientations (models/ensemble.py:77-91), as index transforms"""
+    import itertools
+    out = []
+    for perm in itertools.permutations((0, 1, 2)):
+        for r in range(4):
+            for f in itertools.combinations((0, 1, 2), r):
+                out.append((perm, sum(1 << j for j in f)))
+    return out
+
+
+def test_c_ensemble_kernels_match_torch_index_ops_and_reference_strategy(oracle, golden):
+    """m355o_flip_permute == x.permute(..).flip(..); accumulate (through the inverse transform) + finalize ==
+    the reference's `.flip(f).permute(inverse)` per member followed by apply_strategy (pinned by the golden
+    ens.* vectors, which come from the reference's own apply_strategy)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 3, 4, 5, 6), generator=g)
+    members = _orientation_members(x)
+    preds, back = [], []
+    for perm, fm in members:
+        dims = [2 + j for j in range(3) if (fm >> j) & 1]
+        xm = x.permute(0, 1, *[2 + p for p in perm]).flip(dims).contiguous()
+        assert torch.equal(oracle.flip_permute(x, perm, fm), xm)
+        pm = torch.softmax(xm * (1.0 + 0.1 * len(preds)) + 0.05 * torch.randn(xm.shape, generator=g), dim=1)
+        preds.append(pm)
+        inv = [0, 0, 0]
+        for j, p in enumerate(perm):
+            inv[p] = j
+        back.append(pm.flip(dims).permute(0, 1, *[2 + j for j in inv]))
+    mean, _ = oracle.ensemble(preds, members, x.shape[2:], "mean")
+    torch.testing.assert_close(mean, torch.stack(back).mean(dim=0), rtol=1e-6, atol=1e-6)
+    onehot, votes = oracle.ensemble(preds, members, x.shape[2:], "majority")
+    ref = torch.nn.functional.one_hot(torch.mode(torch.stack(back).argmax(dim=2), dim=0).values, 3).moveaxis(-1, 1)
+    assert torch.equal(onehot, ref)
+    assert (votes.sum(dim=1) == len(members)).all()
+    # the reference's own apply_strategy outputs (tools/gen_golden.py): identity transforms
+    gg = golden("components.npz")
+    ep = [gg.t("ens.preds")[e] for e in range(gg["ens.preds"].shape[0])]
+    ident = [((0, 1, 2), 0)] * len(ep)
+    m2, _ = oracle.ensemble(ep, ident, ep[0].shape[2:], "mean")
+    torch.testing.assert_close(m2, gg.t("ens.mean"), rtol=1e-6, atol=1e-7)
+    o2, _ = oracle.ensemble(ep, ident, ep[0].shape[2:], "majority")
+    assert torch.equal(o2, gg.t("ens.majority"))
+
+
 def test_c_operand_rounding_matches_torch_casts(oracle):
     """bf16 / fp16 operand rounding of the oracle (round-to-nearest-even, subnormals, overflow to inf) ==
     torch's float -> bfloat16 / float16 casts, bit for bit."""
