@@ -94,8 +94,14 @@ enum {
    * filter: the per-launch repacking kernel is skipped.  Weights only change at optimizer.step, so a caller
    * packs once per parameter version.  The buffer also holds the work-queue state of the persistent kernels
    * (reset by the kernel itself when it drains): it must not be shared by two launches that run concurrently. */
-  M355_CONV_W_PACKED = 1
+  M355_CONV_W_PACKED = 1,
+  /* forward only: nn.Softmax(dim=1) over the Cout output channels applied in the conv epilogue (the out conv +
+   * hypothesis of ModularUNet, models/modular_unet.py:99-100); allowed when m355_conv3d_fuses_softmax(desc) != 0
+   * (the fp32 Cout <= 4 kernel, where a voxel's channels sit in one thread's registers).  Same bits as
+   * m355_conv3d_fwd followed by m355_softmax_fwd. */
+  M355_CONV_SOFTMAX = 2
 };
+int32_t m355_conv3d_fuses_softmax(const m355_conv3d_desc* d);
 /* which: 0 = forward, 1 = data gradient.  0 bytes = this descriptor has no packed form (generic direct kernels). */
 size_t m355_conv3d_packed_bytes(const m355_conv3d_desc* d, int32_t which);
 int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const float* w, void* packed, void* stream);
@@ -272,6 +278,14 @@ int m355_avgpool3d_2x_fwd(const float* x, float* y, int32_t N, int32_t C,
 int m355_avgpool3d_2x_bwd(const float* dy, float* dx, int32_t N, int32_t C,
                           int32_t D, int32_t H, int32_t W, /* INPUT size of fwd */
                           int64_t dy_batch_stride, int64_t dx_batch_stride, void* stream);
+
+/* dx = add + pool-backward(dy): the encoder block's output feeds the pool AND the skip connection
+ * (models/modular_unet.py:90-92), so its gradient is the sum of two; `add` (dx's shape, own batch stride) is the
+ * skip gradient -- one pass instead of a pool-backward pass plus a separate elementwise add. */
+int m355_avgpool3d_2x_bwd_add(const float* dy, const float* add, float* dx, int32_t N, int32_t C,
+                              int32_t D, int32_t H, int32_t W, /* INPUT size of fwd */
+                              int64_t dy_batch_stride, int64_t add_batch_stride, int64_t dx_batch_stride,
+                              void* stream);
 
 /* ------------------------------------------------------------- upsampling
  * nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)

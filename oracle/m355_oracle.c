@@ -1026,3 +1026,24 @@ int m355o_ensemble_finalize(const float* acc, const int32_t* votes, float* mean_
     }
   return 0;
 }
+
+/* gradient of a tensor that feeds both AvgPool3d(2,2) and a skip connection (models/modular_unet.py:90-92) */
+int m355o_avgpool3d_2x_bwd_add(const float* dy, const float* add, float* dx, int32_t N, int32_t C, int32_t D, int32_t H,
+                               int32_t W, int64_t dybs, int64_t abs_, int64_t dxbs, void* stream) {
+  (void)stream;
+  const int OD = D / 2, OH = H / 2, OW = W / 2;
+  const int64_t S = (int64_t)D * H * W, OS = (int64_t)OD * OH * OW;
+  if (!dybs) dybs = (int64_t)C * OS;
+  if (!abs_) abs_ = (int64_t)C * S;
+  if (!dxbs) dxbs = (int64_t)C * S;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (int z = 0; z < D; ++z)
+        for (int y = 0; y < H; ++y)
+          for (int x = 0; x < W; ++x) {
+            const int64_t sp = (int64_t)c * S + ((int64_t)z * H + y) * W + x;
+            dx[n * dxbs + sp] = add[n * abs_ + sp] +
+                                dy[n * dybs + (int64_t)c * OS + ((int64_t)(z / 2) * OH + y / 2) * OW + x / 2] * 0.125f;
+          }
+  return 0;
+}

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(_HERE, "libm355seg.so
 M355_OK = 0
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
-CONV_W_PACKED = 1
+CONV_W_PACKED, CONV_SOFTMAX = 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     "m355_version": (C.c_int, []),
     "m355_last_error": (C.c_char_p, []),
     "m355_reload_tuning": (None, []),
+    "m355_conv3d_fuses_softmax": (_i32, [_CD]),
     "m355_conv3d_packed_bytes": (_sz, [_CD, _i32]),
     "m355_conv3d_pack": (C.c_int, [_CD, _i32, _P, _P, _P]),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "m355_norm_act_bwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _sz, _P]),
     "m355_avgpool3d_2x_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_avgpool3d_2x_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
+    "m355_avgpool3d_2x_bwd_add": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _P]),
     "m355_upsample_trilinear2x_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_upsample_trilinear2x_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_softmax_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i64, _f32, _P]),

@@ -613,7 +613,10 @@ __global__ void pack_w3_valu_kernel(const float* __restrict__ w, float* __restri
 __global__ __launch_bounds__(256, 2) void conv3_valu_smallcout_kernel(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, int Cin, int Cout, int D, int H, int W,
-    int ty_tiles, int tx_tiles, int64_t xbs, int64_t ybs) {
+    int ty_tiles, int tx_tiles, int64_t xbs, int64_t ybs, int softmax) {
+  // softmax: nn.Softmax(dim=1) of the hypothesis (models/modular_unet.py:100) applied in the epilogue -- all
+  // (<= 4) channels of a voxel are in this thread's registers, so the logits never travel through HBM.  Same
+  // formula and order as softmax_fwd_kernel (max, sum of expf in channel order, one reciprocal): identical bits.
   constexpr int XE = VS_CC * VS_CS, XPER = (XE + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) float xs[XE];
@@ -707,26 +710,53 @@ __global__ __launch_bounds__(256, 2) void conv3_valu_smallcout_kernel(
   float* yn = y + (int64_t)n * ybs;
   const float* an = add ? add + (int64_t)n * ybs : nullptr;
   const bool vec = gx0 + 8 <= W && ((((uintptr_t)yn) | ((uintptr_t)an)) & 15) == 0 && (W & 3) == 0;
+  float val[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const float bv = (bias && o < Cout) ? bias[o] : 0.f;
+    const int64_t idx = (int64_t)o * iDHW + (int64_t)gz * iHW + (int64_t)gy * W + gx0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) val[o][k] = acc[k][o >> 1][o & 1] + bv;
+    if (an && o < Cout) {
+      if (vec) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(an + idx), a1 = *reinterpret_cast<const f32x4*>(an + idx + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { val[o][k] += a0[k]; val[o][4 + k] += a1[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (gx0 + k < W) val[o][k] += an[idx + k];
+      }
+    }
+  }
+  if (softmax) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < Cout) mx = fmaxf(mx, val[o][k]);
+      float sum = 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < Cout) sum += expf(val[o][k] - mx);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < Cout) val[o][k] = expf(val[o][k] - mx) * inv;
+    }
+  }
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     if (o >= Cout) break;
-    const float bv = bias ? bias[o] : 0.f;
     const int64_t idx = (int64_t)o * iDHW + (int64_t)gz * iHW + (int64_t)gy * W + gx0;
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = acc[k][o >> 1][o & 1] + bv;
     if (vec) {
-      if (an) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(an + idx), a1 = *reinterpret_cast<const f32x4*>(an + idx + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] += a0[k]; v[4 + k] += a1[k]; }
-      }
-      *reinterpret_cast<f32x4*>(yn + idx) = (f32x4){v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(yn + idx + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(yn + idx) = (f32x4){val[o][0], val[o][1], val[o][2], val[o][3]};
+      *reinterpret_cast<f32x4*>(yn + idx + 4) = (f32x4){val[o][4], val[o][5], val[o][6], val[o][7]};
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (gx0 + k < W) yn[idx + k] = v[k] + (an ? an[idx + k] : 0.f);
+        if (gx0 + k < W) yn[idx + k] = val[o][k];
     }
   }
 }
@@ -1876,10 +1906,19 @@ static void launch_pack_smallcout(const m355_conv3d_desc* d, const float* w, flo
   }
 }
 
+// softmax over the output channels in the epilogue: the fp32 packed-FMA kernel for Cout <= 4
+static bool fuses_softmax(const m355_conv3d_desc* d) {
+  return is_k3s1p1(d) && small_cout_fwd(d) && tuning().smallcout_valu && tuning().fuse_softmax &&
+         (int64_t)d->D * d->H * d->W < (1ll << 27);
+}
+extern "C" int32_t m355_conv3d_fuses_softmax(const m355_conv3d_desc* d) { return d && fuses_softmax(d) ? 1 : 0; }
+
 static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const float* w, const float* bias,
                            const float* add, float* y, float* stat, void* workspace, size_t workspace_bytes,
                            void* stream) {
   if (int rc = validate_conv(d, "conv3d_fwd")) return rc;
+  M355_REQUIRE(!(d->flags & M355_CONV_SOFTMAX) || fuses_softmax(d), M355_EUNSUPPORTED,
+               "conv3d_fwd: M355_CONV_SOFTMAX needs m355_conv3d_fuses_softmax(desc) != 0");
   M355_REQUIRE(!stat || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
                "conv3d_fwd_stats: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
   M355_REQUIRE(x && w && y, M355_EINVALID_ARG, "conv3d_fwd: null pointer");
@@ -1901,7 +1940,7 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
       const int tyv = (int)ceil_div(d->H, VS_TY), txv = (int)ceil_div(d->W, VS_TX);
       dim3 gv((unsigned)(ceil_div(d->D, VS_TZ) * tyv * txv), (unsigned)d->N);
       hipLaunchKernelGGL(conv3_valu_smallcout_kernel, gv, dim3(256), 0, st, x, wpz, bias, add, y, d->Cin, d->Cout,
-                         d->D, d->H, d->W, tyv, txv, xbs, ybs);
+                         d->D, d->H, d->W, tyv, txv, xbs, ybs, (d->flags & M355_CONV_SOFTMAX) ? 1 : 0);
       return check_launch("conv3_valu_smallcout");
     }
     const int kin_pad = (int)round_up(d->Cin, 2);

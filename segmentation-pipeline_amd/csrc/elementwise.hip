@@ -55,10 +55,12 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
   }
 }
 
+// add (may be null): a second gradient of the pooled tensor's INPUT, summed in the same pass -- the skip
+// connection's gradient (models/modular_unet.py:90-92: the block output feeds both the pool and the concat)
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy,
                                                            float* __restrict__ dx, int N, int C,
                                                            int D, int H, int W, int64_t dybs,
-                                                           int64_t dxbs) {
+                                                           int64_t dxbs, const float* __restrict__ add, int64_t abs_) {
   const int OD = D / 2, OH = H / 2, OW = W / 2;
   const int W2 = W / 2;  // one thread per x pair
   const int64_t total = (int64_t)N * C * D * H * W2;
@@ -73,9 +75,16 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
     const int n = (int)(r / C);
     const float g = dy[(int64_t)n * dybs + (int64_t)c * OD * OH * OW +
                        ((int64_t)(iz / 2) * OH + iy / 2) * OW + xp] * 0.125f;
-    float* o = dx + (int64_t)n * dxbs + (int64_t)c * D * H * W + ((int64_t)iz * H + iy) * W + 2 * xp;
-    o[0] = g;
-    o[1] = g;
+    const int64_t sp = (int64_t)c * D * H * W + ((int64_t)iz * H + iy) * W + 2 * xp;
+    float* o = dx + (int64_t)n * dxbs + sp;
+    if (add) {
+      const float* a = add + (int64_t)n * abs_ + sp;
+      o[0] = a[0] + g;
+      o[1] = a[1] + g;
+    } else {
+      o[0] = g;
+      o[1] = g;
+    }
   }
 }
 
@@ -380,8 +389,24 @@ extern "C" int m355_avgpool3d_2x_bwd(const float* dy, float* dx, int32_t N, int3
   const int64_t dybs = dense_or(dy_batch_stride, (int64_t)C * (D / 2) * (H / 2) * (W / 2));
   const int64_t total = (int64_t)N * C * D * H * (W / 2);
   hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     dy, dx, N, C, D, H, W, dybs, dxbs);
+                     dy, dx, N, C, D, H, W, dybs, dxbs, (const float*)nullptr, (int64_t)0);
   return check_launch("avgpool3d_2x_bwd");
+}
+
+extern "C" int m355_avgpool3d_2x_bwd_add(const float* dy, const float* add, float* dx, int32_t N, int32_t C, int32_t D,
+                                         int32_t H, int32_t W, int64_t dy_batch_stride, int64_t add_batch_stride,
+                                         int64_t dx_batch_stride, void* stream) {
+  if (int rc = check_ncdhw(N, C, D, H, W, "avgpool3d_2x_bwd_add")) return rc;
+  M355_REQUIRE(dy && add && dx, M355_EINVALID_ARG, "avgpool3d_2x_bwd_add: null pointer");
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED,
+               "avgpool3d_2x_bwd_add: odd spatial size (%d,%d,%d)", D, H, W);
+  const int64_t dense = (int64_t)C * D * H * W;
+  const int64_t dxbs = dense_or(dx_batch_stride, dense), abs_ = dense_or(add_batch_stride, dense);
+  const int64_t dybs = dense_or(dy_batch_stride, (int64_t)C * (D / 2) * (H / 2) * (W / 2));
+  const int64_t total = (int64_t)N * C * D * H * (W / 2);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     dy, dx, N, C, D, H, W, dybs, dxbs, add, abs_);
+  return check_launch("avgpool3d_2x_bwd_add");
 }
 
 extern "C" int m355_upsample_trilinear2x_fwd(const float* x, float* y, int32_t N, int32_t C,

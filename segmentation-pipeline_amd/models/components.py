@@ -156,14 +156,14 @@ def _check_conv_module(m):
     _uniform_int(m.padding, "padding")
 
 
-def run_conv(m, x, add=None, out=None, stats=None, c8_out=False):
+def run_conv(m, x, add=None, out=None, stats=None, c8_out=False, softmax=False):
     """Execute an nn.Conv3d-like parameter container with the HIP conv kernels."""
     if hasattr(m, "effective"):
         weight, bias = m.effective()
     else:
         weight, bias = m.weight, m.bias
     return ops.conv3d(x, weight, bias, add=add, stride=_uniform_int(m.stride, "stride"),
-                      padding=_uniform_int(m.padding, "padding"), out=out, stats=stats, c8_out=c8_out)
+                      padding=_uniform_int(m.padding, "padding"), out=out, stats=stats, c8_out=c8_out, softmax=softmax)
 
 
 def _act_code(m):

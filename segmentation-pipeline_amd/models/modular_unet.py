@@ -23,7 +23,7 @@ def _run_downsample(m, x):
         k, s = _uniform_int(m.kernel_size, "kernel_size"), _uniform_int(m.stride, "stride")
         if k != 2 or s != 2 or _uniform_int(m.padding, "padding") != 0 or m.ceil_mode:
             raise NotImplementedError("only AvgPool3d(kernel_size=2, stride=2) has a HIP kernel")
-        return ops.avgpool3d_2x(x)
+        return None if x is None else ops.avgpool3d_2x(x)
     if isinstance(m, BlurConv3d):
         return m(ops.as_f32(x))
     if isinstance(m, nn.Conv3d):  # WSConv3d / strided nn.Conv3d
@@ -158,8 +158,14 @@ class ModularUNet(nn.Module):
                     buf = torch.empty((N, c_up + f[i]) + spatial, dtype=torch.float32, device=x.device)
                     slot = ops.OutSlot(buf, c_up, c_up + f[i])
                 x = self.down_blocks[i](x, out=slot)
-                skips.append((x, buf, c_up))
-                x = _run_downsample(self.downsampling[i], x)
+                if (isinstance(self.downsampling[i], nn.AvgPool3d) and isinstance(x, torch.Tensor)
+                        and x.requires_grad and torch.is_grad_enabled()):
+                    _run_downsample(self.downsampling[i], None)          # validates the module's geometry
+                    x_skip, x = ops.avgpool3d_2x_with_skip(x)            # one fused gradient for both uses
+                else:
+                    x_skip = x
+                    x = _run_downsample(self.downsampling[i], x)
+                skips.append((x_skip, buf, c_up))
                 spatial = tuple(x.shape[2:])
             else:
                 x = self.down_blocks[i](x, c8_out=bool(flow))
@@ -170,5 +176,8 @@ class ModularUNet(nn.Module):
             x_up = _run_upsample(self.upsampling[i], x, out=slot)
             x = self.up_blocks[i](ops.Concat(buf, [x_up, x_skip]), c8_out=bool(flow))
 
+        if isinstance(self.hypothesis, nn.Softmax) and self.hypothesis.dim == 1 and isinstance(self.out_conv, nn.Conv3d):
+            # out conv + Softmax(dim=1) (:99-100) as one op: the softmax runs in the conv epilogue
+            return run_conv(self.out_conv, x, softmax=True)
         x = run_conv(self.out_conv, x)
         return _run_hypothesis(self.hypothesis, ops.as_f32(x))

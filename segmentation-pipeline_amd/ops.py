@@ -313,6 +313,7 @@ class _ConvMeta:
     out: Optional[OutSlot] = None
     tag: str = "conv3d"
     stats: Optional[dict] = None   # filled with {"partials", "slots"} when the statistics are fused
+    softmax: bool = False          # Softmax(dim=1) over the output channels fused into this op (out conv + hypothesis)
 
 
 def _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad=0, compute=0):
@@ -349,7 +350,8 @@ class _Conv3dFn(torch.autograd.Function):
                                          "tensor and copy_into the slot instead)")
         d = _conv_desc(N, Cin, Cout, D, H, W, k, meta.stride, meta.pad, xbs, ybs, compute=_COMPUTE[_compute_mode])
         wbuf, flags = _packed_weight(weight, d, 0)
-        dk = _with_flags(d, flags)
+        fuse_sm = meta.softmax and L.m355_conv3d_fuses_softmax(C.byref(d)) != 0
+        dk = _with_flags(d, flags | (_lib.CONV_SOFTMAX if fuse_sm else 0))
         ws = _workspace(L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
         prof = CONV_PROFILE
         if prof is not None:
@@ -370,18 +372,34 @@ class _Conv3dFn(torch.autograd.Function):
             flops = 2.0 * k ** 3 * Cin * Cout * N * oshape[2] * oshape[3] * oshape[4]
             prof.append(("conv3d_fwd", flops, e0, e1, conv_plan(d, 0),
                          _conv_bytes(N, Cin, Cout, oshape[2] * oshape[3] * oshape[4], k ** 3, 4, 4)))
+        if meta.softmax and not fuse_sm:   # kernel variants without the fused epilogue: a separate softmax pass
+            logits = y.contiguous()
+            y = torch.empty_like(logits)
+            check(L.m355_softmax_fwd(_p(logits), _p(y), N, Cout, 1, oshape[2] * oshape[3] * oshape[4], 0.0, _stream()),
+                  "softmax_fwd")
         ctx.meta, ctx.desc = meta, d
         ctx.has_bias, ctx.has_add = bias is not None, add is not None
         ctx.part_channels = [p.shape[1] for p in parts]
-        ctx.save_for_backward(x, weight)
+        if meta.softmax:
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, weight = ctx.saved_tensors
-        d = ctx.desc
         meta = ctx.meta
+        d = ctx.desc
+        if meta.softmax:   # dlogits = y * (dy - sum_c y dy)
+            x, weight, y = ctx.saved_tensors
+            dy = dy.contiguous()
+            dl = torch.empty_like(y)
+            check(L.m355_softmax_bwd(_p(y.contiguous()), _p(dy), _p(dl), d.N, d.Cout, 1, y.numel() // (d.N * d.Cout),
+                                     _stream()), "softmax_bwd")
+            dy = dl
+        else:
+            x, weight = ctx.saved_tensors
         dy, dybs = _dense_channels(dy)
         if dybs != d.y_batch_stride:
             d = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.x_batch_stride, dybs, compute=d.compute)
@@ -432,12 +450,13 @@ class _Conv3dFn(torch.autograd.Function):
 
 
 def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[OutSlot] = None,
-           stats: Optional[dict] = None, c8_out: bool = False):
+           stats: Optional[dict] = None, c8_out: bool = False, softmax: bool = False):
     """nn.Conv3d forward (cubic kernel).  `x` is a tensor or a `Concat`; `add` is fused
     into the epilogue (y = conv(x) + bias + add).  `stats`: an empty dict asks the kernel to also
     emit the partial sums the following normalisation needs (filled in when the kernel variant
     supports it; pass it on as `NormCfg.stats`).  `c8_out`: in the c8 flow (x is an `Act16`) return the result
-    as an `Act16` written by the conv epilogue (for the normalisation pass that follows)."""
+    as an `Act16` written by the conv epilogue (for the normalisation pass that follows).  `softmax`: apply
+    nn.Softmax(dim=1) to the result (fused into the conv epilogue where the kernel variant allows)."""
     k = weight.shape[2]
     if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
         raise NotImplementedError("only cubic kernels are supported")
@@ -447,12 +466,13 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
         return pack_act16(conv3d(x, weight, bias, add, stride, padding, None, stats), out.buf16.compute, out.act16())
     if isinstance(x, Act16):
         if k == 3 and stride == 1 and padding == 1:
-            return _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out)
+            y = _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out and not softmax)
+            return softmax_channels(y) if softmax else y
         x = x.to_f32()
     if isinstance(x, Concat):
-        meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats)
+        meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats, softmax=softmax)
         return _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
-    meta = _ConvMeta(k, stride, padding, out=out, stats=stats)
+    meta = _ConvMeta(k, stride, padding, out=out, stats=stats, softmax=softmax)
     return _Conv3dFn.apply(weight, bias, add, meta, x)
 
 
@@ -685,6 +705,44 @@ class _AvgPoolFn(torch.autograd.Function):
         dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
         check(L.m355_avgpool3d_2x_bwd(_p(dy), _p(dx), N, Cc, D, H, W, dybs, 0, _stream()), "avgpool3d_2x_bwd")
         return dx, None
+
+
+class _PoolSkipFn(torch.autograd.Function):
+    """AvgPool3d(2, 2) of a tensor that ALSO continues as a skip connection (models/modular_unet.py:90-92).
+    Returns (skip alias, pooled); the backward receives both gradients together and sums them in the pool-backward
+    pass (m355_avgpool3d_2x_bwd_add) -- autograd would otherwise add them with a separate torch kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        _require(x)
+        xd, xbs = _dense_channels(x)
+        N, Cc, D, H, W = xd.shape
+        y = torch.empty((N, Cc, D // 2, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        check(L.m355_avgpool3d_2x_fwd(_p(xd), _p(y), N, Cc, D, H, W, xbs, 0, _stream()), "avgpool3d_2x_fwd")
+        ctx.shape = (N, Cc, D, H, W)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, g_pool):
+        L = _lib.lib()
+        N, Cc, D, H, W = ctx.shape
+        if g_pool is None:
+            return g_skip
+        g_pool, gpbs = _dense_channels(g_pool)
+        dx = torch.empty(ctx.shape, dtype=g_pool.dtype, device=g_pool.device)
+        if g_skip is None:
+            check(L.m355_avgpool3d_2x_bwd(_p(g_pool), _p(dx), N, Cc, D, H, W, gpbs, 0, _stream()), "avgpool3d_2x_bwd")
+        else:
+            g_skip, gsbs = _dense_channels(g_skip)
+            check(L.m355_avgpool3d_2x_bwd_add(_p(g_pool), _p(g_skip), _p(dx), N, Cc, D, H, W, gpbs, gsbs, 0, _stream()),
+                  "avgpool3d_2x_bwd_add")
+        return dx
+
+
+def avgpool3d_2x_with_skip(x):
+    """-> (x as it continues into the skip connection, AvgPool3d(2, 2)(x)); see _PoolSkipFn."""
+    return _PoolSkipFn.apply(x)
 
 
 def avgpool3d_2x(x, out: Optional[OutSlot] = None):

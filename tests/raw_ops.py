@@ -84,11 +84,15 @@ class RawOps:
         self._chk(self.lib.m355_conv3d_pack(C.byref(d), which, _p(w), _p(buf), self._stream()), "conv3d_pack")
         return buf
 
-    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0, packed=None):
-        """packed: buffer from pack_weights(w, x.shape, 0) -> the call uses M355_CONV_W_PACKED"""
+    def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0, packed=None, softmax=False):
+        """packed: buffer from pack_weights(w, x.shape, 0) -> the call uses M355_CONV_W_PACKED;
+        softmax: M355_CONV_SOFTMAX (HIP library, descriptors with m355_conv3d_fuses_softmax != 0)"""
         x, w, bias, add = map(self.to, (x, w, bias, add))
         k = w.shape[2]
         d = self.conv_desc(x.shape, w.shape[0], k, stride, pad, compute=compute)
+        if softmax:
+            assert self.lib.m355_conv3d_fuses_softmax(C.byref(d)) == 1
+            d.flags |= _lib.CONV_SOFTMAX
         if packed is not None:
             d.flags = _lib.CONV_W_PACKED
             od = lambda n: (n + 2 * pad - k) // stride + 1
@@ -361,6 +365,14 @@ class RawOps:
         N, Cc, D, H, W = x_shape
         dx = self.empty(*x_shape)
         self._chk(self.fn("avgpool3d_2x_bwd")(_p(dy), _p(dx), N, Cc, D, H, W, 0, 0, self._stream()), "avgpool_bwd")
+        return dx
+
+    def avgpool_bwd_add(self, dy, add, x_shape):
+        dy, add = self.to(dy), self.to(add)
+        N, Cc, D, H, W = x_shape
+        dx = self.empty(*x_shape)
+        self._chk(self.fn("avgpool3d_2x_bwd_add")(_p(dy), _p(add), _p(dx), N, Cc, D, H, W, 0, 0, 0, self._stream()),
+                  "avgpool_bwd_add")
         return dx
 
     def upsample_fwd(self, x):

@@ -159,6 +159,17 @@ def test_model_packed_weight_cache_follows_parameter_versions(golden):
     assert w._m355_packed[0] == w._version and not torch.equal(p3, p1)
 
 
+def test_out_conv_softmax_fused_epilogue(hip, oracle):
+    """M355_CONV_SOFTMAX on the Cout <= 4 fp32 kernel (out conv + hypothesis, models/modular_unet.py:99-100) gives the
+    very bits of m355_conv3d_fwd followed by m355_softmax_fwd, and matches the oracle's conv -> softmax."""
+    for (N, ci, co, D, H, W) in [(1, 32, 3, 8, 16, 64), (2, 8, 2, 9, 10, 36), (1, 16, 4, 8, 8, 32)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+        fused = hip.conv3d_fwd(x, w, b, softmax=True)
+        assert torch.equal(fused, hip.softmax_fwd(hip.conv3d_fwd(x, w, b)))
+        close(fused, oracle.softmax_fwd(oracle.conv3d_fwd(x, w, b)), 2e-5, 1e-6, "conv + softmax")
+        assert (fused.sum(dim=1) - 1).abs().max().item() <= 1e-5
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
@@ -248,6 +259,12 @@ def test_pool_upsample_softmax(hip, oracle):
         close(yh, yo, 2e-6, 1e-7, "softmax fwd")
         dy = rnd(*x.shape, seed=6)
         close(hip.softmax_bwd(yo, dy, inner), oracle.softmax_bwd(yo, dy, inner), 1e-5, 1e-6, "softmax bwd")
+
+
+def test_avgpool_bwd_fused_with_skip_gradient(hip, oracle):
+    dy, add = rnd(2, 5, 3, 4, 6, seed=1), rnd(2, 5, 6, 8, 12, seed=2)
+    close(hip.avgpool_bwd_add(dy, add, add.shape), oracle.avgpool_bwd_add(dy, add, add.shape), 0, 1e-7, "pool bwd + add")
+    close(hip.avgpool_bwd_add(dy, add, add.shape), hip.avgpool_bwd(dy, add.shape).cpu() + add, 0, 1e-7, "== separate ops")
 
 
 def test_space_to_depth_roundtrip(hip, oracle):

@@ -166,6 +166,13 @@ def _standardize(w):  # models/components.py:83-84 (torch.std: unbiased)
     return w / (w.std(dim=(1, 2, 3, 4), keepdim=True) + 1e-5)
 
 
+def test_c_avgpool_bwd_add_matches_autograd(oracle):
+    x = rnd(2, 3, 4, 6, 8, seed=1).requires_grad_()
+    dy, gs = rnd(2, 3, 2, 3, 4, seed=2), rnd(2, 3, 4, 6, 8, seed=3)
+    (F.avg_pool3d(x, 2, 2) * dy).sum().backward()
+    close(oracle.avgpool_bwd_add(dy, gs, x.shape), x.grad + gs, 0, 1e-7)
+
+
 def test_c_space_to_depth_and_blur_identities(oracle):
     """s2d/d2s are exact permutations, and the reference's strided Blur convolutions
     (models/components.py:119,152: 4x4x4 effective filter, stride 2, padding 1) equal a stride-1
