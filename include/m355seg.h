@@ -392,6 +392,17 @@ int m355_patch_accumulate(const float* patches, const int32_t* loc, float* accum
 int m355_patch_finalize(const float* accum, const float* count, float* out,
                         int32_t C, int64_t V, void* stream);
 
+/* padding_mode != None (prediction.py:114,132; research/msseg2/competition/ms-inference.py:35 uses "edge"):
+ * torchio pads the volume by b = patch_overlap // 2 per side (numpy.pad) before tiling and crops the aggregate.
+ * The padded volume is never materialised: loc is in PADDED coordinates, the gather maps indices back
+ * (mode: 0 constant `value`, 1 edge, 2 reflect, 3 symmetric, 4 wrap -- numpy.pad's definitions), the accumulators
+ * have the padded size [P0,P1,P2] = V + 2b, and the finalize writes the cropped [C, V0,V1,V2] average. */
+int m355_patch_gather_padded(const float* volume, const int32_t* loc, float* patches, int32_t P, int32_t C,
+                             int32_t V0, int32_t V1, int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2,
+                             int32_t b0, int32_t b1, int32_t b2, int32_t mode, float value, void* stream);
+int m355_patch_finalize_crop(const float* accum, const float* count, float* out, int32_t C, int32_t P0, int32_t P1,
+                             int32_t P2, int32_t b0, int32_t b1, int32_t b2, void* stream);
+
 /* ----------------------------------------------------- evaluation counts
  * CustomArgMax (transforms/custom_label_transforms.py:267) + the TP/FP/FN/TN
  * sums of SegmentationEvaluator (evaluators/segmentation_evaluator.py:69-86):

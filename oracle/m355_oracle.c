@@ -1047,3 +1047,58 @@ int m355o_avgpool3d_2x_bwd_add(const float* dy, const float* add, float* dx, int
           }
   return 0;
 }
+
+/* GridSampler(padding_mode) / GridAggregator crop (torchio 0.18.45, behind prediction.py:114,132): numpy.pad index
+ * rules for 'constant' (0), 'edge' (1), 'reflect' (2), 'symmetric' (3), 'wrap' (4). */
+static int pad_map_o(int p, int V, int mode) {
+  if (p >= 0 && p < V) return p;
+  if (mode == 1) return p < 0 ? 0 : V - 1;
+  if (mode == 2) {
+    if (V == 1) return 0;
+    const int period = 2 * V - 2;
+    int q = p % period;
+    if (q < 0) q += period;
+    return q < V ? q : period - q;
+  }
+  if (mode == 3) {
+    const int period = 2 * V;
+    int q = p % period;
+    if (q < 0) q += period;
+    return q < V ? q : period - 1 - q;
+  }
+  if (mode == 4) {
+    int q = p % V;
+    return q < 0 ? q + V : q;
+  }
+  return -1;
+}
+int m355o_patch_gather_padded(const float* vol, const int32_t* loc, float* patches, int32_t P, int32_t C, int32_t V0,
+                              int32_t V1, int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2, int32_t b0, int32_t b1,
+                              int32_t b2, int32_t mode, float value, void* stream) {
+  (void)stream;
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c)
+      for (int i = 0; i < ps0; ++i)
+        for (int j = 0; j < ps1; ++j)
+          for (int k = 0; k < ps2; ++k) {
+            const int s0 = pad_map_o(loc[p * 3] + i - b0, V0, mode), s1 = pad_map_o(loc[p * 3 + 1] + j - b1, V1, mode),
+                      s2 = pad_map_o(loc[p * 3 + 2] + k - b2, V2, mode);
+            patches[((((int64_t)p * C + c) * ps0 + i) * ps1 + j) * ps2 + k] =
+                (s0 < 0 || s1 < 0 || s2 < 0) ? value : vol[(((int64_t)c * V0 + s0) * V1 + s1) * V2 + s2];
+          }
+  return 0;
+}
+int m355o_patch_finalize_crop(const float* accum, const float* count, float* out, int32_t C, int32_t P0, int32_t P1,
+                              int32_t P2, int32_t b0, int32_t b1, int32_t b2, void* stream) {
+  (void)stream;
+  const int V0 = P0 - 2 * b0, V1 = P1 - 2 * b1, V2 = P2 - 2 * b2;
+  const int64_t PV = (int64_t)P0 * P1 * P2;
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < V0; ++i)
+      for (int j = 0; j < V1; ++j)
+        for (int k = 0; k < V2; ++k) {
+          const int64_t pv = ((int64_t)(i + b0) * P1 + (j + b1)) * P2 + (k + b2);
+          out[(((int64_t)c * V0 + i) * V1 + j) * V2 + k] = accum[(int64_t)c * PV + pv] / count[pv];
+        }
+  return 0;
+}

@@ -105,6 +105,8 @@ SIGNATURES = {
     "m355_weight_standardize_bwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _P]),
     "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
+    "m355_patch_gather_padded": (C.c_int, [_P, _P, _P] + [_i32] * 12 + [_f32, _P]),
+    "m355_patch_finalize_crop": (C.c_int, [_P, _P, _P] + [_i32] * 7 + [_P]),
     "m355_patch_finalize": (C.c_int, [_P, _P, _P, _i32, _i64, _P]),
     "m355_flip_permute": (C.c_int, [_P, _P, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, _P]),
     "m355_ensemble_accumulate": (C.c_int, [_P, _P, _P, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, _i32,

@@ -142,6 +142,74 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
   }
 }
 
+// Padded variant: GridSampler(padding_mode=...) (prediction.py:114,132; torchio 0.18.45 pads the volume by
+// patch_overlap // 2 per side with numpy.pad before tiling and GridAggregator crops it off again).  The padded
+// volume is never materialised: `loc` is in PADDED coordinates and the source index is mapped back.
+// mode: 0 constant (value), 1 edge, 2 reflect (mirror without repeating the border voxel), 3 symmetric, 4 wrap
+__device__ __forceinline__ int pad_map(int p, int V, int mode) {  // p in [-b, V + b) -> source index, or -1
+  if (p >= 0 && p < V) return p;
+  switch (mode) {
+    case 1: return min(max(p, 0), V - 1);
+    case 2: {
+      if (V == 1) return 0;
+      const int period = 2 * V - 2;
+      int q = p % period;
+      if (q < 0) q += period;
+      return q < V ? q : period - q;
+    }
+    case 3: {
+      const int period = 2 * V;
+      int q = p % period;
+      if (q < 0) q += period;
+      return q < V ? q : period - 1 - q;
+    }
+    case 4: {
+      int q = p % V;
+      return q < 0 ? q + V : q;
+    }
+    default: return -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void patch_gather_padded_kernel(const float* __restrict__ vol,
+                                                                  const int32_t* __restrict__ loc,
+                                                                  float* __restrict__ patches, int P, int C, int V0,
+                                                                  int V1, int V2, int ps0, int ps1, int ps2, int b0,
+                                                                  int b1, int b2, int mode, float value) {
+  const int64_t PS = (int64_t)ps0 * ps1 * ps2;
+  const int64_t total = (int64_t)P * C * PS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int k = (int)(i % ps2);
+    int64_t r = i / ps2;
+    const int j = (int)(r % ps1);
+    r /= ps1;
+    const int ii = (int)(r % ps0);
+    r /= ps0;
+    const int c = (int)(r % C);
+    const int pidx = (int)(r / C);
+    const int s0 = pad_map(loc[pidx * 3] + ii - b0, V0, mode), s1 = pad_map(loc[pidx * 3 + 1] + j - b1, V1, mode),
+              s2 = pad_map(loc[pidx * 3 + 2] + k - b2, V2, mode);
+    patches[i] = (s0 < 0 || s1 < 0 || s2 < 0) ? value : vol[(((int64_t)c * V0 + s0) * V1 + s1) * V2 + s2];
+  }
+}
+
+// out[c, v] = accum[c, v + b] / count[v + b]: the average over covering patches with the padding cropped off
+__global__ __launch_bounds__(256) void patch_finalize_crop_kernel(const float* __restrict__ accum,
+                                                                  const float* __restrict__ count,
+                                                                  float* __restrict__ out, int C, int P0, int P1, int P2,
+                                                                  int b0, int b1, int b2) {
+  const int V0 = P0 - 2 * b0, V1 = P1 - 2 * b1, V2 = P2 - 2 * b2;
+  const int64_t V = (int64_t)V0 * V1 * V2, PV = (int64_t)P0 * P1 * P2;
+  const int64_t total = (int64_t)C * V;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t v = i % V;
+    const int c = (int)(i / V);
+    const int k = (int)(v % V2), j = (int)((v / V2) % V1), ii = (int)(v / ((int64_t)V2 * V1));
+    const int64_t pv = ((int64_t)(ii + b0) * P1 + (j + b1)) * P2 + (k + b2);
+    out[i] = accum[(int64_t)c * PV + pv] / count[pv];
+  }
+}
+
 // gather-form, deterministic: each output voxel sums the covering patches in patch order
 // (== torchio's sequential `output[...] += patch` over the batch) and counts them.
 __global__ __launch_bounds__(256) void patch_accumulate_kernel(const float* __restrict__ patches,
@@ -281,6 +349,32 @@ extern "C" int m355_patch_gather(const float* volume, const int32_t* loc, float*
   hipLaunchKernelGGL(patch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, volume,
                      loc, patches, P, C, V0, V1, V2, ps0, ps1, ps2);
   return check_launch("patch_gather");
+}
+
+extern "C" int m355_patch_gather_padded(const float* volume, const int32_t* loc, float* patches, int32_t P, int32_t C,
+                                        int32_t V0, int32_t V1, int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2,
+                                        int32_t b0, int32_t b1, int32_t b2, int32_t mode, float value, void* stream) {
+  if (int rc = check_patch_args(P, C, V0 + 2 * b0, V1 + 2 * b1, V2 + 2 * b2, ps0, ps1, ps2, "patch_gather_padded")) return rc;
+  M355_REQUIRE(volume && loc && patches, M355_EINVALID_ARG, "patch_gather_padded: null pointer");
+  M355_REQUIRE(b0 >= 0 && b1 >= 0 && b2 >= 0 && mode >= 0 && mode <= 4, M355_EINVALID_ARG,
+               "patch_gather_padded: bad border / mode");
+  const int64_t total = (int64_t)P * C * ps0 * ps1 * ps2;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 16384);
+  hipLaunchKernelGGL(patch_gather_padded_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, volume, loc, patches,
+                     P, C, V0, V1, V2, ps0, ps1, ps2, b0, b1, b2, mode, value);
+  return check_launch("patch_gather_padded");
+}
+
+extern "C" int m355_patch_finalize_crop(const float* accum, const float* count, float* out, int32_t C, int32_t P0,
+                                        int32_t P1, int32_t P2, int32_t b0, int32_t b1, int32_t b2, void* stream) {
+  M355_REQUIRE(accum && count && out, M355_EINVALID_ARG, "patch_finalize_crop: null pointer");
+  M355_REQUIRE(C > 0 && b0 >= 0 && b1 >= 0 && b2 >= 0 && P0 > 2 * b0 && P1 > 2 * b1 && P2 > 2 * b2, M355_EINVALID_ARG,
+               "patch_finalize_crop: bad shape");
+  const int64_t total = (int64_t)C * (P0 - 2 * b0) * (P1 - 2 * b1) * (P2 - 2 * b2);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 16384);
+  hipLaunchKernelGGL(patch_finalize_crop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, accum, count, out, C,
+                     P0, P1, P2, b0, b1, b2);
+  return check_launch("patch_finalize_crop");
 }
 
 extern "C" int m355_patch_accumulate(const float* patches, const int32_t* loc, float* accum,

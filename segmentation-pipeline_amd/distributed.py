@@ -231,10 +231,11 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
 
 
 def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dtype, device, group=None,
-                 sharded: bool = True):
+                 sharded: bool = True, dst: Optional[int] = None):
     """ONE collective: every rank contributes its tiles (padded to the max per-rank count);
-    returns [n_tiles, *tile_shape] in global tile order on every rank.  `sharded=False`: the caller
-    computed every tile locally (no collective)."""
+    returns [n_tiles, *tile_shape] in global tile order -- on every rank (all_gather), or with `dst` set only on
+    that rank (gather; the others get None and receive nothing).  `sharded=False`: the caller computed every tile
+    locally (no collective)."""
     world = dist.get_world_size(group) if (sharded and is_distributed()) else 1
     rank = dist.get_rank(group) if (sharded and is_distributed()) else 0
     per = (n_tiles + world - 1) // world
@@ -244,8 +245,15 @@ def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dt
         send[:n_local] = local_out
     if world == 1:
         return send[:n_tiles]
-    recv = torch.empty((world * per,) + tuple(tile_shape), dtype=dtype, device=device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if dst is None:
+        recv = torch.empty((world * per,) + tuple(tile_shape), dtype=dtype, device=device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, parts, dst=dst, group=group)
+        if rank != dst:
+            return None
+        recv = torch.cat(parts, dim=0)
     recv = recv.view((world, per) + tuple(tile_shape))
     # global tile i sits at [i % world, i // world]
     idx = torch.arange(n_tiles, device=device)

@@ -1078,6 +1078,38 @@ def patch_gather(volume, locations, patch_size):
     return patches
 
 
+PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4}
+
+
+def patch_gather_padded(volume, locations, patch_size, border, mode, value=0.0):
+    """As patch_gather on the volume padded by `border` voxels per side (numpy.pad mode `mode`, or 'constant' with
+    `value`) -- locations in PADDED coordinates; the padded volume is never materialised."""
+    L = _lib.lib()
+    _require(volume)
+    _require(locations, dtype=torch.int32)
+    volume, locations = volume.contiguous(), locations.contiguous()
+    Cc, V0, V1, V2 = volume.shape
+    P = locations.shape[0]
+    ps0, ps1, ps2 = patch_size
+    patches = torch.empty((P, Cc, ps0, ps1, ps2), dtype=volume.dtype, device=volume.device)
+    check(L.m355_patch_gather_padded(_p(volume), _p(locations), _p(patches), P, Cc, V0, V1, V2, ps0, ps1, ps2,
+                                     border[0], border[1], border[2], PAD_MODES[mode], float(value), _stream()),
+          "patch_gather_padded")
+    return patches
+
+
+def patch_finalize_crop(accum, count, border):
+    """accum [C, P0, P1, P2] / count with `border` voxels cropped off every side."""
+    L = _lib.lib()
+    _require(accum, count)
+    Cc, P0, P1, P2 = accum.shape
+    out = torch.empty((Cc, P0 - 2 * border[0], P1 - 2 * border[1], P2 - 2 * border[2]), dtype=accum.dtype,
+                      device=accum.device)
+    check(L.m355_patch_finalize_crop(_p(accum), _p(count), _p(out), Cc, P0, P1, P2, border[0], border[1], border[2],
+                                     _stream()), "patch_finalize_crop")
+    return out
+
+
 def patch_accumulate(patches, locations, accum, count):
     """accum[C,V] += patches (in patch order), count[V] += 1 over each patch footprint"""
     L = _lib.lib()

@@ -75,27 +75,63 @@ class StandardPredict:
 
 
 class PatchPredict:
-    """Sliding-window prediction with overlap averaging (reference :105-152)."""
+    """Sliding-window prediction with overlap averaging (reference :105-152).
+
+    padding_mode (reference :114,132 -> torchio GridSampler): None, a number (constant fill) or one of numpy.pad's
+    'constant' / 'edge' / 'reflect' / 'symmetric' / 'wrap': the volume is treated as padded by patch_overlap // 2
+    voxels per side before tiling, and the aggregate is cropped back (index math in the gather / finalize
+    kernels; no padded copy).  The other numpy.pad modes (statistics, ramps) have no kernel.
+
+    Multi-GPU (inside `distributed.unit_sharding()`): tile i -> rank i % world, one collective returns the tile
+    outputs.  `result_on="all"` (default): all_gather, every rank aggregates and returns the volume;
+    `result_on="rank0"`: gather to rank 0 only, which alone aggregates (the other ranks return None) -- no rank
+    receives or re-aggregates tiles it does not need.  `timings` (a dict) accumulates seconds per phase
+    (tile_gather, model, exchange, accumulate, finalize; a device synchronisation per stamp, for profiling).
+    """
 
     def __init__(self, image_names: Sequence[str] = ("X",), patch_batch_size: int = 16, patch_size=None,
-                 patch_overlap=(0, 0, 0), padding_mode=None, overlap_mode: str = "average", ops_backend=ops):
+                 patch_overlap=(0, 0, 0), padding_mode=None, overlap_mode: str = "average", ops_backend=ops,
+                 result_on: str = "all", timings: Optional[dict] = None):
         if overlap_mode != "average":
             raise NotImplementedError("only overlap_mode='average' (the mode the reference uses) is implemented")
-        if padding_mode is not None:
-            raise NotImplementedError("padding_mode is not implemented (the reference's configs use None)")
+        self.pad_value = 0.0
+        if padding_mode is not None and not isinstance(padding_mode, str):
+            self.pad_value, padding_mode = float(padding_mode), "constant"
+        if padding_mode is not None and padding_mode not in ops.PAD_MODES:
+            raise NotImplementedError(f"padding_mode={padding_mode!r} has no kernel (supported: None, a number, "
+                                      f"{sorted(ops.PAD_MODES)})")
+        if result_on not in ("all", "rank0"):
+            raise ValueError("result_on must be 'all' or 'rank0'")
         self.image_names = image_names
         self.patch_batch_size = patch_batch_size
         self.patch_size = _triple(patch_size)
         self.patch_overlap = _triple(patch_overlap)
         self.padding_mode = padding_mode
         self.overlap_mode = overlap_mode
+        self.result_on = result_on
+        self.timings = timings
         self._ops = ops_backend  # the HIP ops; tests inject a CPU double for the gloo plumbing test
 
-    def predict_volume(self, model, volume: torch.Tensor) -> torch.Tensor:
+    def _stamp(self, name, t0, device):
+        if self.timings is None:
+            return t0
+        import time
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        now = time.perf_counter()
+        self.timings[name] = self.timings.get(name, 0.0) + (now - t0)
+        return now
+
+    def predict_volume(self, model, volume: torch.Tensor) -> Optional[torch.Tensor]:
         """volume [C, V0, V1, V2] on the device -> averaged prediction [C_out, V0, V1, V2]."""
+        import time
         k = self._ops
         vshape = tuple(volume.shape[1:])
-        locs = grid_locations(vshape, self.patch_size, self.patch_overlap)
+        border = tuple(o // 2 for o in self.patch_overlap) if self.padding_mode is not None else (0, 0, 0)
+        pshape = tuple(v + 2 * b for v, b in zip(vshape, border))        # the (virtually) padded volume
+        locs = grid_locations(pshape, self.patch_size, self.patch_overlap)
+        dev = volume.device
+        t = time.perf_counter()
         with D.shard_scope() as sharded:  # tiles over ranks only inside distributed.unit_sharding(), outermost sharder
             world = torch.distributed.get_world_size() if sharded else 1
             rank = torch.distributed.get_rank() if sharded else 0
@@ -104,25 +140,40 @@ class PatchPredict:
             with torch.no_grad():
                 for s in range(0, len(mine), self.patch_batch_size):
                     idx = mine[s:s + self.patch_batch_size]
-                    loc = torch.tensor([locs[i] for i in idx], dtype=torch.int32, device=volume.device)
-                    outs.append(model(k.patch_gather(volume, loc, self.patch_size)))
+                    loc = torch.tensor([locs[i] for i in idx], dtype=torch.int32, device=dev)
+                    if self.padding_mode is None:
+                        tiles_in = k.patch_gather(volume, loc, self.patch_size)
+                    else:
+                        tiles_in = k.patch_gather_padded(volume, loc, self.patch_size, border, self.padding_mode,
+                                                         self.pad_value)
+                    t = self._stamp("tile_gather", t, dev)
+                    outs.append(model(tiles_in))
+                    t = self._stamp("model", t, dev)
         local = torch.cat(outs, dim=0) if outs else None
-        meta = torch.tensor([local.shape[1] if local is not None else 0], device=volume.device)
+        meta = torch.tensor([local.shape[1] if local is not None else 0], device=dev)
         if world > 1:  # ranks without tiles learn the channel count (tiny, once per volume)
             torch.distributed.all_reduce(meta, op=torch.distributed.ReduceOp.MAX)
         c_out = int(meta.item())
-        tiles = D.gather_tiles(local, len(locs), (c_out,) + self.patch_size, torch.float32, volume.device,
-                               sharded=world > 1)
-        # aggregation in grid order on every rank: identical bits regardless of world size
-        accum = torch.zeros((c_out,) + vshape, dtype=torch.float32, device=volume.device)
-        count = torch.zeros(vshape, dtype=torch.float32, device=volume.device)
-        all_loc = torch.tensor(locs, dtype=torch.int32, device=volume.device)
+        to_rank0 = world > 1 and self.result_on == "rank0"
+        tiles = D.gather_tiles(local, len(locs), (c_out,) + self.patch_size, torch.float32, dev, sharded=world > 1,
+                               dst=0 if to_rank0 else None)
+        t = self._stamp("exchange", t, dev)
+        if tiles is None:       # result_on="rank0" and this is another rank
+            return None
+        # aggregation in grid order: identical bits regardless of world size
+        accum = torch.zeros((c_out,) + pshape, dtype=torch.float32, device=dev)
+        count = torch.zeros(pshape, dtype=torch.float32, device=dev)
+        all_loc = torch.tensor(locs, dtype=torch.int32, device=dev)
         for s in range(0, len(locs), self.patch_batch_size):  # same batching as the reference loop (:136-141)
             k.patch_accumulate(tiles[s:s + self.patch_batch_size], all_loc[s:s + self.patch_batch_size], accum, count)
-        return k.patch_finalize(accum, count)
+        t = self._stamp("accumulate", t, dev)
+        out = k.patch_finalize(accum, count) if self.padding_mode is None else k.patch_finalize_crop(accum, count, border)
+        self._stamp("finalize", t, dev)
+        return out
 
     def predict(self, model, device, batch, label_attributes=None):
         x = batch["X"].to(device)
         batch = dict(batch)
-        batch["y_pred"] = torch.stack([self.predict_volume(model, v) for v in x])
+        preds = [self.predict_volume(model, v) for v in x]
+        batch["y_pred"] = None if any(p is None for p in preds) else torch.stack(preds)
         return batch

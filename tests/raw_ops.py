@@ -437,6 +437,24 @@ class RawOps:
                                                     self._stream()), "weight_standardize_bwd")
         return dw
 
+    def patch_gather_padded(self, vol, loc, ps, border, mode, value=0.0):
+        vol, loc = self.to(vol), self.to(loc.to(torch.int32))
+        Cc, V0, V1, V2 = vol.shape
+        P = loc.shape[0]
+        out = self.empty(P, Cc, *ps)
+        self._chk(self.fn("patch_gather_padded")(_p(vol), _p(loc), _p(out), P, Cc, V0, V1, V2, ps[0], ps[1], ps[2],
+                                                 border[0], border[1], border[2], mode, float(value), self._stream()),
+                  "patch_gather_padded")
+        return out
+
+    def patch_finalize_crop(self, accum, count, border):
+        accum, count = self.to(accum), self.to(count)
+        Cc, P0, P1, P2 = accum.shape
+        out = self.empty(Cc, P0 - 2 * border[0], P1 - 2 * border[1], P2 - 2 * border[2])
+        self._chk(self.fn("patch_finalize_crop")(_p(accum), _p(count), _p(out), Cc, P0, P1, P2, border[0], border[1],
+                                                 border[2], self._stream()), "patch_finalize_crop")
+        return out
+
     # ---------------------------------------------------------------- ensembles
     @staticmethod
     def _i3(v):

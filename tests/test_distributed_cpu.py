@@ -122,6 +122,19 @@ class CpuPatchOps:
     def patch_finalize(accum, count):
         return accum / count
 
+    @staticmethod
+    def patch_gather_padded(volume, loc, ps, border, mode, value=0.0):
+        import numpy as np
+        kw = {"constant_values": value} if mode == "constant" else {}
+        padded = torch.from_numpy(np.pad(volume.numpy(), ((0, 0),) + tuple((b, b) for b in border), mode=mode, **kw))
+        return CpuPatchOps.patch_gather(padded, loc, ps)
+
+    @staticmethod
+    def patch_finalize_crop(accum, count, border):
+        out = accum / count
+        return out[:, border[0]:out.shape[1] - border[0], border[1]:out.shape[2] - border[1],
+                   border[2]:out.shape[3] - border[2]].contiguous()
+
 
 class TileModel(nn.Module):
     """Not pointwise (neighbouring voxels mix through the rolls, so overlapping tiles really
@@ -166,6 +179,31 @@ def test_sharded_sliding_window_is_bit_identical_to_unsharded():
     with torch.no_grad():
         patches = TileModel()(CpuPatchOps.patch_gather(vol, torch.tensor(locs), (6, 6, 6)))
     torch.testing.assert_close(single, R.aggregate_average(patches, locs, vol.shape[1:]), rtol=0, atol=1e-6)
+
+
+def _predict_padded_rank0(rank=0, world=1):
+    torch.set_num_threads(1)
+    pp = PatchPredict(patch_batch_size=2, patch_size=6, patch_overlap=4, padding_mode="edge", ops_backend=CpuPatchOps,
+                      result_on="rank0")
+    with D.unit_sharding():
+        return pp.predict_volume(TileModel(), _volume())
+
+
+def test_padding_mode_and_rank0_gather_match_the_restatement():
+    """padding_mode='edge' (ms-inference.py:35): pad by overlap // 2, tile, average, crop -- equal to the oracle's
+    restatement through numpy.pad; with result_on='rank0' only rank 0 receives the tiles and aggregates (same bits
+    as one process), the other rank returns None."""
+    nthreads = torch.get_num_threads()
+    single = _predict_padded_rank0()
+    torch.set_num_threads(nthreads)
+    ref = R.sliding_window_average(_volume(), TileModel(), (6, 6, 6), (4, 4, 4), "edge")
+    assert single.shape == ref.shape == (3,) + tuple(_volume().shape[1:])
+    torch.testing.assert_close(single, ref, rtol=0, atol=1e-6)
+    r0, r1 = spawn(_predict_padded_rank0)
+    assert r1 is None and torch.equal(r0, single)
+    with pytest.raises(NotImplementedError):
+        PatchPredict(patch_size=6, padding_mode="mean")
+    assert PatchPredict(patch_size=6, padding_mode=1.5).padding_mode == "constant"
 
 
 def test_predictor_without_opt_in_is_rank_local():

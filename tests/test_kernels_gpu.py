@@ -416,6 +416,17 @@ def test_ensemble_kernels_match_oracle(hip, oracle):
         assert torch.equal(out_h.cpu(), out_o) and torch.equal(acc_h.cpu(), acc_o)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4], ids=["constant", "edge", "reflect", "symmetric", "wrap"])
+def test_padded_gather_and_cropped_finalize(hip, oracle, mode):
+    vol = rnd(3, 9, 6, 11, seed=1)
+    border, ps = (3, 2, 4), (5, 4, 6)
+    locs = torch.tensor([(0, 0, 0), (10, 6, 13), (4, 3, 7), (2, 0, 1)], dtype=torch.int32)
+    assert torch.equal(hip.patch_gather_padded(vol, locs, ps, border, mode, -2.0).cpu(),
+                       oracle.patch_gather_padded(vol, locs, ps, border, mode, -2.0))
+    acc, cnt = rnd(3, 15, 10, 19, seed=2), torch.rand(15, 10, 19) + 1.0
+    close(hip.patch_finalize_crop(acc, cnt, border), oracle.patch_finalize_crop(acc, cnt, border), 1e-6, 1e-7, "crop")
+
+
 def test_error_paths_gpu(hip):
     from segmentation_pipeline_amd import _lib
     L = hip.lib

@@ -339,6 +339,25 @@ def test_patch_predict_end_to_end_on_gpu(golden):
     assert (out.sum(dim=0).cpu() - 1).abs().max() <= 1e-5  # averages of probabilities still sum to 1
 
 
+def test_patch_predict_padding_mode_on_gpu(golden):
+    """padding_mode='edge' / 'reflect' / a constant (prediction.py:114,132): equal to the oracle's restatement of
+    GridSampler padding + GridAggregator crop (numpy.pad); parity with torchio itself stays unpinned (absent)."""
+    from oracle import torch_ref as R
+    from segmentation_pipeline_amd.prediction import PatchPredict
+    g = golden("components.npz")
+    model = ModularUNet(4, 3, [8, 16], 2, block_params=dict(GN8), **CONVT)
+    model.load_state_dict(g.state_dict("flips.sd."))
+    model = model.cuda().eval()
+    vol = torch.randn((4, 20, 16, 24), generator=torch.Generator().manual_seed(5))
+    run = lambda p: model(p.cuda()).cpu()
+    for mode in ("edge", "reflect", 0.25):
+        pp = PatchPredict(patch_batch_size=3, patch_size=8, patch_overlap=4, padding_mode=mode)
+        out = pp.predict(model, torch.device("cuda"), {"X": vol[None]})["y_pred"][0]
+        ref = R.sliding_window_average(vol, run, (8, 8, 8), (4, 4, 4), mode)
+        assert out.shape == (3, 20, 16, 24)
+        assert maxerr(out, ref) <= 1e-5, mode
+
+
 def test_standard_predict_sagittal_split_on_gpu(golden):
     from segmentation_pipeline_amd.prediction import StandardPredict
     g = golden("components.npz")

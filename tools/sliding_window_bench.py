@@ -35,3 +35,21 @@ assert (s - 1).abs().max().item() < 1e-5, (s - 1).abs().max().item()
 print(f"cfg4 sliding window: {n} patches of 4x160^3 per 4x256^3 volume, {dt * 1e3:.1f} ms per volume "
       f"({n / dt:.2f} patches/s), max |sum p - 1| = {(s - 1).abs().max().item():.1e}, "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+# phase table (a device synchronisation per stamp: slower than the overlapped run above, but it separates the
+# per-tile work that shards over GPUs -- tile_gather + model -- from the serial part every aggregating rank repeats:
+# exchange (one gather) + accumulate + finalize)
+import segmentation_pipeline_amd as sp  # noqa: E402
+for mode in (sys.argv[1:] or ["fp32", "bf16"]):
+    sp.set_precision(mode)
+    timings = {}
+    pt = PatchPredict(patch_batch_size=1, patch_size=160, patch_overlap=20, timings=timings)
+    pt.predict_volume(model, vol)
+    timings.clear()
+    for _ in range(reps):
+        pt.predict_volume(model, vol)
+    tot = sum(timings.values()) / reps
+    serial = sum(v for k, v in timings.items() if k in ("exchange", "accumulate", "finalize")) / reps
+    print(f"  [{mode}] phases per volume (ms): " + "  ".join(f"{k} {v / reps * 1e3:.2f}" for k, v in timings.items()) +
+          f"  | total {tot * 1e3:.1f}; serial (not sharded over GPUs) {serial * 1e3:.2f} ms = {serial / tot * 100:.1f} % "
+          f"-> Amdahl bound at 8 GPUs: {tot / (serial + (tot - serial) / 8):.2f}x")
+sp.set_precision("fp32")
