@@ -1849,6 +1849,19 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
       }
     }
   }
+  // Queue-driven: the plan above fills the chip in ONE residency (one workgroup per CU), so a CU that another
+  // kernel still holds when this one starts -- an RCCL gradient bucket overlapping the backward pass -- delays
+  // exactly the workgroup mapped there, and the launch takes up to twice as long.  Splitting the voxel range 2-3x
+  // finer makes 2-3 units per CU that the hardware dispatcher hands to whichever CU is free (a held CU simply
+  // takes fewer); every unit still sums a FIXED tile set into its own slab, so the result does not depend on who
+  // ran what and stays bit-reproducible.  Each unit pays a pipeline fill and a slab write (and the reduce reads
+  // one more slab), so this is only done where a unit keeps >= 32 tiles: measured +0.8 % on 96->32 @128^3 at 3
+  // units per CU, but +9 % / +18 % on 32->32 @128^3 / 64->64 @64^3 (11 / 5 tiles per unit), which stay static.
+  if (tuning().bww_queue && Cin > 4 && Cout > 4 && pairs * nsplit <= cus) {
+    const int64_t per_unit = ceil_div(ntiles, nsplit);
+    const int m = per_unit >= 96 ? 3 : (per_unit >= 64 ? 2 : 1);
+    if (m * nsplit * (int64_t)Cout * Cin * 27 * 4 <= (96ll << 20)) nsplit *= m;
+  }
   if (const int force = tuning().bww_nsplit) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
   if (Cin <= 4 || Cout <= 4)  // tap-on-lane kernel: small LDS footprint, ~3 workgroups per CU
     nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
