@@ -213,6 +213,75 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   }
 }
 
+// ---- 16-row output tile (v_mfma_f32_16x16x4_f32) for the remainder of channel counts that are no multiple of
+// 32 (the reference's real widths are 40 / 80 / 120: research/msseg2/msseg2.py:87, main_config.py:123-127;
+// a 32-row tile for 8 remaining channels is 75 % padding).  Same flop rate as the 32x32x2 form; the K-step of 4
+// is exactly one 4-channel LDS chunk at a tap.  C/D layout: col = lane & 15 (voxel), row = 4 * (lane >> 4) + reg.
+// A 32-voxel group is two MFMAs (x-halves h2); acc[g][h2] holds 4 channels of one voxel per lane.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NTW, int GX>
+__device__ __forceinline__ void store_conv_tile16(const f32x4v (&acc)[NTW][2], float* __restrict__ dst,
+                                                  const float* __restrict__ addp, const float* __restrict__ bias,
+                                                  int o0, int Cout, int z, int y0, int x0, int lane, int D, int H, int W,
+                                                  float* __restrict__ stat) {
+  constexpr int GY = 32 / GX;
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  const int ob = o0 + 4 * (lane >> 4);
+  float bb[4], s1[4], s2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bb[r] = (bias && ob + r < Cout) ? bias[ob + r] : 0.f;
+    s1[r] = s2[r] = 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int vox = 16 * h2 + (lane & 15);
+      const int yg = y0 + g * GY + vox / GX, xg = x0 + vox % GX;
+      const bool ok = z < D && yg < H && xg < W;
+      const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[g][h2][r] + bb[r];
+      if (addp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += addp[(ok && ob + r < Cout) ? base + (int64_t)r * DHW : 0];
+      }
+      if (stat) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = ok ? v[r] : 0.f;
+          s1[r] += t;
+          s2[r] = fmaf(t, t, s2[r]);
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < Cout) dst[base + (int64_t)r * DHW] = v[r];
+      }
+    }
+  if (stat) {  // sum over the 16 lanes (voxels) of each channel quad, fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        s1[r] += __shfl_xor(s1[r], off, 64);
+        s2[r] += __shfl_xor(s2[r], off, 64);
+      }
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ob + r < Cout) {
+          stat[(int64_t)(ob + r) * 2] = s1[r];
+          stat[(int64_t)(ob + r) * 2 + 1] = s2[r];
+        }
+    }
+  }
+}
+
 // ---- persistent variant of conv3_mfma_fwd_kernel ----
 // A workgroup of the kernel above lives for nchunks/ksplit chunks and pays ~2.5 chunks of fixed
 // cost around them (measured: 8-chunk layers reach 112 TFLOP/s, 48-chunk layers 140): the first
@@ -224,21 +293,27 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
 // this stays bit-reproducible.  The
 // (item, chunk) sequence is flattened: during the last chunk of an item the FIRST chunk of the next
 // item is prefetched, so the MFMA stream only stops for the output stores.
-template <int NTW, int GX>
+// M16: the 16-row remainder tile (see store_conv_tile16): the items are the spatial tiles x ONE 16-channel tile at
+// o_base; one MFMA 16x16x4 per (tap, 16-voxel half group) covers the chunk's 4 channels, 27 steps per chunk.
+// The LDS channel stride is padded to == 16 (mod 32) so the four channels of a B fragment (lane >> 4) and the two
+// voxel halves fall on distinct banks; the weights of odd channels are read from the upper 16 columns of their
+// LDS row (both halves of a row are staged with the same 16 output channels).
+template <int NTW, int GX, bool M16 = false>
 __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles,
     int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride,
-    float* __restrict__ stat, int* __restrict__ work_counter) {
+    float* __restrict__ stat, int* __restrict__ work_counter, int o_base) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
-                CS = T::CS, CC = T::CC;
+                CS0 = T::CS, CC = T::CC;
+  constexpr int CS = M16 ? ((CS0 + 31) / 32) * 32 + 16 : CS0;   // LDS channel stride (elements past CS0: padding)
   constexpr int XE = CC * CS;
   constexpr int XPER = (XE + 255) / 256;
   constexpr int WE4 = CC * 27 * 8;
   constexpr int WPER = (WE4 + 255) / 256;
-  constexpr int NSTEP = (CC / 2) * 27;
+  constexpr int NSTEP = M16 ? 27 : (CC / 2) * 27;
   static_assert(XPER <= NSTEP && WPER <= NSTEP, "one prefetch item per MFMA step");
   __shared__ float xs[2][XE];
   __shared__ __attribute__((aligned(16))) float ws[2][CC * 27 * 32];
@@ -269,7 +344,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     q.x0 = txt * TX;
     q.y0 = (sp % ty_tiles) * TY;
     q.z0 = (sp / ty_tiles) * TZ;
-    q.o0 = (r % otiles) * 32;
+    q.o0 = o_base + (r % otiles) * 32;
     r /= otiles;
     q.ks = r % ksplit;
     q.n = r / ksplit;
@@ -292,7 +367,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
       const int zz = r / PS, r2 = r - zz * PS;
       const int yy = r2 / RS, xx = r2 - yy * RS;
       const int gz = q.z0 + zz - 1, gy = q.y0 + yy - 1, gx = q.x0 + xx - 1;
-      const bool ok = e < XE && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const bool ok = e < XE && r < CS0 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                      (unsigned)gx < (unsigned)W;
       goff[i] = ok ? (unsigned)(c * DHW + gz * iHW + gy * W + gx) * 4u : OOB;
     }
   };
@@ -312,7 +388,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     if (s < WPER) {
       const int idx = tid + 256 * s;
       const int idc = idx < WE4 ? idx : WE4 - 1;
-      wr[s] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & 7) * 4);
+      wr[s] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)(idc >> 3) * cout_pad + (idc & (M16 ? 3 : 7)) * 4);
     }
   };
   auto commit = [&](int buf) {
@@ -374,7 +450,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
   __syncthreads();
   int buf = 0;
 
-  f32x16 acc[NTW];
+  f32x16 acc[M16 ? 1 : NTW];
+  f32x4v acc16[M16 ? NTW : 1][2];
   while (true) {
     // thread 0 takes a ticket for this workgroup's next item now; the item is published through
     // LDS after the first chunk (a barrier later) and consumed at the start of the last chunk
@@ -384,10 +461,17 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
       if (tid == 0) next_item_s = resolve(pending);
       __syncthreads();
     }
+    if constexpr (M16) {
 #pragma unroll
-    for (int g = 0; g < NTW; ++g)
+      for (int g = 0; g < NTW; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[g][0][r] = acc16[g][1][r] = 0.f;
+    } else {
+#pragma unroll
+      for (int g = 0; g < NTW; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    }
     Item nxt = cur;
     int nit = total;
     for (int ch = cur.ch_begin; ch < cur.ch_end; ++ch) {
@@ -400,6 +484,40 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
         compute_goff(nxt);
         chunk_setup(nxt, nxt.ch_begin, live);
       }
+      if constexpr (M16) {
+        const int kq = lane >> 4, l16 = lane & 15;                       // channel of the chunk, voxel / output row
+        const float* wb = ws[buf] + kq * (27 * 32) + l16 + 16 * (kq & 1);
+        const float* xb0 = xs[buf] + kq * CS + wave * PS + (l16 / GX) * RS + l16 % GX;                  // x-half 0
+        const float* xb1 = xs[buf] + kq * CS + wave * PS + ((16 + l16) / GX) * RS + (16 + l16) % GX;    // x-half 1
+        float av[2], bv[2][NTW][2];
+        auto lds_step = [&](int s, int slot) {  // s = tap
+          const int dz = s / 9, dy = (s / 3) % 3, dx = s % 3;
+          av[slot] = wb[s * 32];
+#pragma unroll
+          for (int g = 0; g < NTW; ++g) {
+            bv[slot][g][0] = xb0[dz * PS + (g * GY + dy) * RS + dx];
+            bv[slot][g][1] = xb1[dz * PS + (g * GY + dy) * RS + dx];
+          }
+        };
+        lds_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          if (s + 1 < NSTEP) lds_step(s + 1, (s + 1) & 1);
+          fetch_item(s);
+#pragma unroll
+          for (int g = 0; g < NTW; ++g)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+              acc16[g][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1], bv[s & 1][g][h2], acc16[g][h2], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 2 * NTW; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       const float* xb = xs[buf] + half * CS + wave * PS + ly * RS + lx;
       const float* wb = ws[buf] + half * (27 * 32) + l32;
       float av[2], bv[2][NTW];
@@ -426,6 +544,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
       if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
       commit(buf ^ 1);
       __syncthreads();
@@ -433,7 +552,17 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     }
 
     // ---- output tile of `cur` ----
-    {
+    if constexpr (M16) {
+      const int z = cur.z0 + wave;
+      if (ksplit == 1) {
+        float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * 4 + wave) * Cout * 2 : nullptr;
+        store_conv_tile16<NTW, GX>(acc16, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
+                                   cur.o0, Cout, z, cur.y0, cur.x0, lane, D, H, W, st);
+      } else {
+        store_conv_tile16<NTW, GX>(acc16, slab + (int64_t)cur.ks * slab_stride + (int64_t)cur.n * Cout * D * HW, nullptr,
+                                   nullptr, cur.o0, Cout, z, cur.y0, cur.x0, lane, D, H, W, nullptr);
+      }
+    } else {
       const int z = cur.z0 + wave;
       const int xg = cur.x0 + lx;
       const bool lane_ok = z < D && xg < W;
@@ -1022,69 +1151,80 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
 //    each row keeps the slices from being hoisted back into one block).  The prefetch is
 //    unconditional (the last iteration re-fetches its own tile): a branch would split the row into
 //    basic blocks and undo the interleaving.
-template <int GX>
-__global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
-    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
-    int ctiles, int otiles, int64_t xbs, int64_t ybs) {
+// Channel counts that are no multiple of 32 (the reference's real widths are 40 / 80 / 120): a remainder of 1..16
+// channels on the o and / or the c side runs on v_mfma_f32_16x16x4_f32 over 16-channel sub-tiles (MT x NT of them;
+// the full 32 x 32 pair keeps the 32x32x2 form): a (32 o, 16 c) pair costs half a full pair, (16, 16) a quarter --
+// 40 x 40 channels are 2.25 pair-units of MFMA time instead of 4.  K is a quad of x-adjacent voxels; the fragments
+// are (channel = lane & 15, voxel = lane >> 4), so the LDS channel strides are == 2 (mod 32) there.
+// C/D layout 16x16x4: col (c) = lane & 15, row (o) = 4 * (lane >> 4) + reg.
+struct BwwClasses {
+  int of, cf, orem, crem;   // full 32-channel tiles per side, and whether a 16-row remainder tile follows them
+  int ns[4];                // voxel-range splits of a pair of class (o remainder ? 2 : 0) + (c remainder ? 1 : 0)
+  int start[4];             // first workgroup of each class
+};
+
+template <int GX, int MT, int NT>
+__device__ __forceinline__ void bww2_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                          float* __restrict__ sl, int N, int Cin, int Cout, int D, int H, int W,
+                                          int tz_tiles, int ty_tiles, int tx_tiles, int nsplit, int split, int c0,
+                                          int o0, int64_t xbs, int64_t ybs, float* __restrict__ xs,
+                                          float* __restrict__ ds) {
   using T = BwTile<GX>;
-  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS,
-                CSW = T::CSW, DSW = T::DSW, NV = T::NV;
+  constexpr bool F = MT == 2 && NT == 2;     // full pair: one 32x32x2 MFMA per (tap, voxel pair)
+  constexpr int NCX = 16 * NT, NCO = 16 * MT;
+  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, RS = T::RS, PS = T::PS, NV = T::NV;
+  constexpr int CSW = F ? T::CSW : T::CSW + 1, DSW = F ? T::DSW : T::DSW + 1;
   static_assert(NV == 256, "one dy voxel per thread");
-  __shared__ float xs[32 * CSW];
-  __shared__ float ds[32 * DSW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
-  // XCD-aware placement (speed only): blocks b and b + 8 are observed to share an XCD and its L2, so
-  // the block id is swizzled to give each XCD a contiguous run of virtual ids, and the virtual id is
-  // decoded with the (c-tile, o-tile) pair fastest: the workgroups on one L2 work on the same and on
-  // neighbouring voxel tiles, sharing the dy tile, the x tile and the halos.  A bijection of the
-  // grid -- which partial sums land in which slab does not change, so results stay bit-identical.
-  int vid;
-  {
-    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int pairs = ctiles * otiles;
-  const int pair = vid % pairs, split = vid / pairs;
-  const int ctile = pair % ctiles, otile = pair / ctiles;
-  const int c0 = ctile * 32, o0 = otile * 32;
+  const int kq = lane >> 4, l16 = lane & 15;
   const int iHW = H * W, iDHW = D * H * W;
 
-  f32x16 acc[7];
+  f32x16 acc[F ? 7 : 1];
+  f32x4v acc16[F ? 1 : 7][MT][NT];
+  if constexpr (F) {
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+    for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc16[t][mt][nt][r] = 0.f;
+  }
 
   // per-wave tap bases into the x halo tile; everything else in an LDS read address is an immediate
   const float* xt[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = min(wave * 7 + t, 26);
-    xt[t] = xs + l32 * CSW + half + (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3);
+    xt[t] = xs + (F ? l32 * CSW + half : l16 * CSW + kq) + (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3);
   }
-  const float* db = ds + l32 * DSW + half;
+  const float* db = ds + (F ? l32 * DSW + half : l16 * DSW + kq);
 
   const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
   const int ntiles = N * tiles_per_n;
   const int vz = tid / (TY * TX), vy = (tid / TX) % TY, vx = tid % TX;
 
   constexpr int RPC = (TZ + 2) * (TY + 2);   // rows per channel
-  constexpr int ROWS = 32 * RPC;
+  constexpr int ROWS = NCX * RPC;
   constexpr int Q = TX / 4;                  // float4 per interior row
-  constexpr int NI = ROWS * Q, IPER = NI / 256;
-  constexpr int NH = ROWS * 2, HPER = NH / 256;
-  static_assert(NI % 256 == 0 && NH % 256 == 0, "every thread owns whole prefetch items");
+  constexpr int NI = ROWS * Q, IPER = (NI + 255) / 256;
+  constexpr int NH = ROWS * 2, HPER = (NH + 255) / 256;
+  constexpr bool IFULL = NI % 256 == 0, HFULL = NH % 256 == 0;   // every thread owns whole prefetch items
   constexpr int NR = TZ * TY;                // MFMA rows per tile == prefetch slices
   constexpr unsigned OOB = 0x80000000u;      // >= num_records of any sample we accept: load returns 0
   f32x4 xi[IPER];
   float xh[HPER];
-  float dr[32];
+  float dr[NCO];
 
   // tile-invariant descriptors (see conv3_mfma_bww_kernel)
   int relI[IPER], ldsI[IPER], relH[HPER], ldsH[HPER];
@@ -1097,7 +1237,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
     const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
     relI[k] = c * iDHW + zz * iHW + yy * W + 4 * q;
     ldsI[k] = c * CSW + zz * PS + yy * RS + 1 + 4 * q;
-    codeI[k] = (1u << zz) | (1u << (8 + yy)) | (1u << (20 + q));
+    codeI[k] = (IFULL || m < NI) ? (1u << zz) | (1u << (8 + yy)) | (1u << (20 + q)) : 0xffffffffu;  // past the end: never valid
   }
 #pragma unroll
   for (int j = 0; j < HPER; ++j) {
@@ -1107,7 +1247,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
     const int zz = rem / (TY + 2), yy = rem - zz * (TY + 2);
     relH[j] = c * iDHW + zz * iHW + yy * W + (side ? TX : -1);
     ldsH[j] = c * CSW + zz * PS + yy * RS + (side ? TX + 1 : 0);
-    codeH[j] = (1u << zz) | (1u << (8 + yy)) | (1u << (20 + side));
+    codeH[j] = (HFULL || h < NH) ? (1u << zz) | (1u << (8 + yy)) | (1u << (20 + side)) : 0xffffffffu;
   }
 
   // per-tile uniform state of the prefetch
@@ -1159,22 +1299,24 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
             float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(base + relH[j]) * 4u : OOB, 0, 0));
       }
 #pragma unroll
-    for (int j = 0; j < 32; ++j)
+    for (int j = 0; j < NCO; ++j)
       if (j % NR == r)
         dr[j] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rd, vok ? (unsigned)(dsp + j * iDHW) * 4u : OOB, 0, 0));
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int k = 0; k < IPER; ++k) {
-      float* p = xs + ldsI[k];
+    for (int k = 0; k < IPER; ++k)
+      if (IFULL || tid + 256 * k < NI) {
+        float* p = xs + ldsI[k];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) p[e] = xi[k][e];
-    }
+        for (int e = 0; e < 4; ++e) p[e] = xi[k][e];
+      }
 #pragma unroll
-    for (int j = 0; j < HPER; ++j) xs[ldsH[j]] = xh[j];
+    for (int j = 0; j < HPER; ++j)
+      if (HFULL || tid + 256 * j < NH) xs[ldsH[j]] = xh[j];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) ds[j * DSW + tid] = dr[j];
+    for (int j = 0; j < NCO; ++j) ds[j * DSW + tid] = dr[j];
   };
 
   if (split < ntiles) {
@@ -1192,12 +1334,30 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
     for (int r = 0; r < NR; ++r) {
       fetch_slice(r);
       const int ro = (r / TY) * PS + (r % TY) * RS;  // immediate
+      if constexpr (F) {
 #pragma unroll
-      for (int xp = 0; xp < TX / 2; ++xp) {
-        const float a = db[r * TX + 2 * xp];
+        for (int xp = 0; xp < TX / 2; ++xp) {
+          const float a = db[r * TX + 2 * xp];
 #pragma unroll
-        for (int t = 0; t < 7; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xt[t][ro + 2 * xp], acc[t], 0, 0, 0);
+          for (int t = 0; t < 7; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xt[t][ro + 2 * xp], acc[t], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int xq = 0; xq < TX / 4; ++xq) {
+          float a[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt] = db[mt * 16 * DSW + r * TX + 4 * xq];
+#pragma unroll
+          for (int t = 0; t < 7; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float b = xt[t][nt * 16 * CSW + ro + 4 * xq];
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc16[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b, acc16[t][mt][nt], 0, 0, 0);
+            }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1207,29 +1367,111 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
   }
 
   // partial dW -> slab[split][27][Cout][Cin]: the lane index is the input channel, so every store
-  // writes 32 consecutive floats (the [o][c][27] order of dW would scatter each lane to its own
+  // writes 32 (16) consecutive floats (the [o][c][27] order of dW would scatter each lane to its own
   // cache line: 28k line requests per workgroup instead of ~900)
-  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
-  const int c = c0 + l32;
+  if constexpr (F) {
+    const int c = c0 + l32;
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = wave * 7 + t;
-    if (tap < 27 && c < Cin) {
+    for (int t = 0; t < 7; ++t) {
+      const int tap = wave * 7 + t;
+      if (tap < 27 && c < Cin) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int tap = wave * 7 + t;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int c = c0 + 16 * nt + l16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * mt + 4 * kq + r;
+            if (tap < 27 && c < Cin && o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc16[t][mt][nt][r];
+          }
+        }
+    }
+  }
+}
+
+template <int GX>
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww2_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
+    int ctiles, int otiles, int64_t xbs, int64_t ybs) {
+  using T = BwTile<GX>;
+  __shared__ float xs[32 * T::CSW];
+  __shared__ float ds[32 * T::DSW];
+  // XCD-aware placement (speed only): blocks b and b + 8 are observed to share an XCD and its L2, so
+  // the block id is swizzled to give each XCD a contiguous run of virtual ids, and the virtual id is
+  // decoded with the (c-tile, o-tile) pair fastest: the workgroups on one L2 work on the same and on
+  // neighbouring voxel tiles, sharing the dy tile, the x tile and the halos.  A bijection of the
+  // grid -- which partial sums land in which slab does not change, so results stay bit-identical.
+  int vid;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pairs = ctiles * otiles;
+  const int pair = vid % pairs, split = vid / pairs;
+  const int ctile = pair % ctiles, otile = pair / ctiles;
+  bww2_body<GX, 2, 2>(x, dy, slab + (int64_t)split * 27 * Cout * Cin, N, Cin, Cout, D, H, W, tz_tiles, ty_tiles, tx_tiles,
+                      nsplit, split, ctile * 32, otile * 32, xbs, ybs, xs, ds);
+}
+
+// The same, with the pairs of a channel remainder on their 16-row sub-tiles: ONE launch holds all four pair
+// classes, each class cut into a number of voxel-range splits proportional to its MFMA cost, so that every
+// workgroup of the launch lasts about equally long (the grid still fills the chip in whole residencies).
+template <int GX>
+__global__ __launch_bounds__(256, 1) void conv3_mfma_bww2c_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, BwwClasses k,
+    int64_t xbs, int64_t ybs) {
+  using T = BwTile<GX>;
+  __shared__ float xs[32 * (T::CSW + 1)];
+  __shared__ float ds[32 * (T::DSW + 1)];
+  int vid;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int cls = vid >= k.start[3] ? 3 : (vid >= k.start[2] ? 2 : (vid >= k.start[1] ? 1 : 0));
+  const int idx = vid - k.start[cls];
+  const int npairs = cls == 0 ? k.of * k.cf : (cls == 1 ? k.of : (cls == 2 ? k.cf : 1));
+  const int pair = idx % npairs, split = idx / npairs;
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
+  const int ns = k.ns[cls];
+  if (cls == 0) {
+    bww2_body<GX, 2, 2>(x, dy, sl, N, Cin, Cout, D, H, W, tz_tiles, ty_tiles, tx_tiles, ns, split, (pair % k.cf) * 32,
+                        (pair / k.cf) * 32, xbs, ybs, xs, ds);
+  } else if (cls == 1) {
+    bww2_body<GX, 2, 1>(x, dy, sl, N, Cin, Cout, D, H, W, tz_tiles, ty_tiles, tx_tiles, ns, split, k.cf * 32, pair * 32,
+                        xbs, ybs, xs, ds);
+  } else if (cls == 2) {
+    bww2_body<GX, 1, 2>(x, dy, sl, N, Cin, Cout, D, H, W, tz_tiles, ty_tiles, tx_tiles, ns, split, pair * 32, k.of * 32,
+                        xbs, ybs, xs, ds);
+  } else {
+    bww2_body<GX, 1, 1>(x, dy, sl, N, Cin, Cout, D, H, W, tz_tiles, ty_tiles, tx_tiles, ns, split, k.cf * 32, k.of * 32,
+                        xbs, ybs, xs, ds);
   }
 }
 
 // dW[o][c][27] = sum over splits of slab[split][27][o][c] (fixed order): one block per (o, 32 input
 // channels); coalesced reads along c, transposed through LDS, one contiguous 864-float write.
 __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                            int Cin, int Cout, int nsplit) {
+                                                            int Cin, int Cout, BwwClasses k) {
   __shared__ float tr[32 * 27 + 32];
   const int o = blockIdx.x, c0 = blockIdx.y * 32;
+  const int nsplit = k.ns[(o >= k.of * 32 ? 2 : 0) + ((int)blockIdx.y >= k.cf ? 1 : 0)];  // splits of this pair's class
   const int64_t plane = (int64_t)Cout * Cin, split_stride = 27 * plane;
   const int cw = min(32, Cin - c0);
   for (int e = threadIdx.x; e < 27 * 32; e += 256) {
@@ -1604,6 +1846,11 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   p.kin_pad = (int)round_up(kin, cc);
   p.mout_pad = (int)round_up(mout, 32);
   p.otiles = p.mout_pad / 32;
+  // fp32: a remainder of 1..16 channels runs as ONE 16-row tile on v_mfma_f32_16x16x4_f32 (half the MFMA time of a
+  // padded 32-row tile): 40 channels = 32 + 16 rows instead of 64, 80 = 64 + 16 instead of 96
+  p.tile16 = (!h16 && tuning().tile16 && mout % 32 >= 1 && mout % 32 <= 16) ? 1 : 0;
+  if (p.tile16) p.otiles -= 1;
+  const int wtiles = p.otiles + p.tile16;   // workgroup items per spatial tile
   p.nchunks = p.kin_pad / cc;
   p.tz_tiles = (int)ceil_div(D, 4);
   p.tx_tiles = (int)ceil_div(W, p.gx);
@@ -1638,10 +1885,11 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   }
   for (int i = 0; i < 4 && !h16; ++i) {
     const int ntw = cands[i];
-    if (force_ntw && ntw != force_ntw) continue;
+    if (p.tile16 && ntw == 8) continue;              // the 16-row kernel is instantiated for NTW <= 4
+    if (force_ntw && ntw != force_ntw && !(p.tile16 && force_ntw == 8)) continue;
     const int ty = ntw * gy;
     if (ty > H && ntw > 1 && !force_ntw) continue;  // do not overhang H by a whole factor
-    const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+    const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * wtiles * N;
     const int per_cu = ntw <= 4 ? 2 : 1;
     // narrow tiles re-read the weights from LDS more often per MFMA ((1 + NTW) / NTW reads each)
     const double chunk_us = 54.0 * ntw * 64.0 / 2040.0 / (ntw >= 4 ? 1.0 : ntw == 2 ? 0.96 : 0.8);
@@ -1681,6 +1929,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
                    tuning().conv_persistent;
+    (void)wtiles;
   }
   // packed weights + 256 B for the work counter of the persistent kernel
   p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (h16 ? 2 : 4), 256) + 256;
@@ -1719,16 +1968,27 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
   dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
             (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
-  if (p.persistent) {
-    const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus());
-    hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
-                       add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter);
-    return;
+  const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus());
+  if (p.otiles > 0) {
+    if (p.persistent) {
+      hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, false>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
+                         add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
+                         p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter, 0);
+    } else {
+      hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
+                         y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
+                         p.ksplit, xbs, ybs, slab_stride, stat);
+    }
   }
-  hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
-                     y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
-                     p.ksplit, xbs, ybs, slab_stride, stat);
+  if constexpr (NTW <= 4) {
+    if (p.tile16) {  // the 16-row remainder tile: queue-driven kernel over (spatial tile x sample x split) items
+      const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * N * p.ksplit;
+      hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, true>), dim3((unsigned)std::min<int64_t>(items, slots)),
+                         dim3(256), 0, st, x, wp, bias, add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles,
+                         p.ty_tiles, p.tx_tiles, 1, p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter,
+                         32 * p.otiles);
+    }
+  }
 }
 
 // bytes of the c8 staging copy the fp32-input entry points make in 16-bit operand modes
@@ -1813,6 +2073,9 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
 struct BwwPlan {
   int gx, tz_tiles, ty_tiles, tx_tiles, otiles, ctiles, nsplit;
   size_t slab_bytes;
+  bool classes;     // a 1..16 channel remainder on either side: conv3_mfma_bww2c_kernel (needs the gen-2 conditions)
+  BwwClasses k;     // always filled: without remainders one class with ns[*] = nsplit
+  int class_wgs;    // grid of the class kernel
 };
 
 static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
@@ -1826,6 +2089,12 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
   p.ctiles = (int)ceil_div(Cin, 32);
   const int64_t ntiles = (int64_t)N * p.tz_tiles * p.ty_tiles * p.tx_tiles;
   const int64_t pairs = (int64_t)p.otiles * p.ctiles;
+  const auto rem16 = [](int c) { return c % 32 >= 1 && c % 32 <= 16 ? 1 : 0; };
+  p.k.orem = tuning().tile16 ? rem16(Cout) : 0;
+  p.k.crem = tuning().tile16 ? rem16(Cin) : 0;
+  p.k.of = p.otiles - p.k.orem;
+  p.k.cf = p.ctiles - p.k.crem;
+  p.classes = (p.k.orem || p.k.crem) && Cin > 4 && Cout > 4;
   // One workgroup per CU; workgroups have equal work, so time ~ rounds x (tiles per split + fixed
   // cost of a workgroup: pipeline fill + the 110 KB slab write, ~half a tile).  Pick the split that
   // minimises it (a power of two up to the tile count) instead of just filling 256 CUs once.
@@ -1867,7 +2136,38 @@ static BwwPlan plan_bww(int N, int Cin, int Cout, int D, int H, int W) {
     nsplit = std::max<int64_t>(1, 768 / std::max<int64_t>(1, ceil_div(Cin <= 4 ? Cout : Cin, 32)));
   nsplit = std::min<int64_t>(nsplit, ntiles);
   p.nsplit = (int)nsplit;
-  p.slab_bytes = (size_t)round_up((int64_t)p.nsplit * Cout * Cin * 27 * 4, 256);
+  int64_t max_ns = nsplit;
+  for (int c = 0; c < 4; ++c) p.k.ns[c] = p.nsplit;
+  if (p.classes) {
+    // pair classes of the remainder kernel: MFMA cost of a pair in units of a full 32 x 32 pair; the split count of
+    // a class is proportional to it, scaled so that the whole launch is `rounds` residencies of equal workgroups
+    const double cost[4] = {1.0, 0.5, 0.5, 0.25};
+    const int64_t npairs[4] = {(int64_t)p.k.of * p.k.cf, (int64_t)p.k.of * p.k.crem, (int64_t)p.k.orem * p.k.cf,
+                               (int64_t)p.k.orem * p.k.crem};
+    double units = 0;
+    for (int c = 0; c < 4; ++c) units += cost[c] * (double)npairs[c];
+    // splits of a full pair: one residency of the chip (one workgroup per CU), never more splits than tiles; the
+    // rounding of the per-class counts must not spill a workgroup into a second residency
+    double base = std::min((double)ntiles, (double)cus / units);
+    if (const int force = tuning().bww_nsplit) base = (double)std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
+    int wg = 0;
+    for (;;) {
+      wg = 0;
+      max_ns = 1;
+      for (int c = 0; c < 4; ++c) {
+        const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)(base * cost[c] + 0.5)));
+        p.k.ns[c] = npairs[c] ? (int)ns : 1;
+        p.k.start[c] = wg;
+        wg += (int)(npairs[c] * p.k.ns[c]);
+        if (npairs[c]) max_ns = std::max<int64_t>(max_ns, ns);
+      }
+      if (wg <= cus || base <= 1.0 || tuning().bww_nsplit) break;
+      base *= 0.99;
+    }
+    p.class_wgs = wg;
+    max_ns = std::max<int64_t>(max_ns, nsplit);   // the uniform plan stays usable (generic kernel when W % 4 != 0)
+  }
+  p.slab_bytes = (size_t)round_up(max_ns * Cout * Cin * 27 * 4, 256);
   return p;
 }
 
@@ -2249,7 +2549,14 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
   hipLaunchKernelGGL((conv3_mfma_bww2_kernel<GXV>), dim3((unsigned)(p.ctiles * p.otiles * p.nsplit)),  \
                      dim3(256), 0, st, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, \
                      p.ty_tiles, p.tx_tiles, p.nsplit, p.ctiles, p.otiles, xbs, ybs);
-    if (gen2) {
+#define M355_BWW2C_LAUNCH(GXV)                                                                    \
+  hipLaunchKernelGGL((conv3_mfma_bww2c_kernel<GXV>), dim3((unsigned)p.class_wgs), dim3(256), 0, st, x, dy, slab, d->N, \
+                     d->Cin, d->Cout, d->D, d->H, d->W, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.k, xbs, ybs);
+    BwwClasses kred = p.k;   // what the reduction sums: the class splits, or the uniform count
+    if (gen2 && p.classes) {
+      if (p.gx == 32) { M355_BWW2C_LAUNCH(32) } else if (p.gx == 16) { M355_BWW2C_LAUNCH(16) } else { M355_BWW2C_LAUNCH(8) }
+    } else if (gen2) {
+      for (int c = 0; c < 4; ++c) kred.ns[c] = p.nsplit;
       if (p.gx == 32) { M355_BWW2_LAUNCH(32) } else if (p.gx == 16) { M355_BWW2_LAUNCH(16) } else { M355_BWW2_LAUNCH(8) }
     } else if (p.gx == 32)
       M355_BWW_LAUNCH(32)
@@ -2259,7 +2566,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
       M355_BWW_LAUNCH(8)
     if (gen2) {
       hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)p.ctiles), dim3(256), 0, st, slab, dw,
-                         d->Cin, d->Cout, p.nsplit);
+                         d->Cin, d->Cout, kred);
     } else {
       const int64_t total = (int64_t)d->Cout * d->Cin * 27;
       const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);

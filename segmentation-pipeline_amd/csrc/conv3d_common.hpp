@@ -136,7 +136,8 @@ struct FwdPlan {
   bool persistent;  // more items than resident workgroups: the queue-driven kernel variants
   int gx, ntw;
   int tz_tiles, ty_tiles, tx_tiles;
-  int otiles, kin_pad, mout_pad, nchunks, ksplit;
+  int otiles, kin_pad, mout_pad, nchunks, ksplit;   // otiles: 32-row output tiles
+  int tile16;       // + one 16-row remainder tile at channel 32 * otiles (fp32 path, mout % 32 in 1..16)
   size_t wp_bytes, slab_bytes;
 };
 

@@ -16,7 +16,7 @@ patches are cut out by the `patch_gather` kernel at corner locations drawn on th
 torchio is not available offline, so both follow its documented behaviour (parity unpinned, as for
 the grid sampler); the tests check the distributional properties and the index arithmetic.
 """
-from typing import Optional, Sequence, Tuple
+from typing import Callable, Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
 
@@ -94,3 +94,92 @@ class WeightedSampler(UniformSampler):
         for v in extra or ():
             out.append(self._ops.patch_gather(v, loc, self.patch_size))
         return (out[0] if not extra else tuple(out)), loc
+
+
+
+class VolumeFeeder:
+    """Double-buffered host -> device feeding of whole volumes for patch training (the feeding half of N2).
+
+    The reference's patch loader (`tio.Queue`, data_loader_factory.py:36-54) cuts patches on the CPU and ships
+    every patch batch over PCIe.  Here a SUBJECT's volumes cross the link once: while the samplers above cut
+    patches from the resident volume(s) on the device, the next subject is staged into page-locked host memory and
+    copied to the device on a side HIP stream (`non_blocking`), so the H2D transfer (a 4 x 256^3 fp32 volume is
+    268 MB = ~4.5 ms at PCIe Gen5 x16) overlaps `patches_per_volume` training steps.  Two device slots and two
+    pinned staging buffers per tensor name are reused for the whole run (no allocation in the loop).
+
+        feeder = VolumeFeeder(subjects, device)             # subjects: iterable of {name: CPU tensor}
+        for vols in feeder:                                  # vols: {name: device tensor}, valid until the next step
+            for _ in range(patches_per_volume):
+                (x, y), loc = sampler(vols["X"], vols["prob"], n, extra=[vols["y"]])
+                ...
+    """
+
+    def __init__(self, subjects: Iterable[dict], device, pin_memory: bool = True):
+        self.subjects = subjects
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.pin = pin_memory and self.cuda
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._slots = [{}, {}]       # device tensors per slot
+        self._stage = [{}, {}]       # pinned host tensors per slot
+        self._ready = [None, None]   # event: the slot's upload has finished
+        self._free = [None, None]    # event: the consumer is done with the slot
+
+    def _upload(self, slot: int, subject: dict):
+        """stage `subject` into slot `slot` (asynchronously on the copy stream)"""
+        dev, st = self._slots[slot], self._stage[slot]
+        if self.cuda:
+            if self._free[slot] is not None:
+                self.copy_stream.wait_event(self._free[slot])   # the trainer has finished reading this slot
+            ctx = torch.cuda.stream(self.copy_stream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for name, t in subject.items():
+                if not torch.is_tensor(t):
+                    dev[name] = t
+                    continue
+                if name not in dev or dev[name].shape != t.shape or dev[name].dtype != t.dtype:
+                    dev[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                    if self.pin:
+                        st[name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                if self.pin:
+                    st[name].copy_(t)                       # pageable -> pinned (host memcpy)
+                    dev[name].copy_(st[name], non_blocking=True)
+                else:
+                    dev[name].copy_(t)
+            for name in list(dev):
+                if name not in subject:
+                    del dev[name]
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+                self._ready[slot] = ev
+
+    def __iter__(self) -> Iterator[dict]:
+        it = iter(self.subjects)
+        try:
+            nxt = next(it)
+        except StopIteration:
+            return
+        slot = 0
+        self._upload(slot, nxt)
+        while True:
+            try:
+                nxt = next(it)
+                have_next = True
+            except StopIteration:
+                have_next = False
+            if have_next:
+                self._upload(slot ^ 1, nxt)                 # next subject in flight while this one is consumed
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
+            yield dict(self._slots[slot])
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._free[slot] = ev
+            if not have_next:
+                return
+            slot ^= 1

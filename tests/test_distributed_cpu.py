@@ -347,6 +347,20 @@ def test_train_loop_patience_and_time_budget_single_process():
     assert loop3.stop_reason == "time_expired" and loop3.iteration == 0
 
 
+def test_volume_feeder_yields_every_subject_in_order_on_cpu():
+    """host logic of the double-buffered feeder (two slots reused, shapes may change between subjects)"""
+    from segmentation_pipeline_amd.sampling import VolumeFeeder
+    subs = [{"X": torch.full((2, 4, 4, 4), float(i)), "y": torch.full((1, 4, 4, 4), float(-i)), "name": f"s{i}"}
+            for i in range(5)]
+    subs[3]["X"] = torch.full((2, 6, 4, 4), 3.0)
+    seen = []
+    for vols in VolumeFeeder(subs, "cpu"):
+        seen.append((vols["name"], float(vols["X"].mean()), tuple(vols["X"].shape), float(vols["y"].mean())))
+    assert [s[0] for s in seen] == [f"s{i}" for i in range(5)]
+    assert [s[1] for s in seen] == [0.0, 1.0, 2.0, 3.0, 4.0] and seen[3][2] == (2, 6, 4, 4)
+    assert list(VolumeFeeder([], "cpu")) == []
+
+
 class BNNet(nn.Module):
     def __init__(self):
         super().__init__()

@@ -87,6 +87,48 @@ def test_conv3d_persistent_kernel_matches_oracle(hip, oracle, env, tuning):
               "persistent bwd_data")
 
 
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}, {"M355_CONV_NTW": "1"}, {"M355_CONV_NTW": "2", "M355_CONV_KSPLIT": "3"},
+                                 {"M355_CONV_NTW": "4", "M355_CONV_KSPLIT": "1"}])
+def test_conv3d_16_row_remainder_tile(hip, oracle, env, tuning):
+    """Channel counts that are no multiple of 32 (the reference's real widths 40 / 80 / 120, research/msseg2/
+    msseg2.py:87): the last 1..16 output channels run as one 16-row tile on v_mfma_f32_16x16x4_f32.  Forward
+    (bias + residual), data gradient (the remainder is then over Cin), every lane width (W = 8 / 16 / 32+), every
+    voxel-tile height, split-K, a tiny residency; against the oracle and against the padded 32-row plan
+    (M355_TILE16=0), which must agree to rounding."""
+    for (N, ci, co, D, H, W) in [(1, 64, 40, 8, 8, 16), (1, 40, 80, 8, 12, 32), (2, 12, 8, 9, 10, 36), (1, 33, 16, 5, 9, 8),
+                                 (1, 48, 33, 6, 7, 20), (1, 20, 120, 4, 8, 8)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
+        add = rnd(N, co, D, H, W, seed=4)
+        dy = rnd(N, co, D, H, W, seed=5)
+        tuning(M355_TILE16=1, **env)
+        y16 = hip.conv3d_fwd(x, w, b, add)
+        dx16 = hip.conv3d_bwd_data(dy, w, x.shape)
+        close(y16, oracle.conv3d_fwd(x, w, b, add), what=f"fwd {ci}->{co}")
+        close(dx16, oracle.conv3d_bwd_data(dy, w, x.shape), what=f"bwd_data {ci}->{co}")
+        tuning(M355_TILE16=0, **env)
+        close(y16, hip.conv3d_fwd(x, w, b, add), 2e-6, 2e-6, "vs padded 32-row plan")
+        close(dx16, hip.conv3d_bwd_data(dy, w, x.shape), 2e-6, 2e-6, "bwd_data vs padded 32-row plan")
+
+
+@pytest.mark.parametrize("env", [{}, {"M355_BWW_NSPLIT": "3"}, {"M355_BWW_NSPLIT": "1"}])
+def test_conv3d_bwd_weight_remainder_pair_classes(hip, oracle, env, tuning):
+    """Weight gradient with a 1..16 channel remainder on the output and / or the input side: the pairs touching a
+    remainder run on 16-channel sub-tiles (v_mfma_f32_16x16x4_f32), all four pair classes in one launch with
+    cost-proportional split counts (conv3_mfma_bww2c_kernel).  Both sides ragged, one side only, no full tile on a
+    side at all, every lane width, N = 2, ragged volumes; vs the oracle and vs the padded 32 x 32 plan."""
+    for (N, ci, co, D, H, W) in [(1, 40, 40, 8, 8, 32), (1, 64, 40, 8, 8, 16), (2, 12, 8, 9, 10, 36), (1, 33, 80, 5, 9, 8),
+                                 (1, 80, 33, 6, 7, 20), (1, 120, 16, 4, 8, 8), (1, 48, 96, 4, 6, 12)]:
+        x, dy = rnd(N, ci, D, H, W, seed=1), rnd(N, co, D, H, W, seed=5)
+        tuning(M355_TILE16=1, **env)
+        dw, db = hip.conv3d_bwd_weight(x, dy, 3)
+        dwo, dbo = oracle.conv3d_bwd_weight(x, dy, 3)
+        tol = 3e-5 * (N * D * H * W) ** 0.5
+        close(dw, dwo, 3e-5, tol, f"bwd_weight {ci}->{co}")
+        close(db, dbo, 3e-5, tol, "dbias")
+        tuning(M355_TILE16=0, **env)
+        close(dw, hip.conv3d_bwd_weight(x, dy, 3)[0], 1e-5, tol / 3, "vs padded 32 x 32 pairs")
+
+
 @pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}])
 def test_conv3d_fused_statistics(hip, oracle, env, tuning):
     """m355_conv3d_fwd_stats + m355_norm_stats_from_partials == statistics of the conv output (GroupNorm and

@@ -417,6 +417,22 @@ def test_device_side_samplers_on_gpu():
     assert (pmaps[:, 0, 4, 4, 4] == 1.0).all()
 
 
+def test_volume_feeder_double_buffered_uploads_on_gpu():
+    """N2 feeding half: pinned, double-buffered H2D on a side stream; every subject arrives intact and in order while
+    the previous one is being sampled (device-side WeightedSampler on the resident volume)."""
+    from segmentation_pipeline_amd.sampling import UniformSampler, VolumeFeeder
+    g = torch.Generator().manual_seed(3)
+    subs = [{"X": torch.randn((2, 24, 20, 28), generator=g), "name": i} for i in range(4)]
+    sampler = UniformSampler(8)
+    dg = torch.Generator(device="cuda").manual_seed(0)
+    for i, vols in enumerate(VolumeFeeder(subs, "cuda")):
+        assert vols["name"] == i and vols["X"].is_cuda
+        patches, loc = sampler(vols["X"], 6, generator=dg)
+        ref = subs[i]["X"]
+        for p, (a, b, c) in zip(patches.cpu(), loc.tolist()):
+            assert torch.equal(p, ref[:, a:a + 8, b:b + 8, c:c + 8])
+
+
 @pytest.mark.parametrize("norm", ["group", "batch"])
 def test_residual_blocks_with_batch_gt1_match_cpu_oracle(norm):
     """Residual Block3d (components.py:41-46,67-68) with N = 2: the fused residual add is dense while

@@ -25,11 +25,14 @@ def run(name, model, shape, ncls, cw=None, steps=3):
         torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
     print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)", flush=True)
 
+only = sys.argv[1] if len(sys.argv) > 1 else ""   # "msseg2" / "dmri_hippo": run one of the two (profiling)
 torch.manual_seed(0)
-run("msseg2 ModularUNet(2,2,[40,40,80,80,120,120],6,residual,Blur) 1x2x96^3",
+if only in ("", "msseg2"):
+  run("msseg2 ModularUNet(2,2,[40,40,80,80,120,120],6,residual,Blur) 1x2x96^3",
     ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
                 downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
                 upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0}),
     (1, 2, 96, 96, 96), 2, [1, 100])
-run("dmri_hippo NestedResUNet(3,2,40) 8x3x48x88x24 (sagittal split of 4x3x96x88x24)",
+if only in ("", "dmri_hippo"):
+  run("dmri_hippo NestedResUNet(3,2,40) 8x3x48x88x24 (sagittal split of 4x3x96x88x24)",
     NestedResUNet(3, 2, 40), (8, 3, 48, 88, 24), 2)
