@@ -268,6 +268,101 @@ __global__ __launch_bounds__(256) void convt_k2s2_fwd_c8_kernel(
   }
 }
 
+// ---- c8 -> c8 on the 16-bit matrix core (large levels).  The kernel above multiplies in fp32 (157 TFLOP/s peak)
+// and lands its 16-byte items 32 bytes apart; for the two full-resolution decoder levels that is 3-6x the time the
+// bytes need.  Here the GEMM [8 Cout x Cin] x [Cin x voxels] runs on v_mfma_f32_32x32x16_{bf16,f16}: a c8 item
+// (8 channels of a voxel) IS the B fragment of a lane, loaded from global memory straight into registers and kept
+// for all the m-tiles; the weights are rounded to the 16-bit type (the operand rounding of the mode, as in the
+// 3x3x3 kernels) and staged ONCE per workgroup in LDS in A-fragment order, then the workgroup walks voxel tiles.
+// An m-tile is (channel block cb, z parity a); its 32 rows are ordered so that a lane ends up with the 8 channels
+// of two output voxels -- row m: channel (m & 3) + 4 * ((m >> 3) & 1), x parity c = (m >> 2) & 1 = the lane half,
+// y parity b = m >> 4 -- and one store instruction of the wave covers 64 consecutive 16-byte items of an output row.
+template <typename HT, int KS, int NG>
+__global__ __launch_bounds__(256) void convt_k2s2_fwd_h16_kernel(
+    const HT* __restrict__ x16, const float* __restrict__ w, const float* __restrict__ bias, HT* __restrict__ y16,
+    int Cin, int Cout, int D, int H, int W, int64_t xbs16, int64_t ybs16, int mt_per_wg) {
+  using hx8 = typename H16<HT>::x8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  hx8* afrag = reinterpret_cast<hx8*>(lds_raw);  // [m-tile of this workgroup][k-step][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int ks_n = (Cin + 15) / 16, CBin = (Cin + 7) / 8;
+  const int mtiles = 2 * ((Cout + 7) / 8);
+  const int mt0 = blockIdx.y * mt_per_wg, nmt = min(mtiles, mt0 + mt_per_wg) - mt0;
+  for (int e = tid; e < nmt * ks_n * 64; e += 256) {
+    const int L = e & 63, s = (e >> 6) % ks_n, mt = mt0 + (e >> 6) / ks_n;
+    const int cb = mt >> 1, a = mt & 1, m = L & 31;
+    const int o = cb * 8 + (m & 3) + 4 * ((m >> 3) & 1), c = (m >> 2) & 1, b = m >> 4;
+    hx8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = s * 16 + (L >> 5) * 8 + j;
+      v[j] = (k < Cin && o < Cout) ? (HT)w[(((int64_t)k * Cout + o) * 2 + a) * 4 + b * 2 + c] : (HT)0.f;
+    }
+    afrag[e] = v;
+  }
+  __syncthreads();
+  const int n = blockIdx.z;
+  const hx8* xin = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs16);
+  hx8* yn = reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs16);
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t OS = (int64_t)S * 8;
+  const hx8 zero = {};
+  for (int vt = blockIdx.x; (int64_t)vt * (128 * NG) < S; vt += gridDim.x) {
+    const int vb = vt * (128 * NG) + wave * (32 * NG);
+    if (vb >= S) continue;
+    hx8 bfr[KS][NG];
+    int64_t obase[NG];
+    bool vok[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int v = vb + g * 32 + l32;
+      vok[g] = v < S;
+      const int vc = min(v, S - 1);
+      const int ix = vc % W, iy = (vc / W) % H, iz = vc / (W * H);
+      obase[g] = ((int64_t)(2 * iz) * OH + 2 * iy) * OW + 2 * ix + half;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int cbk = 2 * s + half;
+        bfr[s][g] = (s < ks_n && vok[g] && cbk < CBin) ? xin[(int64_t)cbk * S + vc] : zero;
+      }
+    }
+    for (int t = 0; t < nmt; ++t) {
+      const int mt = mt0 + t, cb = mt >> 1, a = mt & 1;
+      f32x16 acc[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+      const hx8* af = afrag + (int64_t)t * ks_n * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        if (s < ks_n) {
+          const hx8 av = af[s * 64];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g] = H16<HT>::mfma(av, bfr[s][g], acc[g]);
+        }
+      float bv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = (bias && cb * 8 + q < Cout) ? bias[cb * 8 + q] : 0.f;
+      hx8* yo = yn + (int64_t)cb * OS + (int64_t)a * OH * OW;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (!vok[g]) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          hx8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (HT)(acc[g][b * 8 + q] + bv[q]);
+          yo[obase[g] + (int64_t)b * OW] = o;
+        }
+      }
+    }
+  }
+}
+
 // ---- data gradient: workgroup = NVT input voxels x 32*MT input channels; K is walked 4 output
 // channels (32 k) at a time.  dY is de-interleaved while staging (dys[(o,t)][v]; the k-pair is
 // (c=0, c=1) of one (o,a,b)); the next slab's global loads are in flight while the current one is
@@ -817,6 +912,30 @@ extern "C" int m355_conv_transpose3d_fwd_h16(const m355_conv3d_desc* d, const vo
   M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)y16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
                "conv_transpose3d_fwd_h16: c8 tensor not 16B aligned");
   hipStream_t st = (hipStream_t)stream;
+  {
+    // large levels: 16-bit MFMA kernel (weights staged once per workgroup; worth it from ~16k voxels per sample)
+    const int ks_n = (int)ceil_div(d->Cin, 16);
+    const int mtiles = 2 * (int)c8_blocks(d->Cout);
+    if (S >= 16384 && ks_n <= 8 && tuning().convt_h16) {
+      const int mt_per_wg = std::max(1, std::min(mtiles, 64 / ks_n));          // <= 64 KB of A fragments
+      const int groups = (int)ceil_div(mtiles, mt_per_wg);
+      const int ng = (S / 256) * groups * d->N >= 512 ? 2 : 1;
+      const int64_t vox_tiles = ceil_div(S, 128 * ng);
+      const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(vox_tiles, ceil_div(512, (int64_t)groups * d->N)));
+      dim3 grid((unsigned)gx, (unsigned)groups, (unsigned)d->N);
+      const size_t lds = (size_t)mt_per_wg * ks_n * 1024;
+#define M355_CONVT_H16(HT, KS, NG)                                                                                  \
+  hipLaunchKernelGGL((convt_k2s2_fwd_h16_kernel<HT, KS, NG>), grid, dim3(256), lds, st, (const HT*)x16, w, bias,     \
+                     (HT*)y16, d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, mt_per_wg)
+#define M355_CONVT_H16_T(HT)                                                         \
+  if (ks_n <= 4) { if (ng == 2) M355_CONVT_H16(HT, 4, 2); else M355_CONVT_H16(HT, 4, 1); } \
+  else { if (ng == 2) M355_CONVT_H16(HT, 8, 2); else M355_CONVT_H16(HT, 8, 1); }
+      if (compute == M355_COMPUTE_BF16) { M355_CONVT_H16_T(__bf16) } else { M355_CONVT_H16_T(_Float16) }
+#undef M355_CONVT_H16_T
+#undef M355_CONVT_H16
+      return check_launch("convt_k2s2_fwd_h16");
+    }
+  }
   const int64_t vox_tiles = ceil_div(S, nvt) * d->N;
   const int mpairs = (int)ceil_div(ceil_div(d->Cout, 4), 2);
   const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, vox_tiles), ceil_div(mpairs, 4)));

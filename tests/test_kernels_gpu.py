@@ -644,6 +644,31 @@ def test_conv_transpose3d_c8(hip, oracle, compute):
             assert (y16[:, -1, :, co % 8:].float() == 0).all()
 
 
+@pytest.mark.parametrize("compute", [1, 2])
+def test_conv_transpose3d_c8_large_levels_on_16bit_mfma(hip, oracle, compute, tuning):
+    """From 16k voxels per sample the c8 conv-transpose runs on v_mfma_f32_32x32x16_{bf16,f16}
+    (convt_k2s2_fwd_h16_kernel): weights rounded to the 16-bit type like every other operand of the mode, fp32
+    accumulation, 64 consecutive 16-byte items per store.  == the oracle on the rounded operands (output rounded
+    once); ragged channel counts (odd number of input channel blocks, Cout not a multiple of 8), ragged voxel
+    tiles, N = 2, both k-step widths; and == the fp32-MFMA c8 kernel (M355_CONVT_H16=0) to operand rounding."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    ulp = 2.0 ** -8 if compute == 1 else 2.0 ** -11
+    for (N, ci, co, D, H, W) in [(1, 64, 32, 16, 32, 32), (1, 128, 64, 16, 32, 32), (1, 24, 40, 17, 31, 33), (2, 16, 8, 16, 32, 32),
+                                 (1, 72, 13, 8, 64, 32)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(ci, co, 2, 2, 2, seed=2) * 0.2, rnd(co, seed=3)
+        x16 = hip.act16_pack(x, compute)
+        ref = oracle.convt_fwd(x.to(dt).float(), w.to(dt).float(), b, 2, 0, 0)
+        tuning(M355_CONVT_H16=1)
+        y16 = hip.conv_transpose3d_fwd_h16(x16, ci, (D, H, W), w, b, compute)
+        got = _c8_to_ncdhw(y16, co, (2 * D, 2 * H, 2 * W))
+        assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + 1e-4).all(), (ci, co, (got - ref).abs().max().item())
+        if co % 8:
+            assert (y16[:, -1, :, co % 8:].float() == 0).all()
+        tuning(M355_CONVT_H16=0)
+        old = _c8_to_ncdhw(hip.conv_transpose3d_fwd_h16(x16, ci, (D, H, W), w, b, compute), co, (2 * D, 2 * H, 2 * W))
+        close(got, old, 4 * ulp, 4 * ulp * (ci ** 0.5) * 0.2, "vs the fp32-weight c8 kernel")
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["unet_gn_convt.npz", "unet_default_bn.npz", "unet_res_blur.npz"])
 def test_c8_inference_flow_matches_fp32_golden_and_autograd_path(golden, mode, name):

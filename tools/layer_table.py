@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-layer table of the conv launches (ops.CONV_PROFILE) of one train step of the two architectures the reference
+trained (tools/arch_bench.py): launches grouped by (op, GFLOP, algorithmic MB, plan), mean ms, TFLOP/s.
+usage: python tools/layer_table.py [msseg2|dmri_hippo|cfg2]"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from segmentation_pipeline_amd import ops  # noqa: E402
+from segmentation_pipeline_amd.models import ModularUNet, NestedResUNet, BlurConv3d, BlurConvTranspose3d  # noqa: E402
+from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "msseg2"
+torch.manual_seed(0)
+if which == "msseg2":
+    model = ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
+                        downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
+                        upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0})
+    shape, ncls = (1, 2, 96, 96, 96), 2
+elif which == "cfg2":
+    import bench
+    cfg = bench.WORKLOADS["cfg2"]
+    model, shape, ncls = bench.build_model(cfg), (1, cfg[0]) + cfg[4], cfg[1]
+else:
+    model, shape, ncls = NestedResUNet(3, 2, 40), (8, 3, 48, 88, 24), 2
+model = model.cuda()
+crit = HybridLogisticDiceLoss()
+opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)
+x = torch.randn(shape, device="cuda")
+lab = torch.randint(0, ncls, (shape[0],) + tuple(shape[2:]), device="cuda")
+y = torch.nn.functional.one_hot(lab, ncls).permute(0, 4, 1, 2, 3).float().contiguous()
+
+
+def step():
+    model.train()
+    ld = crit(model(x), y)
+    opt.zero_grad()
+    ld["loss"].backward()
+    opt.step()
+
+
+for _ in range(2):
+    step()
+ops.CONV_PROFILE = []
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+groups = {}
+for (tag, flops, e0, e1, plan, nbytes) in prof:
+    g = groups.setdefault((tag, round(flops / 1e9, 2), round(nbytes / 1e6, 1), plan), [0.0, 0])
+    g[0] += e0.elapsed_time(e1)
+    g[1] += 1
+tot = sum(g[0] for g in groups.values()) / 3
+print(f"{which}: conv launches of one train step, {tot:.2f} ms (event-timed, includes packing / reductions)")
+for (tag, gf, mb, plan), (ms, n) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {tag:18s} {gf:8.2f} GF {mb:7.1f} MB plan {str(plan):18s} x{n // 3:<3d} {ms / n:7.3f} ms  {gf / (ms / n):7.1f} TF/s  "
+          f"{ms / 3:7.2f} ms/step")
