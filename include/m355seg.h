@@ -147,6 +147,16 @@ int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16, int64_t x
                            void* workspace, size_t workspace_bytes, void* stream);
 int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride, const float* w,
                              float* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* weight gradient of the 3x3x3 / stride 1 / padding 1 conv with BOTH operands in c8: x16 = the packed conv input the
+ * forward pass consumed, dy16 = the packed output gradient the data gradient consumes (so the 16-bit training flow
+ * converts each tensor once).  dw fp32 [Cout][Cin][3][3][3]; dbias (may be NULL) is reduced from the fp32 `dy`
+ * (NCDHW, desc->y_batch_stride; may be NULL when dbias is).  Replaces the reference's autograd conv weight
+ * gradient under `torch.cuda.amp.autocast` (segmentation_pipeline/segmentation_trainer.py:203-227).  Volumes
+ * below 2^25 voxels per sample. */
+size_t m355_conv3d_bwd_weight_h16_workspace(const m355_conv3d_desc* d);
+int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                               int64_t dy16_batch_stride, const float* dy, float* dw, float* dbias, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
  * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA

@@ -62,6 +62,8 @@ SIGNATURES = {
     "m355_conv3d_fwd_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_fwd_h16_c8": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _i64, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_bwd_weight_h16_workspace": (_sz, [_CD]),
+    "m355_conv3d_bwd_weight_h16": (C.c_int, [_CD, _P, _i64, _P, _i64, _P, _P, _P, _P, _sz, _P]),
     "m355_norm_act_fwd_h16": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _P]),
     "m355_norm_act_fwd_c8": (C.c_int, [_ND, _P, _i64, _P, _P, _P, _P, _P, _i64, _P, _i64, _i32, _P]),
     "m355_act16_partials_slots": (_i64, [_i64]),

@@ -2407,6 +2407,75 @@ extern "C" int m355_conv3d_bwd_data_h16(const m355_conv3d_desc* d, const void* d
                        dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8), packed ? w : nullptr);
 }
 
+// ---- weight gradient with both operands in c8 (the 16-bit training flow keeps the packed conv input of the forward
+// pass and packs dy once for the data and the weight gradient) ----
+static size_t dbias_ws_bytes(int Cout, int64_t S);
+int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int64_t ybs, void* ws, hipStream_t st);
+static int bww_c8_nsplit(const m355_conv3d_desc* d) {
+  const int64_t ntiles = (int64_t)d->N * ceil_div(d->D, 2) * ceil_div(d->H, 4) * ceil_div(d->W, 32);
+  const int64_t pairs = ceil_div(d->Cin, 32) * ceil_div(d->Cout, 32);
+  const int64_t slots = 2 * (int64_t)num_cus();
+  if (const int force = tuning().bww_nsplit) return (int)std::min<int64_t>(force, ntiles);
+  // time ~ residencies x (tiles per split x ~1.8 us (two workgroups share a CU) + ~4 us pipeline fill and slab
+  // write) + the reduction's read of nsplit slabs at ~4 TB/s
+  const double slab_us = (double)d->Cout * d->Cin * 27 * 4 / 4.0e6;
+  double best = 1e30;
+  int64_t best_ns = 1;
+  for (int r = 1; r <= 4; ++r) {
+    const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots * r / pairs));
+    const double rounds = (double)ceil_div(pairs * ns, slots);
+    const double cost = rounds * ((double)ceil_div(ntiles, ns) * 1.8 + 4.0) + (double)ns * slab_us;
+    if (cost < best * 0.97) {
+      best = cost;
+      best_ns = ns;
+    }
+  }
+  return (int)best_ns;
+}
+
+static bool bww_c8_ok(const m355_conv3d_desc* d) {
+  return is_k3s1p1(d) && d->compute != M355_COMPUTE_F32 && (int64_t)d->D * d->H * d->W * 64 < (1ll << 31);
+}
+
+extern "C" size_t m355_conv3d_bwd_weight_h16_workspace(const m355_conv3d_desc* d) {
+  if (!d || !bww_c8_ok(d)) return 0;
+  return (size_t)round_up((int64_t)bww_c8_nsplit(d) * d->Cout * d->Cin * 27 * 4, 256) +
+         dbias_ws_bytes(d->Cout, (int64_t)d->D * d->H * d->W);
+}
+
+extern "C" int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                          const void* dy16, int64_t dy16_batch_stride, const float* dy, float* dw,
+                                          float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_h16(d, "conv3d_bwd_weight_h16")) return rc;
+  M355_REQUIRE(x16 && dy16 && dw && workspace, M355_EINVALID_ARG, "conv3d_bwd_weight_h16: null pointer");
+  M355_REQUIRE(bww_c8_ok(d), M355_EUNSUPPORTED, "conv3d_bwd_weight_h16: volume too large for the c8 kernel (>= 2^25 voxels)");
+  M355_REQUIRE(!dbias || dy, M355_EINVALID_ARG, "conv3d_bwd_weight_h16: the bias gradient needs the fp32 dy");
+  M355_REQUIRE(workspace_bytes >= m355_conv3d_bwd_weight_h16_workspace(d), M355_EWORKSPACE,
+               "conv3d_bwd_weight_h16: workspace too small (%zu < %zu)", workspace_bytes,
+               m355_conv3d_bwd_weight_h16_workspace(d));
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t xbs = dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8);
+  const int64_t ybs = dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "conv3d_bwd_weight_h16: c8 tensor not 16B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bww_c8_nsplit(d);
+  float* slab = (float*)workspace;
+  if (int rc = launch_bww_c8(d->compute, x16, dy16, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, nsplit, xbs, ybs, st))
+    return rc;
+  BwwClasses kred{};
+  kred.of = (int)ceil_div(d->Cout, 32);
+  kred.cf = (int)ceil_div(d->Cin, 32);
+  for (int c = 0; c < 4; ++c) kred.ns[c] = nsplit;
+  hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)kred.cf), dim3(256), 0, st, slab, dw, d->Cin,
+                     d->Cout, kred);
+  if (dbias) {
+    const size_t slab_b = (size_t)round_up((int64_t)nsplit * d->Cout * d->Cin * 27 * 4, 256);
+    launch_dbias(dy, dbias, d->N, d->Cout, S, dense_or(d->y_batch_stride, (int64_t)d->Cout * S), (char*)workspace + slab_b, st);
+  }
+  return check_launch("conv3d_bwd_weight_h16");
+}
+
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
   M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
   out4[0] = out4[1] = out4[2] = out4[3] = 0;

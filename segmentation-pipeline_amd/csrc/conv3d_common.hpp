@@ -157,6 +157,10 @@ int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, in
                    int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
                    hipStream_t st);
 
+// weight gradient from c8 operands (tile 2 x 4 x 32 voxels); slab[split][27][Cout][Cin], summed by slab_reduce_t_kernel
+int launch_bww_c8(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
+                  int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st);
+
 // y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                      const float* __restrict__ add, float* __restrict__ y, int N,

@@ -833,6 +833,199 @@ int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, in
   return check_launch("conv3_mfma_bww_h16");
 }
 
+// ------------------------------------------------ weight gradient from c8 operands (16-bit training flow)
+// dW[o,c,tap] = sum_v dy[o,v] * x[c,v+off(tap)] with BOTH operands handed over in the c8 layout (h16.hpp) -- the
+// tensors the forward / data-gradient convolutions of the same layer consume anyway, so nothing is converted here
+// and the bytes per voxel are half of the fp32 kernel above.  LDS keeps the tiles VOXEL-major, [voxel][32 channels]
+// (64-byte rows = four c8 items, copied 16 bytes at a time straight from global memory): a tap is then a whole-row
+// offset for every (dz, dy, dx) -- no pre-shifted copies -- and the MFMA fragments (k = 16 x-adjacent voxels of one
+// channel) come out of `ds_read_b64_tr_b16`, the hardware transpose read: per 16-lane group a block of 4 voxels x
+// 16 channels, delivered channel-per-lane.  The four rows a half-wave reads are 256 contiguous bytes: conflict-free
+// for every tap.  Tile = 2 x 4 x 32 voxels (halo 4 x 6 x 34): 68.6 KB of LDS, two workgroups per CU; each wave
+// owns 7 of the 27 taps (as the fp32 kernels).  Out-of-volume halo voxels, ragged tiles and channel blocks past the
+// tensor are zero-filled by the buffer descriptor.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <typename HT>
+__device__ __forceinline__ typename H16<HT>::x8 tr_frag(const unsigned char* p) {
+  // two transposed 4-voxel blocks -> the 8 k-values of this lane's half
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 256));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename H16<HT>::x8, v);
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
+    const HT* __restrict__ x16, const HT* __restrict__ dy16, float* __restrict__ slab, int N, int CBin, int CBout,
+    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit, int ctiles,
+    int otiles, int64_t xbs16, int64_t ybs16) {
+  constexpr int TZ = 2, TY = 4, TX = 32, NV = TZ * TY * TX;          // 256 voxels
+  constexpr int HR = TX + 2, HP = (TY + 2) * HR, HVX = (TZ + 2) * HP;  // 34, 204, 816 halo voxels
+  constexpr int XI = HVX * 4, XPER = (XI + 255) / 256;                // 16-byte items of the x tile: 3264 -> 13
+  constexpr int DI = NV * 4, DPER = DI / 256;                         // of the dy tile: 1024 -> 4
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) uint4 xs[XI];   // [halo voxel][channel block of the tile]
+  __shared__ __attribute__((aligned(16))) uint4 ds[DI];   // [voxel][channel block]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  int vid;  // XCD-aware placement, (c-tile, o-tile) pair fastest: see conv3_mfma_bww2_kernel
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pairs = ctiles * otiles;
+  const int pair = vid % pairs, split = vid / pairs;
+  const int ctile = pair % ctiles, otile = pair / ctiles;
+  const int iHW = H * W, S = D * iHW;
+
+  // tile-invariant part of the staging: item e of the x tile = (channel block e / HVX, halo voxel e % HVX)
+  int xrel[XPER];
+  unsigned xcode[XPER];
+#pragma unroll
+  for (int k = 0; k < XPER; ++k) {
+    const int e = tid + 256 * k;
+    const int cbl = e / HVX, hv = e - cbl * HVX;
+    const int zz = hv / HP, r = hv - zz * HP;
+    const int yy = r / HR, xx = r - yy * HR;
+    xrel[k] = cbl * S + zz * iHW + yy * W + xx;
+    xcode[k] = e < XI ? (1u << zz) | (1u << (8 + yy)) | ((unsigned)xx << 16) : 0xffffu;  // past the end: never valid
+  }
+  const int dv = tid, dvz = dv / (TY * TX), dvy = (dv / TX) % TY, dvx = dv % TX;  // dy item k: (block k, voxel tid)
+
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+  __amdgpu_buffer_rsrc_t rx, rd;
+  unsigned zymask = 0u;
+  int xbase = 0, dbase = 0, xlim = 0;
+  bool dok = false;
+  auto tile_setup = [&](int tile, bool live) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles, tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    const int nbx = min(4, CBin - 4 * ctile), nbd = min(4, CBout - 4 * otile);
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x16 + (int64_t)n * xbs16 + (int64_t)(4 * ctile) * S * 8), 0,
+                                           live ? nbx * S * 16 : 0, 0x00020000);
+    rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy16 + (int64_t)n * ybs16 + (int64_t)(4 * otile) * S * 8), 0,
+                                           live ? nbd * S * 16 : 0, 0x00020000);
+    zymask = 0u;
+    for (int zz = 0; zz < TZ + 2; ++zz)
+      if (z0 + zz - 1 >= 0 && z0 + zz - 1 < D) zymask |= 1u << zz;
+    for (int yy = 0; yy < TY + 2; ++yy)
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) zymask |= 1u << (8 + yy);
+    xbase = (z0 - 1) * iHW + (y0 - 1) * W + x0 - 1;
+    xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
+    const int gz = z0 + dvz, gy = y0 + dvy, gx = x0 + dvx;
+    dok = gz < D && gy < H && gx < W;
+    dbase = gz * iHW + gy * W + gx;
+  };
+  uint4 xr[XPER], dr[DPER];
+  auto fetch = [&]() {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+      const int xx = (int)(xcode[k] >> 16);
+      const bool ok = ((xcode[k] & 0xffffu) & ~zymask) == 0u && (unsigned)(xlim + xx) < (unsigned)W;
+      xr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(xbase + xrel[k]) * 16u : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < DPER; ++k)
+      dr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rd, dok ? (unsigned)(k * S + dbase) * 16u : OOB, 0, 0));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+      const int e = tid + 256 * k;
+      const int cbl = e / HVX, hv = e - cbl * HVX;
+      if (e < XI) xs[hv * 4 + cbl] = xr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DPER; ++k) ds[dv * 4 + k] = dr[k];
+  };
+
+  // transposed-read bases: lane 4q + p of a 16-lane group addresses voxel row q, channels 4p .. 4p+3 of its
+  // group's 16-channel half; groups 2, 3 (the upper MFMA half) take the voxels 8 .. 15 of the k-step
+  const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int lb = (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
+  const unsigned char* db = reinterpret_cast<const unsigned char*>(ds) + lb;
+  const unsigned char* xt[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(wave * 7 + t, 26);
+    xt[t] = reinterpret_cast<const unsigned char*>(xs) + lb + ((tap / 9) * HP + ((tap / 3) % 3) * HR + tap % 3) * 64;
+  }
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (split < ntiles) {
+    tile_setup(split, true);
+    fetch();
+    commit();
+  }
+  __syncthreads();
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    tile_setup(more ? tile + nsplit : tile, more);
+    fetch();   // unconditional (zero-sized descriptors after the last tile): keeps the loop one basic block
+#pragma unroll
+    for (int r = 0; r < TZ * TY; ++r) {
+      const int z = r / TY, y = r % TY;
+#pragma unroll
+      for (int xk = 0; xk < 2; ++xk) {
+        const typename H16<HT>::x8 a = tr_frag<HT>(db + ((z * TY + y) * TX + 16 * xk) * 64);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+          acc[t] = H16<HT>::mfma(a, tr_frag<HT>(xt[t] + (z * HP + y * HR + 16 * xk) * 64), acc[t]);
+      }
+    }
+    __syncthreads();  // every wave is done reading this tile
+    if (more) commit();
+    __syncthreads();
+  }
+
+  // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
+  const int c = ctile * 32 + l32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave * 7 + t;
+    if (tap < 27 && c < Cin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = otile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+      }
+    }
+  }
+}
+
+int launch_bww_c8(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
+                  int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st) {
+  const int CBin = (int)c8_blocks(Cin), CBout = (int)c8_blocks(Cout);
+  const int ctiles = (int)ceil_div(Cin, 32), otiles = (int)ceil_div(Cout, 32);
+  const int tz = (int)ceil_div(D, 2), ty = (int)ceil_div(H, 4), tx = (int)ceil_div(W, 32);
+  const dim3 grid((unsigned)(ctiles * otiles * nsplit));
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(conv3_bww_c8_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x16, (const __bf16*)dy16, slab,
+                       N, CBin, CBout, Cin, Cout, D, H, W, tz, ty, tx, nsplit, ctiles, otiles, xbs16, ybs16);
+  else
+    hipLaunchKernelGGL(conv3_bww_c8_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x16,
+                       (const _Float16*)dy16, slab, N, CBin, CBout, Cin, Cout, D, H, W, tz, ty, tx, nsplit, ctiles, otiles,
+                       xbs16, ybs16);
+  return check_launch("conv3_bww_c8");
+}
+
 #ifdef M355_H16_STAMPS
 }  // namespace m355
 extern "C" int m355_debug_h16_stamps(unsigned long long* host_out) {

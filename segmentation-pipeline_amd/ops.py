@@ -216,6 +216,9 @@ def as_f32(x):
 # the 16-bit modes, flipped / transposed for the data gradient) and the library used to repack before every
 # launch (234 launches per profiled run).  Weights only change at optimizer.step(), which bumps `_version`.
 PACK_CACHE = True
+# 16-bit precision modes, training: pack the conv input / output gradient to c8 once in the autograd function and run
+# forward, data gradient and weight gradient on the c8 entry points (False: fp32 operands, staged inside the library)
+H16_TRAIN_C8 = True
 
 
 def _packed_weight(weight, d, which):
@@ -352,13 +355,28 @@ class _Conv3dFn(torch.autograd.Function):
         wbuf, flags = _packed_weight(weight, d, 0)
         fuse_sm = meta.softmax and L.m355_conv3d_fuses_softmax(C.byref(d)) != 0
         dk = _with_flags(d, flags | (_lib.CONV_SOFTMAX if fuse_sm else 0))
-        ws = _workspace(L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
+        # 16-bit training flow: the conv input is packed to c8 ONCE here (the library would stage the same copy
+        # internally), consumed by the forward kernel and kept for the weight gradient (m355_conv3d_bwd_weight_h16
+        # reads both operands as c8); the fp32 input is then not saved at all
+        x16 = None
+        if (H16_TRAIN_C8 and d.compute != _lib.COMPUTE_F32 and k == 3 and meta.stride == 1 and meta.pad == 1
+                and Cin > 4 and Cout > 4 and not meta.softmax and D * H * W * 64 < 2 ** 31
+                and ctx.needs_input_grad[0]):
+            x16 = pack_act16(x, d.compute)
+        ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0) if x16 is not None
+                        else L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
         prof = CONV_PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         slots = L.m355_conv3d_stats_slots(C.byref(d)) if meta.stats is not None else 0
-        if slots > 0:
+        if x16 is not None:
+            part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x.device) if slots > 0 else None
+            check(L.m355_conv3d_fwd_h16(C.byref(dk), x16.ptr(), x16.batch_stride(), _p(wbuf), _p(bias), _p(add), _p(y),
+                                        _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16")
+            if part is not None:
+                meta.stats["partials"], meta.stats["slots"] = part, slots
+        elif slots > 0:
             # statistics of the following normalisation fused into the conv epilogue (per-wave partials)
             part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x.device)
             check(L.m355_conv3d_fwd_stats(C.byref(dk), _p(x), _p(wbuf), _p(bias), _p(add), _p(y), _p(part), _p(ws),
@@ -380,8 +398,13 @@ class _Conv3dFn(torch.autograd.Function):
         ctx.meta, ctx.desc = meta, d
         ctx.has_bias, ctx.has_add = bias is not None, add is not None
         ctx.part_channels = [p.shape[1] for p in parts]
+        ctx.x16 = None
         if meta.softmax:
             ctx.save_for_backward(x, weight, y)
+        elif x16 is not None:
+            ctx.x16 = (x16.C, x16.spatial, x16.compute)
+            ctx.x_meta = (x.dtype, x.device)
+            ctx.save_for_backward(x16.data, weight)
         else:
             ctx.save_for_backward(x, weight)
         return y
@@ -408,15 +431,28 @@ class _Conv3dFn(torch.autograd.Function):
         dw = db = dadd = None
         dparts: List[Optional[torch.Tensor]] = [None] * len(ctx.part_channels)
         prof = CONV_PROFILE
+        x16 = dy16 = None
+        if ctx.x16 is not None:   # 16-bit training flow: `x` is the saved c8 conv input; dy is packed once for both gradients
+            x16 = Act16(x, *ctx.x16)
+            x_dtype, x_device = ctx.x_meta
+            dy16 = pack_act16(dy, x16.compute)
+        else:
+            x_dtype, x_device = x.dtype, x.device
         if need_w or (need_b and ctx.has_bias):
             dw = torch.empty_like(weight)
             db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
-            ws = _workspace(L.m355_conv3d_bwd_weight_workspace(C.byref(d)), x.device)
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(L.m355_conv3d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(),
-                                           _stream()), "conv3d_bwd_weight")
+            if x16 is not None:
+                ws = _workspace(L.m355_conv3d_bwd_weight_h16_workspace(C.byref(d)), x_device)
+                check(L.m355_conv3d_bwd_weight_h16(C.byref(d), x16.ptr(), x16.batch_stride(), dy16.ptr(), dy16.batch_stride(),
+                                                   _p(dy) if db is not None else None, _p(dw), _p(db), _p(ws), ws.numel(),
+                                                   _stream()), "conv3d_bwd_weight_h16")
+            else:
+                ws = _workspace(L.m355_conv3d_bwd_weight_workspace(C.byref(d)), x_device)
+                check(L.m355_conv3d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(),
+                                               _stream()), "conv3d_bwd_weight")
             if prof is not None:
                 e1.record()
                 vox = dy.shape[2] * dy.shape[3] * dy.shape[4]
@@ -424,16 +460,21 @@ class _Conv3dFn(torch.autograd.Function):
                              _conv_bytes(d.N, d.Cin, d.Cout, vox, d.k ** 3, 4, 4)))
         if need_x:
             # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part
-            dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
+            dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x_dtype, device=x_device)
             dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, d.y_batch_stride, compute=d.compute)
             wbuf, flags = _packed_weight(weight, dd, 1)
-            ws = _workspace(L.m355_conv3d_bwd_data_workspace(C.byref(dd)), x.device)
+            ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(dd), 1) if dy16 is not None
+                            else L.m355_conv3d_bwd_data_workspace(C.byref(dd)), x_device)
             dd = _with_flags(dd, flags)
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(L.m355_conv3d_bwd_data(C.byref(dd), _p(dy), _p(wbuf), _p(dx), _p(ws), ws.numel(),
-                                         _stream()), "conv3d_bwd_data")
+            if dy16 is not None:
+                check(L.m355_conv3d_bwd_data_h16(C.byref(dd), dy16.ptr(), dy16.batch_stride(), _p(wbuf), _p(dx), _p(ws),
+                                                 ws.numel(), _stream()), "conv3d_bwd_data_h16")
+            else:
+                check(L.m355_conv3d_bwd_data(C.byref(dd), _p(dy), _p(wbuf), _p(dx), _p(ws), ws.numel(),
+                                             _stream()), "conv3d_bwd_data")
             if prof is not None:
                 e1.record()
                 vox = dy.shape[2] * dy.shape[3] * dy.shape[4]

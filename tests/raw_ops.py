@@ -201,6 +201,18 @@ class RawOps:
                                                  self._stream()), "conv3d_bwd_data_h16")
         return dx
 
+    def conv3d_bwd_weight_h16(self, x16, dy16, dy, Cin, Cout, spatial, compute=1, with_bias=True):
+        """weight (and bias) gradient of the 3x3x3 conv from c8 operands"""
+        N = x16.shape[0]
+        d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 3, 1, 1, compute=compute)
+        dw, db = self.empty(Cout, Cin, 3, 3, 3), (self.empty(Cout) if with_bias else None)
+        n = self.lib.m355_conv3d_bwd_weight_h16_workspace(C.byref(d))
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("conv3d_bwd_weight_h16")(C.byref(d), _p(x16), 0, _p(dy16), 0, _p(self.to(dy)) if with_bias else None,
+                                                   _p(dw), _p(db), _p(ws), ws.numel(), self._stream()),
+                  "conv3d_bwd_weight_h16")
+        return dw, db
+
     def conv_transpose3d_fwd_h16(self, x16, Cin, spatial, w, bias, compute):
         """k2 s2 conv-transpose c8 -> c8; returns the c8 output [N, CBout, 8S, 8]"""
         w, bias = self.to(w), self.to(bias)

@@ -779,6 +779,26 @@ def test_conv3d_bwd_weight_bf16_mode(hip, oracle, case, compute):
     assert torch.equal(d1, d2)
 
 
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("env", [{}, {"M355_BWW_NSPLIT": "1"}, {"M355_BWW_NSPLIT": "5"}])
+def test_conv3d_bwd_weight_from_c8_operands(hip, oracle, compute, env, tuning):
+    """m355_conv3d_bwd_weight_h16: x and dy handed over as c8 (what the 16-bit training flow holds anyway), voxel-major
+    LDS tiles read through ds_read_b64_tr_b16.  == the oracle on the operands rounded to the 16-bit type (products
+    exact in fp32, fp32 accumulation); ragged volumes (W no multiple of 32, odd D / H), ragged channel counts (odd
+    number of c8 blocks, partial 32-channel tiles), N = 2, one split and several; bit-reproducible."""
+    tuning(**env)
+    for (N, ci, co, D, H, W) in [(1, 32, 32, 4, 8, 32), (1, 96, 32, 6, 8, 64), (2, 24, 40, 5, 7, 33), (1, 72, 8, 3, 9, 20),
+                                 (1, 16, 100, 4, 4, 16)]:
+        x, dy = rnd(N, ci, D, H, W, seed=1), rnd(N, co, D, H, W, seed=5)
+        x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
+        dw, db = hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (D, H, W), compute)
+        dwo, dbo = oracle.conv3d_bwd_weight(x, dy, 3, compute=compute)
+        tol = 3e-5 * (N * D * H * W) ** 0.5
+        close(dw, dwo, 3e-5, tol, f"bwd_weight from c8 {ci}->{co}")
+        close(db, dbo, 3e-5, tol, "dbias")
+        assert torch.equal(dw, hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (D, H, W), compute)[0])
+
+
 def test_conv3d_bwd_weight_bf16_mode_falls_back_to_exact_fp32(hip, oracle):
     """Geometries the bf16 kernel does not cover (W % 32 != 0, tiny channel counts) stay exact fp32."""
     for (N, Ci, Co, D, H, W) in [(1, 16, 16, 8, 8, 16), (1, 4, 32, 8, 8, 32)]:

@@ -59,6 +59,8 @@ def main():
                 ms = timeit(lambda: hip.conv3d_fwd(x, w, compute=compute))
             elif o == "bwd_data":
                 ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
+            elif compute and ci > 4 and co > 4 and "--f32in" not in sys.argv:   # c8 operands (the 16-bit training flow)
+                ms = timeit(lambda: hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (sp, sp, sp), compute, with_bias=False))
             else:
                 ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False, compute=compute))
             tot[o][0] += ms
