@@ -142,6 +142,9 @@ int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_
                         size_t workspace_bytes, void* stream);
 /* forward whose OUTPUT is c8 as well (written by the epilogue: lanes exchange channel halves and store whole
  * 16-byte items): the pre-norm tensor of conv -> norm/act -> conv never exists in fp32.  No fused `add`. */
+/* statistics slots of m355_conv3d_fwd_h16_c8 (differs from m355_conv3d_stats_slots for split-K plans, whose
+ * reduction pass emits the partials: one slot per block of that pass) */
+int64_t m355_conv3d_stats_slots_c8(const m355_conv3d_desc* d);
 int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const float* w,
                            const float* bias, void* y16, int64_t y16_batch_stride, float* stat_partials,
                            void* workspace, size_t workspace_bytes, void* stream);

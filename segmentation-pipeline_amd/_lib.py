@@ -60,6 +60,7 @@ SIGNATURES = {
     "m355_act16_unpack": (C.c_int, [_P, _P, _i32, _i32, _i64, _i64, _i64, _i32, _P]),
     "m355_conv3d_h16_workspace": (_sz, [_CD, _i32]),
     "m355_conv3d_fwd_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "m355_conv3d_stats_slots_c8": (_i64, [_CD]),
     "m355_conv3d_fwd_h16_c8": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _i64, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _P, _sz, _P]),
     "m355_conv3d_bwd_weight_h16_workspace": (_sz, [_CD]),

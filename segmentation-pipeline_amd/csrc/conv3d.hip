@@ -2012,7 +2012,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
                          bool out16 = false) {
   // prepacked: weights already packed for this plan by m355_conv3d_pack (M355_CONV_W_PACKED); `w` is then unused
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
-  M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG,
+  M355_REQUIRE(!stat || p.ksplit == 1 || (out16 && compute != M355_COMPUTE_F32), M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
   if (compute != M355_COMPUTE_F32) {
     if (!in16) {
@@ -2206,6 +2206,14 @@ static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
 }
 extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }
+// c8-output forward of the 16-bit modes: split-K plans emit the partials from their reduction pass
+static int64_t conv_stats_slots_c8(const m355_conv3d_desc* d) {
+  if (!is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
+  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
+  if (p.ksplit != 1) return splitk_c8_slots((int64_t)d->D * d->H * d->W);
+  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
+}
+extern "C" int64_t m355_conv3d_stats_slots_c8(const m355_conv3d_desc* d) { return d ? conv_stats_slots_c8(d) : 0; }
 
 static void launch_pack_smallcout(const m355_conv3d_desc* d, const float* w, float* wpz, hipStream_t st) {
   if (tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27)) {
@@ -2384,8 +2392,8 @@ extern "C" int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16
                                       float* stat_partials, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_h16(d, "conv3d_fwd_h16_c8")) return rc;
   M355_REQUIRE(x16 && w && y16 && workspace, M355_EINVALID_ARG, "conv3d_fwd_h16_c8: null pointer");
-  M355_REQUIRE(!stat_partials || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
-               "conv3d_fwd_h16_c8: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
+  M355_REQUIRE(!stat_partials || conv_stats_slots_c8(d) > 0, M355_EINVALID_ARG,
+               "conv3d_fwd_h16_c8: this descriptor has no fused statistics (m355_conv3d_stats_slots_c8() == 0)");
   const int64_t S = (int64_t)d->D * d->H * d->W;
   const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
   return run_mfma_conv(nullptr, packed ? nullptr : w, false, d->Cout, d->Cin, bias, nullptr, (float*)y16, d->N, d->Cin,

@@ -157,6 +157,9 @@ int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, in
                    int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
                    hipStream_t st);
 
+// blocks along the voxel axis of splitk_reduce_c8_kernel == statistics slots it emits per sample
+inline int64_t splitk_c8_slots(int64_t S) { return std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256), 2048)); }
+
 // weight gradient from c8 operands (tile 2 x 4 x 32 voxels); slab[split][27][Cout][Cin], summed by slab_reduce_t_kernel
 int launch_bww_c8(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
                   int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st);

@@ -195,20 +195,27 @@ __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT*
   }
 }
 
-// c8 output of a split-K plan: y16[n][cb][s] = bias + sum_ks slab[ks][n][o][s] (fixed order), rounded once
+// c8 output of a split-K plan: y16[n][cb][s] = bias + sum_ks slab[ks][n][o][s] (fixed order), rounded once.
+// `stat` (optional): the statistics partials of the normalisation that follows, as the conv epilogue of the
+// unsplit plans emits them -- (sum, sum of squares) of the fp32 values per channel, one slot per block:
+// stat[((n * gridDim.x + blockIdx.x) * Cout + c) * 2 + {0,1}].  Saves the separate pass over the c8 tensor.
 template <typename HT>
 __global__ __launch_bounds__(256) void splitk_reduce_c8_kernel(const float* __restrict__ slab,
                                                                const float* __restrict__ bias, HT* __restrict__ y16,
                                                                int Cout, int64_t S, int ksplit, int64_t slab_stride,
-                                                               int64_t ybs16) {
+                                                               int64_t ybs16, float* __restrict__ stat) {
   using hx8 = typename H16<HT>::x8;
+  __shared__ float red[4][16];
   const int cb = blockIdx.y, n = blockIdx.z;
   const int c0 = cb * 8, nc = min(8, Cout - c0);
   const float* sp = slab + ((int64_t)n * Cout + c0) * S;
   hx8* dst = reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs16) + (int64_t)cb * S;
-  float bv[8];
+  float bv[8], s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bv[j] = (bias && j < nc) ? bias[c0 + j] : 0.f;
+  for (int j = 0; j < 8; ++j) {
+    bv[j] = (bias && j < nc) ? bias[c0 + j] : 0.f;
+    s1[j] = s2[j] = 0.f;
+  }
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
     float v[8];
 #pragma unroll
@@ -220,8 +227,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_c8_kernel(const float* __re
     }
     hx8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (HT)(j < nc ? v[j] + bv[j] : 0.f);
+    for (int j = 0; j < 8; ++j) {
+      const float t = j < nc ? v[j] + bv[j] : 0.f;
+      o[j] = (HT)t;
+      s1[j] += t;
+      s2[j] = fmaf(t, t, s2[j]);
+    }
     dst[i] = o;
+  }
+  if (!stat) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = wave_sum(s1[j]);
+    s2[j] = wave_sum(s2[j]);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[w][j] = s1[j];
+      red[w][8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x & 7, k = threadIdx.x >> 3;
+    const float t = ((red[0][k * 8 + j] + red[1][k * 8 + j]) + red[2][k * 8 + j]) + red[3][k * 8 + j];
+    if (j < nc) stat[(((int64_t)n * gridDim.x + blockIdx.x) * Cout + c0 + j) * 2 + k] = t;
   }
 }
 
@@ -600,7 +632,8 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
                "conv3d(16-bit operands): workspace / c8 input not 16B aligned");
   M355_REQUIRE((int64_t)D * H * W * 32 < (1ll << 31) && (int64_t)mout * D * H * W < (1ll << 31), M355_EUNSUPPORTED,
                "conv3d(16-bit operands): volume exceeds the 32-bit offsets of a buffer descriptor");
-  M355_REQUIRE(!stat || p.ksplit == 1, M355_EINVALID_ARG, "conv3d(16-bit operands): no fused statistics for a split-K plan");
+  M355_REQUIRE(!stat || p.ksplit == 1 || out16, M355_EINVALID_ARG,
+               "conv3d(16-bit operands): fused statistics of a split-K plan exist only for the c8 output");
   M355_REQUIRE(!out16 || (!add && ((uintptr_t)out & 15) == 0 && out_bs % 8 == 0), M355_EINVALID_ARG,
                "conv3d(16-bit operands): a c8 output takes no fused `add` and must be 16B aligned");
   HT* wpb = prepacked ? (HT*)prepacked : (HT*)ws;
@@ -611,8 +644,8 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
   const float* ka = p.ksplit == 1 ? add : nullptr;
 #define M355_H16_CASE(NTW, GX)                                                                               \
   if (p.ntw == NTW && p.gx == GX) {                                                                          \
-    launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st, stat, \
-                            work_counter, out16);                                                            \
+    launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st,       \
+                            p.ksplit == 1 ? stat : nullptr, work_counter, out16);                                                          \
   } else
   M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
   M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
@@ -623,10 +656,9 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
 #undef M355_H16_CASE
   if (p.ksplit > 1 && out16) {
     const int64_t S = (int64_t)D * H * W;
-    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256), 2048)), (unsigned)c8_blocks(mout),
-              (unsigned)N);
+    dim3 grid((unsigned)splitk_c8_slots(S), (unsigned)c8_blocks(mout), (unsigned)N);
     hipLaunchKernelGGL(splitk_reduce_c8_kernel<HT>, grid, dim3(256), 0, st, slab, bias, (HT*)out, mout, S, p.ksplit,
-                       (int64_t)N * mout * S, out_bs);
+                       (int64_t)N * mout * S, out_bs, stat);
   } else if (p.ksplit > 1) {
     const int64_t S = (int64_t)D * H * W;
     const int64_t total = (int64_t)N * mout * S;

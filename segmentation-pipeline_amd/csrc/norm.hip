@@ -251,66 +251,68 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(
   }
 }
 
-// Backward finalize, stage 1: AB[(n*C + c)*2 + {0,1}] = sum over blocks (one wave per (n,c)).
-__global__ __launch_bounds__(64) void norm_bwd_collapse_kernel(const double* __restrict__ partial,
-                                                                double* __restrict__ ab, int nblk) {
-  const int64_t nc = blockIdx.x;
-  double a = 0.0, b = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += 64) {
-    a += partial[(nc * nblk + k) * 2];
-    b += partial[(nc * nblk + k) * 2 + 1];
-  }
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if (threadIdx.x == 0) {
-    ab[nc * 2] = a;
-    ab[nc * 2 + 1] = b;
-  }
-}
-
-// Stage 2: dgamma[c] = sum_n B; dbeta[c] = sum_n A; per-statistic means
-// m1 = mean(dxhat), m2 = mean(dxhat*xhat) -> stat_m[s*2+{0,1}]
-__global__ void norm_bwd_finalize_kernel(const double* __restrict__ ab,
-                                         const float* __restrict__ gamma,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                         float* __restrict__ stat_m, int N, int C, int groups,
-                                         int64_t count, int training) {
+// Both finalize stages in one launch (one wave per block index s; every sum in a fixed lane-strided order + the
+// fixed shuffle tree of wave_sum): for s < nstats the per-statistic means m1 = mean(dxhat), m2 = mean(dxhat * xhat)
+// straight from the per-block partials, for s < C the parameter gradients dgamma[c] = sum_n B, dbeta[c] = sum_n A.
+// These launches are latency-bound (~5 us each between two bandwidth-bound passes), so one instead of two is
+// 108 launches less per cfg2 train step.
+__global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __restrict__ partial,
+                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ stat_m, int N,
+                                                              int C, int groups, int nblk, int64_t count, int training) {
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
-  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const int lane = threadIdx.x;
   if (s < nstats) {
     double m1 = 0.0, m2 = 0.0;
-    if (groups == 0) {
-      const int c = (int)s;
-      const double g = gamma ? (double)gamma[c] : 1.0;
-      for (int n = 0; n < N; ++n) {
-        m1 += ab[((int64_t)n * C + c) * 2];
-        m2 += ab[((int64_t)n * C + c) * 2 + 1];
-      }
-      m1 *= g;
-      m2 *= g;
-    } else {
-      const int cpg = C / groups;
-      const int n = (int)(s / groups), gi = (int)(s % groups);
-      for (int cc = 0; cc < cpg; ++cc) {
-        const int c = gi * cpg + cc;
+    if (training) {
+      if (groups == 0) {
+        const int c = (int)s;
+        const int64_t items = (int64_t)N * nblk;
+        for (int64_t i = lane; i < items; i += 64) {
+          const int64_t n = i / nblk, k = i - n * nblk;
+          m1 += partial[((n * C + c) * nblk + k) * 2];
+          m2 += partial[((n * C + c) * nblk + k) * 2 + 1];
+        }
         const double g = gamma ? (double)gamma[c] : 1.0;
-        m1 += g * ab[((int64_t)n * C + c) * 2];
-        m2 += g * ab[((int64_t)n * C + c) * 2 + 1];
+        m1 *= g;
+        m2 *= g;
+      } else {
+        const int cpg = C / groups;
+        const int64_t n = s / groups;
+        const int c0 = (int)(s % groups) * cpg;
+        const int64_t items = (int64_t)cpg * nblk;
+        for (int64_t i = lane; i < items; i += 64) {
+          const int cc = (int)(i / nblk);
+          const int64_t k = i - (int64_t)cc * nblk;
+          const double g = gamma ? (double)gamma[c0 + cc] : 1.0;
+          m1 += g * partial[((n * C + c0 + cc) * nblk + k) * 2];
+          m2 += g * partial[((n * C + c0 + cc) * nblk + k) * 2 + 1];
+        }
       }
+      m1 = wave_sum(m1);
+      m2 = wave_sum(m2);
     }
-    if (!training) { m1 = 0.0; m2 = 0.0; }
-    stat_m[s * 2 + 0] = (float)(m1 / (double)count);
-    stat_m[s * 2 + 1] = (float)(m2 / (double)count);
+    if (lane == 0) {
+      stat_m[s * 2 + 0] = (float)(m1 / (double)count);
+      stat_m[s * 2 + 1] = (float)(m2 / (double)count);
+    }
   }
   if (s < C && (dgamma || dbeta)) {
     const int c = (int)s;
     double a = 0.0, bb = 0.0;
-    for (int n = 0; n < N; ++n) {
-      a += ab[((int64_t)n * C + c) * 2];
-      bb += ab[((int64_t)n * C + c) * 2 + 1];
+    const int64_t items = (int64_t)N * nblk;
+    for (int64_t i = lane; i < items; i += 64) {
+      const int64_t n = i / nblk, k = i - n * nblk;
+      a += partial[((n * C + c) * nblk + k) * 2];
+      bb += partial[((n * C + c) * nblk + k) * 2 + 1];
     }
-    if (dbeta) dbeta[c] = (float)a;
-    if (dgamma) dgamma[c] = (float)bb;
+    a = wave_sum(a);
+    bb = wave_sum(bb);
+    if (lane == 0) {
+      if (dbeta) dbeta[c] = (float)a;
+      if (dgamma) dgamma[c] = (float)bb;
+    }
   }
 }
 
@@ -493,8 +495,7 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
   const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
   double* partial = (double*)workspace;
-  double* ab = (double*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
-  float* stat_m = (float*)((char*)ab + round_up((int64_t)d->N * d->C * 2 * sizeof(double), 256));
+  float* stat_m = (float*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
   const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) &&
                    (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
   if (vec)
@@ -508,10 +509,8 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
                        dy, mean, rstd, gamma, beta, partial, d->C, d->S, d->groups, d->act,
                        d->act_slope, xbs, ybs, nblk_c);
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
-  hipLaunchKernelGGL(norm_bwd_collapse_kernel, dim3((unsigned)(d->N * d->C)), dim3(64), 0, st, partial, ab,
-                     nblk_c);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)ceil_div(nthreads, 64)), dim3(64), 0,
-                     st, ab, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, g.count, training);
+  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)nthreads), dim3(64), 0, st, partial, gamma, dgamma, dbeta,
+                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training);
   const int64_t work = vec ? d->S / 4 : d->S;
   const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
   dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);

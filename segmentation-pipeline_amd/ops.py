@@ -285,7 +285,9 @@ def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     part = None
-    slots = L.m355_conv3d_stats_slots(C.byref(d)) if stats is not None else 0
+    slots = 0
+    if stats is not None:
+        slots = L.m355_conv3d_stats_slots_c8(C.byref(d)) if c8_out else L.m355_conv3d_stats_slots(C.byref(d))
     if slots > 0:
         part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x16.device)
         stats["partials"], stats["slots"] = part, slots

@@ -166,7 +166,7 @@ class RawOps:
         ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
         part = None
         if with_stats:
-            slots = self.fn("conv3d_stats_slots")(C.byref(d))
+            slots = self.fn("conv3d_stats_slots_c8")(C.byref(d))
             assert slots > 0
             part = self.empty(N, slots, Cout, 2)
         self._chk(self.fn("conv3d_fwd_h16_c8")(C.byref(d), _p(x16), CBp * S * 8, _p(w), _p(bias), _p(y16), 0, _p(part),

@@ -591,8 +591,9 @@ def test_norm_act_and_avgpool_c8_outputs(hip, oracle, compute):
                                  {"M355_CONV_KSPLIT": "1", "M355_CONV_NTW": "1"}])
 def test_conv3d_h16_c8_output_and_c8_norm(hip, oracle, compute, env, tuning):
     """m355_conv3d_fwd_h16_c8: the epilogue writes c8 (lanes exchange channel halves with v_permlane32_swap) ==
-    the fp32-output kernel's result rounded once; statistics fused (fp32, before rounding) or taken from the c8
-    tensor (m355_act16_channel_partials, split-K plans); m355_norm_act_fwd_c8 (c8 -> c8, residual in c8)."""
+    the fp32-output kernel's result rounded once; statistics fused (fp32, before rounding: conv epilogue, or the
+    reduction pass of a split-K plan) and taken from the c8 tensor (m355_act16_channel_partials);
+    m355_norm_act_fwd_c8 (c8 -> c8, residual in c8)."""
     tuning(**env)
     dt = torch.bfloat16 if compute == 1 else torch.float16
     ulp = 2.0 ** -8 if compute == 1 else 2.0 ** -11
@@ -600,22 +601,19 @@ def test_conv3d_h16_c8_output_and_c8_norm(hip, oracle, compute, env, tuning):
         x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
         x16 = hip.act16_pack(x, compute)
         y32 = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute).cpu()
-        fused = env["M355_CONV_KSPLIT"] == "1"
-        if fused:
-            y16, part = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
-        else:
-            y16 = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute)
-            part = hip.act16_channel_partials(y16, co, compute)
+        # statistics partials: from the conv epilogue (unsplit plans) or from the split-K reduction pass -- of the fp32
+        # values either way; and m355_act16_channel_partials over the finished c8 tensor (the rounded values)
+        y16, part = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
+        assert torch.equal(y16, hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute)), "same output without stats"
         got = _c8_to_ncdhw(y16, co, (D, H, W))
         assert torch.equal(got, y32.to(dt).float()), "c8 output == the fp32 output rounded once"
         if co % 8:
             assert (y16[:, -1, :, co % 8:].float() == 0).all()
-        # per-channel sums from the partials: of the fp32 values when fused, of the rounded values otherwise
-        src = y32 if fused else got
-        s1 = part[..., 0].sum(dim=1).cpu().double()
-        s2 = part[..., 1].sum(dim=1).cpu().double()
-        torch.testing.assert_close(s1, src.double().sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
-        torch.testing.assert_close(s2, (src.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
+        for pp, src in ((part, y32), (hip.act16_channel_partials(y16, co, compute), got)):
+            s1 = pp[..., 0].sum(dim=1).cpu().double()
+            s2 = pp[..., 1].sum(dim=1).cpu().double()
+            torch.testing.assert_close(s1, src.double().sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
+            torch.testing.assert_close(s2, (src.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
         # c8 -> c8 normalise + activation + residual
         gamma, beta = rnd(co, seed=4) * 0.5 + 1.0, rnd(co, seed=5) * 0.1
         mean, rstd = oracle.norm_stats(got, groups)[:2]
