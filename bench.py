@@ -12,6 +12,7 @@ synthetic 1x4x128^3 patch per rank, with the 5-level GroupNorm/ConvTranspose U-N
 reported under "infer".  One JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -97,28 +98,52 @@ def cpu_model():
     return "unknown"
 
 
+def kernel_groups(prof, precision):
+    """ops.CONV_PROFILE entries grouped by (kernel name, tile variant) -> [flops, bytes, ms, launches, {(tag, plan)}]"""
+    groups = {}
+    for (tag, flops, e0, e1, plan, nbytes) in prof:
+        if tag == "conv3d_bwd_weight":
+            key = ("conv3_mfma_bww2_kernel" if precision == "fp32" else "conv3_bww_c8_kernel", "")
+        elif plan is None:
+            continue
+        else:
+            key = (PLAN_KERNEL.get(plan[0], "conv3d"), f"<{plan[1]},{plan[2]}>" + (f" split-K {plan[3]}" if plan[3] > 1 else ""))
+        g = groups.setdefault(key, [0.0, 0.0, 0.0, 0, set()])
+        g[0] += flops
+        g[1] += nbytes
+        g[2] += e0.elapsed_time(e1)
+        g[3] += 1
+        g[4].add((tag, plan))
+    return groups
+
+
+def dominant_keys(prof, precision):
+    """(tag, plan) pairs of the launches of the kernel that accumulates the most time"""
+    groups = kernel_groups(prof, precision)
+    return groups[max(groups, key=lambda k: groups[k][2])][4] if groups else None
+
+
+def conv_summary_of(prof, steps):
+    by_tag = {}
+    for tag, f, e0, e1, plan, _nb in prof:
+        a = by_tag.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += f
+        a[1] += e0.elapsed_time(e1)
+        a[2] += 1
+    return {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1] / steps, "launches_per_step": v[2] / steps}
+            for k, v in by_tag.items()}
+
+
 def roofline_of(prof, precision):
     """Roofline object of the dominant conv kernel of a timed region.  prof: ops.CONV_PROFILE entries
     (tag, flops, e0, e1, plan, bytes).  Kernels are grouped by (kernel name, tile variant); the group with
     the most accumulated time is the dominant kernel.  bound = whichever of algorithmic-bytes / 8 TB/s and
     flops / dense-MFMA-peak is larger over the group's launches; achieved / peak are reported in that unit."""
-    groups = {}
-    for (tag, flops, e0, e1, plan, nbytes) in prof:
-        if tag == "conv3d_bwd_weight":
-            key = ("conv3_mfma_bww2_kernel" if precision == "fp32" else "conv3_mfma_bww_h16_kernel", "")
-        elif plan is None:
-            continue
-        else:
-            key = (PLAN_KERNEL.get(plan[0], "conv3d"), f"<{plan[1]},{plan[2]}>" + (f" split-K {plan[3]}" if plan[3] > 1 else ""))
-        g = groups.setdefault(key, [0.0, 0.0, 0.0, 0])
-        g[0] += flops
-        g[1] += nbytes
-        g[2] += e0.elapsed_time(e1)
-        g[3] += 1
+    groups = kernel_groups(prof, precision)
     if not groups:
         return None
     key = max(groups, key=lambda k: groups[k][2])
-    flops, nbytes, ms, n = groups[key]
+    flops, nbytes, ms, n = groups[key][:4]
     peak_tf = PEAK_TFLOPS[precision]
     t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
     kname = key[0] + key[1]
@@ -234,8 +259,25 @@ def main():
     gpu_dice0 = float(crit(p0, y)["dice_loss"])
     hard0 = hard_dice_from_counts(counts)[0].tolist()
 
-    for _ in range(args.warmup):
+    # The last warm-up step is event-timed launch by launch (per-op summary + which kernel dominates); inside the
+    # timed region only the dominant kernel's launches carry timing events (the roofline measurement), so the
+    # timed steps are not perturbed by ~110 events each.
+    prof_w = None
+    for i in range(args.warmup):
+        if i == args.warmup - 1 and rank == 0:
+            ops.CONV_PROFILE = []
         train_step(runner, crit, opt, predictor, batch, device)
+    if ops.CONV_PROFILE is not None:
+        torch.cuda.synchronize()
+        prof_w, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        ops.CONV_PROFILE_KEYS = dominant_keys(prof_w, args.precision)
+    # A full (generation-2) collection of CPython's cyclic GC walks every object alive -- ~90 ms with torch
+    # imported -- and lands at an arbitrary step (measured with tools/step_trace.py: one such host stall drains
+    # the launch queue and idles the GPU for ~8 ms; on a 12 ms step that is +2..4 ms/step of noise in a 10-20 step
+    # window).  Everything allocated so far is long-lived: move it out of the collector's reach, as any
+    # long-running service does; the young generations still collect the per-step garbage.
+    gc.collect()
+    gc.freeze()
     # ---- timed region: exactly K train steps ----
     ops.CONV_PROFILE = [] if rank == 0 else None
     barrier()
@@ -262,8 +304,14 @@ def main():
     if not args.no_infer:
         model.eval()
         with torch.no_grad():
-            for _ in range(max(1, args.warmup)):
+            ops.CONV_PROFILE_KEYS = None
+            for i in range(max(1, args.warmup)):
+                if i == max(1, args.warmup) - 1 and rank == 0:
+                    ops.CONV_PROFILE = []
                 model(x)
+            if ops.CONV_PROFILE is not None:
+                torch.cuda.synchronize()
+                ops.CONV_PROFILE_KEYS = dominant_keys(ops.CONV_PROFILE, args.precision)
             ops.CONV_PROFILE = [] if rank == 0 else None
             barrier()
             t0 = time.perf_counter()
@@ -283,14 +331,8 @@ def main():
         roofline = roofline_of(prof, args.precision)
         if infer is not None and prof_inf:
             infer["roofline"] = roofline_of(prof_inf, args.precision)
-        by_tag = {}
-        for tag, f, e0, e1, plan, _nb in prof:
-            a = by_tag.setdefault(tag, [0.0, 0.0, 0])
-            a[0] += f
-            a[1] += e0.elapsed_time(e1)
-            a[2] += 1
-        conv_summary = {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1] / args.steps, "launches_per_step": v[2] / args.steps}
-                        for k, v in by_tag.items()}
+        # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
+        conv_summary = conv_summary_of(prof_w, 1) if prof_w else conv_summary_of(prof, args.steps)
 
         out = {
             "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
