@@ -32,7 +32,7 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
 HBM_PEAK_GBS = 8000.0
 # m355_conv3d_plan(): kernel family -> kernel name
 PLAN_KERNEL = {1: "conv3_mfma_fwd_kernel", 3: "conv3_mfma_fwd_p_kernel", 2: "conv3_valu_smallcout_kernel",
-               4: "conv3_h16_kernel", 0: "conv3d_direct_kernel"}
+               4: "conv3_h16_kernel", 5: "conv3_h16_kernel(8 waves)", 0: "conv3d_direct_kernel"}
 WORKLOADS = {
     # name: (in_ch, out_ch, filters, depth, patch)
     "cfg2": (4, 3, [32, 64, 128, 256, 320], 5, (128, 128, 128)),

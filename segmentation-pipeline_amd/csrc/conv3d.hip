@@ -1852,6 +1852,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   if (p.tile16) p.otiles -= 1;
   const int wtiles = p.otiles + p.tile16;   // workgroup items per spatial tile
   p.nchunks = p.kin_pad / cc;
+  p.nw = 4;
   p.tz_tiles = (int)ceil_div(D, 4);
   p.tx_tiles = (int)ceil_div(W, p.gx);
   // Pick (voxel-tile height NTW, split-K) by a cost model instead of "fill the chip once":
@@ -1914,6 +1915,21 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
       }
     }
   }
+  if (h16 && p.gx == 32 && tuning().h16_w8 && D >= 8 && H >= 2) {
+    // 8-wave double-buffered variant (tile 8 x 2 x 32, one workgroup per CU) for SHORT items (<= 4 chunks = 64
+    // input channels) whose tiles fill the chip without split-K: there the single-buffered kernel spends as long
+    // on chunk boundaries and item switches as on MFMAs (32->32 @128^3: 0.194 -> 0.167 ms, 32->64 @64^3: 0.088 ->
+    // 0.058).  Long items stay on the 4-wave kernel: its 4-row wave tile needs 0.75 LDS fragment reads per MFMA,
+    // the 2-row tile of this variant 1.17, and at 6+ chunks that LDS traffic costs more than the boundaries
+    // (96->32 @128^3: 0.33 vs 0.41 ms).
+    const int64_t items8 = (int64_t)ceil_div(D, 8) * ceil_div(H, 2) * p.tx_tiles * p.otiles * N;
+    if (((items8 >= 2 * (int64_t)cus && p.nchunks <= 4) || tuning().h16_w8 == 2) && (!force_ntw || force_ntw == 2)) {   // 2: always (tests)
+      p.nw = 8;
+      p.tz_tiles = (int)ceil_div(D, 8);
+      chosen = 2;
+      chosen_ks = 1;
+    }
+  }
   if (force_ks) {
     chosen_ks = std::min(force_ks, p.nchunks);
     while (chosen_ks > 1 && (chosen_ks - 1) * (int)ceil_div(p.nchunks, chosen_ks) >= p.nchunks)
@@ -1925,7 +1941,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   const int ksplit = chosen_ks;
   {
     // resident workgroups (LDS + registers: 2 per CU up to NTW = 4); the override exists for the tests
-    const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (p.ntw <= 4 ? 2 : 1) * num_cus());
+    const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (p.nw == 8 ? 1 : (p.ntw <= 4 ? 2 : 1)) * num_cus());
     const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
                    tuning().conv_persistent;
@@ -2203,7 +2219,7 @@ static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || small_cout_fwd(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return 0;
-  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
+  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }
 // c8-output forward of the 16-bit modes: split-K plans emit the partials from their reduction pass
@@ -2211,7 +2227,7 @@ static int64_t conv_stats_slots_c8(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return splitk_c8_slots((int64_t)d->D * d->H * d->W);
-  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * 4;
+  return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots_c8(const m355_conv3d_desc* d) { return d ? conv_stats_slots_c8(d) : 0; }
 
@@ -2491,7 +2507,7 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  out4[0] = d->compute != M355_COMPUTE_F32 ? 4 : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  out4[0] = d->compute != M355_COMPUTE_F32 ? (p.nw == 8 ? 5 : 4) : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 

@@ -266,8 +266,14 @@ __device__ unsigned long long m355_h16_stamps[1024][8];
 #define STAMP(var)
 #endif
 // OUT16: the output tile is written as c8 items into y16 (ybs in ELEMENTS of it); otherwise fp32 NCDHW into y.
-template <int NTW, int GX, typename HT, bool OUT16>
-__global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
+// NW: waves per workgroup = z slices of the tile.  NW = 4: one LDS buffer (commit between two barriers), two
+// workgroups per CU cover each other's commits.  NW = 8: ONE workgroup of 8 waves per CU (two waves per SIMD)
+// with the tile 8 x NTW rows x 32 and DOUBLE-buffered LDS (2 x (x tile + weights) = 142 KB at NTW = 2): the next
+// chunk is written into the other buffer as soon as its loads have landed, while the other waves keep issuing
+// MFMAs, and a chunk costs one barrier -- the structure of the fp32 kernel (conv3d.hip), which the 16-bit
+// chunks (16x shorter in MFMA time) need even more.
+template <int NTW, int GX, typename HT, bool OUT16, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void conv3_h16_kernel(
     const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
     int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int nchunks, int ksplit, int nbatch,
@@ -275,15 +281,17 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     int stagger) {
   using T = FwdTile<NTW, GX>;
   using hx8 = typename H16<HT>::x8;
-  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = T::CS;
+  constexpr int GY = T::GY, TZ = NW, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = (TZ + 2) * PS;
+  constexpr int NT = NW * 64;                    // threads
+  constexpr bool DB = NW == 8;                   // double-buffered LDS
   constexpr bool REUSE = GX == 32;               // row-fragment reuse across (output row, tap row), see the header
   constexpr int XI = 2 * HV;                     // (half, halo voxel) items of 16 bytes
-  constexpr int XPER = (XI + 255) / 256;
+  constexpr int XPER = (XI + NT - 1) / NT;
   constexpr int WI = 27 * 2 * 32;                // (tap, half, o) items of 16 bytes
-  constexpr int WPER = (WI + 255) / 256;
+  constexpr int WPER = (WI + NT - 1) / NT;
   constexpr int NSTEP = REUSE ? 9 : 27;          // MFMA steps per chunk: (dx, dz) pairs, or single taps
-  __shared__ __attribute__((aligned(16))) hx8 xs[XI];
-  __shared__ __attribute__((aligned(16))) hx8 ws[WI];
+  __shared__ __attribute__((aligned(16))) hx8 xs[DB ? 2 : 1][XI];
+  __shared__ __attribute__((aligned(16))) hx8 ws[DB ? 2 : 1][WI];
   __shared__ int next_item_s;
 
   const int tid = threadIdx.x;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
   auto compute_goff = [&](const Item& q) {
 #pragma unroll
     for (int i = 0; i < XPER; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + NT * i;
       const int h = e / HV, r = e - h * HV;
       const int zz = r / PS, r2 = r - zz * PS;
       const int yy = r2 / RS, xx = r2 - yy * RS;
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, goff[k], 0, 0));
   };
   auto fetch_w = [&](int k) {
-    const int idx = tid + 256 * k;
+    const int idx = tid + NT * k;
     const int idc = idx < WI ? idx : WI - 1;  // clamp: keeps the array fully scalarised
     wr[k] = wsrc[(int64_t)(idc >> 5) * cout_pad + (idc & 31)];
   };
@@ -370,13 +378,13 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
     for (int k = 0; k < WPER; ++k)
       if (ESTEPS + k / WPS == s) fetch_w(k);
   };
-  auto commit = [&]() {
+  auto commit = [&](int b) {
 #pragma unroll
     for (int i = 0; i < XPER; ++i)
-      if (tid + 256 * i < XI) reinterpret_cast<f32x4*>(xs)[tid + 256 * i] = xr[i];
+      if (tid + NT * i < XI) reinterpret_cast<f32x4*>(xs[b])[tid + NT * i] = xr[i];
 #pragma unroll
     for (int j = 0; j < WPER; ++j)
-      if (tid + 256 * j < WI) reinterpret_cast<f32x4*>(ws)[tid + 256 * j] = wr[j];
+      if (tid + NT * j < WI) reinterpret_cast<f32x4*>(ws[b])[tid + NT * j] = wr[j];
   };
 
   // ---- work queue (see conv3_mfma_fwd_p_kernel in conv3d.hip): eight contiguous item regions, one per XCD
@@ -421,17 +429,18 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
   chunk_setup(cur, cur.ch_begin, true);
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) fetch_step(s);
-  commit();
+  commit(0);
   __syncthreads();
+  int buf = 0;
 
-  const hx8* xb = xs + half * HV + wave * PS + ly * RS + lx;
-  const hx8* wb = ws + half * 32 + l32;
+  const int xoff = half * HV + wave * PS + ly * RS + lx;
+  const int woff = half * 32 + l32;
 
   // Two workgroups share a CU (one wave of each per SIMD) and start together with identical work: left alone they
   // run in lockstep -- both in their MFMA phase (sharing the matrix pipe), then both at the barriers / LDS commit
   // with the pipe idle (SQ counters: pipe busy 54 %, and a wave's non-MFMA time never overlapped its partner's
   // MFMAs).  The workgroup in the odd hardware wave slot starts half a chunk late; equal periods keep the offset.
-  if (stagger > 0) {
+  if (!DB && stagger > 0) {
     const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.WAVE_ID
     if (wave_slot & 1u) {
       for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);               // 16 x 64 cycles each
@@ -467,6 +476,8 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
         chunk_setup(nxt, nxt.ch_begin, live);
       }
       STAMP(t0);
+      const hx8* xb = xs[buf] + xoff;
+      const hx8* wb = ws[buf] + woff;
       if constexpr (REUSE) {
         // step s = (dx, dz): rows j = 0 .. NTW+1 of plane wave + dz at column offset dx; MFMA (g, dy) uses
         // row g + dy and the weights of tap (dz, dy, dx).  MFMAs run row by row, so a row fragment dies early;
@@ -536,9 +547,22 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
       }
       if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
       STAMP(t1);
+      if constexpr (DB) {
+        STAMP(t2);
+        commit(buf ^ 1);   // the other buffer: last read a chunk ago, and every wave has passed that chunk's barrier
+        STAMP(t3);
+        __syncthreads();
+        buf ^= 1;
+#ifdef M355_H16_STAMPS
+        {
+          STAMP(t4);
+          ph_mfma += t1 - t0; ph_b1 += t2 - t1; ph_commit += t3 - t2; ph_b2 += t4 - t3; ph_n += 1;
+        }
+#endif
+      } else {
       __syncthreads();  // every wave has read its last fragment of this chunk
       STAMP(t2);
-      commit();
+      commit(0);
       STAMP(t3);
       __syncthreads();
 #ifdef M355_H16_STAMPS
@@ -547,6 +571,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
         ph_mfma += t1 - t0; ph_b1 += t2 - t1; ph_commit += t3 - t2; ph_b2 += t4 - t3; ph_n += 1;
       }
 #endif
+      }
     }
     STAMP(te0);
 
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_h16_kernel(
       const int xg = cur.x0 + lx;
       const bool lane_ok = z < D && xg < W;
       if (ksplit == 1) {
-        float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * 4 + wave) * Cout * 2 : nullptr;
+        float* st = stat ? stat + (((int64_t)cur.n * sp_tiles + cur.sp) * NW + wave) * Cout * 2 : nullptr;
         if constexpr (OUT16)
           store_conv_tile_c8<NTW, GY, HT>(acc, reinterpret_cast<HT*>(y) + (int64_t)cur.n * ybs, bias, cur.o0, Cout, z,
                                           cur.y0, xg, ly, half, H, W, (int64_t)S, lane_ok, st);
@@ -591,9 +616,22 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
                        int64_t ybs, hipStream_t st, float* stat, int* work_counter, bool out16) {
   const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
-  const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus();
+  const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (p.nw == 8 ? 1 : (NTW <= 4 ? 2 : 1)) * num_cus();
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, slots));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  if constexpr (NTW == 2 && GX == 32) {
+    if (p.nw == 8) {  // 8-wave double-buffered variant
+      if (out16 && p.ksplit == 1)
+        hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
+                           slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0);
+      else
+        hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
+                           slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0);
+      return;
+    }
+  }
   if (out16 && p.ksplit == 1)
     hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
                        (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,

@@ -128,6 +128,13 @@ class RawOps:
         self._chk(self.fn("act16_unpack")(_p(x16), _p(x), N, Cc, S, CBp * S * 8, 0, compute, self._stream()), "act16_unpack")
         return x
 
+    def conv_plan(self, x_shape, Cout, compute=0, which=0):
+        """(kernel family, NTW, GX, split-K) of the 3x3x3 kernel the library picks (m355_conv3d_plan)"""
+        d = self.conv_desc(x_shape, Cout, 3, 1, 1, compute=compute)
+        out = (C.c_int32 * 4)()
+        self._chk(self.lib.m355_conv3d_plan(C.byref(d), which, out), "conv3d_plan")
+        return tuple(out)
+
     def conv3d_fwd_h16(self, x16, Cin, spatial, w, bias=None, add=None, compute=1, groups=None, eps=1e-5):
         """forward on a c8 input; groups != None also returns the fused statistics (mean, rstd)"""
         w, bias, add = map(self.to, (w, bias, add))

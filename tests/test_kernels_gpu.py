@@ -553,6 +553,43 @@ def test_conv3d_h16_c8_input_persistent_and_fused_statistics(hip, oracle, comput
     assert torch.equal(a, hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute))
 
 
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "3"}, {"M355_CONV_KSPLIT": "2", "M355_CONV_SLOTS": "5"}])
+def test_conv3d_h16_eight_wave_double_buffered_variant(hip, oracle, compute, env, tuning):
+    """The 8-wave variant of the 16-bit conv kernel (tile 8 x 2 x 32, one workgroup per CU, double-buffered LDS, one
+    barrier per chunk) forced on small volumes (M355_H16_W8=2): forward with bias + residual, fused statistics,
+    c8 output, data gradient; ragged D / H / W, odd channel-block counts, N = 2, tiny residency (every workgroup
+    walks many items), split-K; == the oracle on rounded operands and == the 4-wave kernel bit for bit."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    for (N, ci, co, D, H, W, groups) in [(1, 32, 32, 8, 6, 32, 8), (2, 24, 40, 9, 5, 64, 8), (1, 96, 32, 17, 4, 62, 0),
+                                        (1, 8, 13, 8, 2, 32, None)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
+        dy = rnd(N, co, D, H, W, seed=5)
+        x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
+        out = {}
+        for w8 in (2, 0):
+            tuning(**{"M355_H16_W8": w8, "M355_CONV_KSPLIT": 1, **env})  # (the planner would split K on these volumes)
+            fused = groups is not None and "M355_CONV_KSPLIT" not in env
+            if fused:
+                y, mean, rstd = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute, groups=groups)
+            else:
+                y, mean, rstd = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute), None, None
+            y16 = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute)
+            dx = hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute)
+            out[w8] = (y, y16, dx)
+            if w8 == 2:
+                assert hip.conv_plan((N, ci, D, H, W), co, compute)[0] == 5, "the 8-wave variant was not selected"
+                close(y, oracle.conv3d_fwd(x, w, b, compute=compute), 3e-5, 3e-5, "8-wave fwd")
+                close(dx, oracle.conv3d_bwd_data(dy, w, x.shape, compute=compute), 3e-5, 3e-5, "8-wave bwd_data")
+                assert torch.equal(_c8_to_ncdhw(y16, co, (D, H, W)), y.cpu().to(dt).float())
+                if fused:
+                    m2, r2 = hip.norm_stats(y, groups)[:2]
+                    close(mean, m2, 1e-5, 1e-6, "fused mean")
+                    close(rstd, r2, 1e-5, 1e-6, "fused rstd")
+        for a, bb, what in zip(out[2], out[0], ("fwd", "c8 out", "bwd_data")):
+            assert torch.equal(a, bb), f"8-wave {what} != 4-wave {what} (same k order: must be bit-identical)"
+
+
 def _c8_to_ncdhw(x16, Cc, spatial):
     N, CB, S, _ = x16.shape
     return x16.float().cpu().permute(0, 1, 3, 2).reshape(N, CB * 8, S)[:, :Cc].reshape(N, Cc, *spatial)
