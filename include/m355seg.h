@@ -260,6 +260,13 @@ int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
                       const float* mean, const float* rstd, const float* gamma,
                       const float* beta, float* dx, float* dgamma, float* dbeta,
                       int training, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with dx ALSO written as a c8 tensor (h16 layout above) by the second pass: in the 16-bit training flow dx
+ * is the output gradient of the convolution in front of the normalisation, and that convolution's data- and
+ * weight-gradient kernels read it as c8 (m355_conv3d_bwd_data_h16 / m355_conv3d_bwd_weight_h16). */
+int m355_norm_act_bwd_h16(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, float* dx, float* dgamma,
+                          float* dbeta, int training, void* dx16, int64_t dx16_batch_stride, int32_t compute,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* The passes that WRITE c8 tensors in the 16-bit modes (so that conv -> norm/act -> conv never converts):
  * m355_norm_act_fwd with a c8 output y16 (the layout transposer: reads the fp32 NCDHW conv output) and,

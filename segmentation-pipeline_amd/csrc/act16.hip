@@ -89,6 +89,92 @@ __global__ __launch_bounds__(256) void norm_act_fwd_c8_kernel(
   }
 }
 
+// Backward twin of the pass above (16-bit TRAINING flow): the second pass of the normalisation backward
+// (norm_bwd_apply_kernel in norm.hip: dx = rstd * (g * gamma - m1 - xhat * m2), g = dy * act'(pre)) over 8 channel
+// planes per thread, writing dx as fp32 NCDHW (same expressions, bit-identical to the fp32 pass) AND as c8 items --
+// dx is the output gradient of the convolution in front of the norm, whose data- and weight-gradient kernels read
+// it as c8; emitting the twin here replaces a separate conversion pass (read 4 + write 2 bytes per element) by
+// 2 bytes per element written.
+__device__ __forceinline__ float act16_grad(float pre, int act, float slope) {
+  if (act == M355_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+  if (act == M355_ACT_LEAKY_RELU) return pre > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+template <typename HT>
+__global__ __launch_bounds__(256) void norm_bwd_apply_c8_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stat_m, float* __restrict__ dx, HT* __restrict__ dx16, int C, int64_t S, int groups,
+    int act, float slope, int64_t xbs, int64_t ybs, int64_t dx16bs) {
+  using hx8 = typename H16<HT>::x8;
+  const int cb = blockIdx.y, n = blockIdx.z;
+  const int c0 = cb * 8, nc = min(8, C - c0);
+  float m[8], r[8], g[8], sc[8], sh[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(c0 + j, C - 1);
+    const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+    m[j] = mean[s];
+    r[j] = rstd[s];
+    g[j] = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    sc[j] = r[j] * g[j];
+    sh[j] = bt - m[j] * sc[j];  // same expressions as norm_bwd_apply_kernel
+    m1[j] = stat_m[s * 2];
+    m2[j] = stat_m[s * 2 + 1];
+  }
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c0 * S;
+  const float* dp = dy + (int64_t)n * ybs + (int64_t)c0 * S;
+  float* op = dx + (int64_t)n * xbs + (int64_t)c0 * S;
+  hx8* dst = reinterpret_cast<hx8*>(dx16 + (int64_t)n * dx16bs) + (int64_t)cb * S;
+  constexpr int U = 2;
+  const int64_t stride = gridDim.x * 256ll;
+  for (int64_t i0 = blockIdx.x * 256ll + threadIdx.x; i0 < S; i0 += stride * U) {
+    float xv[U][8], dv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = min(i0 + u * stride, S - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[u][j] = j < nc ? xp[(int64_t)j * S + i] : 0.f;
+        dv[u][j] = j < nc ? dp[(int64_t)j * S + i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= S) break;
+      hx8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (xv[u][j] - m[j]) * r[j];
+        const float pre = fmaf(xv[u][j], sc[j], sh[j]);
+        const float gg = dv[u][j] * act16_grad(pre, act, slope) * g[j];
+        const float v = r[j] * (gg - m1[j] - xh * m2[j]);
+        o[j] = (HT)(j < nc ? v : 0.f);
+        if (j < nc) op[(int64_t)j * S + i] = v;
+      }
+      dst[i] = o;
+    }
+  }
+}
+
+int launch_norm_bwd_apply_c8(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, const float* stat_m, float* dx, void* dx16, int N, int C, int64_t S,
+                             int groups, int act, float slope, int64_t xbs, int64_t ybs, int64_t dx16bs, int compute,
+                             hipStream_t st) {
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256 * 2), 1024));
+  dim3 grid(bx, (unsigned)c8_blocks(C), (unsigned)N);
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(norm_bwd_apply_c8_kernel<__bf16>, grid, dim3(256), 0, st, x, dy, mean, rstd, gamma, beta, stat_m, dx,
+                       (__bf16*)dx16, C, S, groups, act, slope, xbs, ybs, dx16bs);
+  else
+    hipLaunchKernelGGL(norm_bwd_apply_c8_kernel<_Float16>, grid, dim3(256), 0, st, x, dy, mean, rstd, gamma, beta, stat_m,
+                       dx, (_Float16*)dx16, C, S, groups, act, slope, xbs, ybs, dx16bs);
+  return check_launch("norm_bwd_apply_c8");
+}
+
 // c8 -> c8 average pool: one thread per output voxel and channel block; the 2x2x2 window is four 32-byte
 // runs (two x-adjacent items each).  Sums in fp32 in torch's (z, y, x) order, one rounding at the end.
 template <typename HT>

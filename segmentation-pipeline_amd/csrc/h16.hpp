@@ -42,4 +42,10 @@ int launch_pack_act16(const float* x, void* x16, int N, int C, int64_t S, int64_
 int launch_unpack_act16(const void* x16, float* x, int N, int C, int64_t S, int64_t x16bs, int64_t xbs, int compute,
                         hipStream_t st);
 
+// second pass of the normalisation backward that also emits dx as c8 (act16.hip; used by m355_norm_act_bwd_h16)
+int launch_norm_bwd_apply_c8(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, const float* stat_m, float* dx, void* dx16, int N, int C, int64_t S,
+                             int groups, int act, float slope, int64_t xbs, int64_t ybs, int64_t dx16bs, int compute,
+                             hipStream_t st);
+
 }  // namespace m355

@@ -12,6 +12,7 @@
 // the partials in fixed order.  Pass 2 (apply): float4 streaming, one (n,c)
 // channel chunk per block so gamma/beta/mean/rstd are block-uniform.
 #include "common.hpp"
+#include "h16.hpp"
 
 namespace m355 {
 
@@ -479,11 +480,10 @@ extern "C" int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const 
   return check_launch("norm_act_fwd");
 }
 
-extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
-                                 const float* mean, const float* rstd, const float* gamma,
-                                 const float* beta, float* dx, float* dgamma, float* dbeta,
-                                 int training, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, float* dx, float* dgamma,
+                             float* dbeta, int training, void* workspace, size_t workspace_bytes, void* stream,
+                             void* dx16, int64_t dx16_batch_stride, int compute) {
   if (int rc = validate_norm(d, "norm_act_bwd")) return rc;
   M355_REQUIRE(x && dy && mean && rstd && dx && workspace, M355_EINVALID_ARG,
                "norm_act_bwd: null pointer");
@@ -511,6 +511,10 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)nthreads), dim3(64), 0, st, partial, gamma, dgamma, dbeta,
                      stat_m, d->N, d->C, d->groups, nblk_c, g.count, training);
+  if (dx16)   // 16-bit training flow: dx as fp32 and as c8 in one pass
+    return launch_norm_bwd_apply_c8(x, dy, mean, rstd, gamma, beta, stat_m, dx, dx16, d->N, d->C, d->S, d->groups, d->act,
+                                    d->act_slope, xbs, ybs, dense_or(dx16_batch_stride, c8_blocks(d->C) * d->S * 8), compute,
+                                    st);
   const int64_t work = vec ? d->S / 4 : d->S;
   const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
   dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
@@ -523,4 +527,24 @@ extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const 
                        gamma, beta, stat_m, dx, d->C, d->S, d->groups, d->act, d->act_slope, xbs,
                        ybs);
   return check_launch("norm_act_bwd");
+}
+
+extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
+                                 const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, float* dx, float* dgamma, float* dbeta,
+                                 int training, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return norm_act_bwd_impl(d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, training, workspace, workspace_bytes,
+                           stream, nullptr, 0, 0);
+}
+
+extern "C" int m355_norm_act_bwd_h16(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                                     const float* rstd, const float* gamma, const float* beta, float* dx,
+                                     float* dgamma, float* dbeta, int training, void* dx16, int64_t dx16_batch_stride,
+                                     int32_t compute, void* workspace, size_t workspace_bytes, void* stream) {
+  M355_REQUIRE(dx16 && (compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16) && ((uintptr_t)dx16 & 15) == 0 &&
+                   dx16_batch_stride % 8 == 0,
+               M355_EINVALID_ARG, "norm_act_bwd_h16: needs an aligned c8 destination and a 16-bit compute type");
+  return norm_act_bwd_impl(d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, training, workspace, workspace_bytes,
+                           stream, dx16, dx16_batch_stride, compute);
 }

@@ -262,6 +262,15 @@ def _packed_weight(weight, d, which):
     return buf, _lib.CONV_W_PACKED
 
 
+def _c8_twin(t, compute):
+    """the c8 twin a producer pass attached to this fp32 tensor (norm_act forward / backward in the 16-bit
+    training flow), if it describes exactly this tensor"""
+    tw = getattr(t, "_m355_c8", None)
+    if tw is not None and tw.compute == compute and tw.shape == tuple(t.shape) and tw.device == t.device:
+        return tw
+    return None
+
+
 def _with_flags(d, flags):
     if flags == d.flags:
         return d
@@ -334,6 +343,7 @@ class _ConvMeta:
     tag: str = "conv3d"
     stats: Optional[dict] = None   # filled with {"partials", "slots"} when the statistics are fused
     softmax: bool = False          # Softmax(dim=1) over the output channels fused into this op (out conv + hypothesis)
+    h16_train: int = 0             # set by the forward: the 16-bit compute code when the c8 training flow ran
 
 
 def _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad=0, compute=0):
@@ -379,7 +389,10 @@ class _Conv3dFn(torch.autograd.Function):
         if (H16_TRAIN_C8 and d.compute != _lib.COMPUTE_F32 and k == 3 and meta.stride == 1 and meta.pad == 1
                 and Cin > 4 and Cout > 4 and not meta.softmax and D * H * W * 64 < 2 ** 31
                 and ctx.needs_input_grad[0]):
-            x16 = pack_act16(x, d.compute)
+            x16 = _c8_twin(x, d.compute)
+            if x16 is None:
+                x16 = pack_act16(x, d.compute)
+            meta.h16_train = d.compute
         ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0) if x16 is not None
                         else L.m355_conv3d_fwd_workspace(C.byref(d)), x.device)
         prof, plan = _prof_gate("conv3d_fwd", d, 0)
@@ -451,7 +464,9 @@ class _Conv3dFn(torch.autograd.Function):
         if ctx.x16 is not None:   # 16-bit training flow: `x` is the saved c8 conv input; dy is packed once for both gradients
             x16 = Act16(x, *ctx.x16)
             x_dtype, x_device = ctx.x_meta
-            dy16 = pack_act16(dy, x16.compute)
+            dy16 = _c8_twin(dy, x16.compute)
+            if dy16 is None:
+                dy16 = pack_act16(dy, x16.compute)
         else:
             x_dtype, x_device = x.dtype, x.device
         if need_w or (need_b and ctx.has_bias):
@@ -530,9 +545,16 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
         x = x.to_f32()
     if isinstance(x, Concat):
         meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats, softmax=softmax)
-        return _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
-    meta = _ConvMeta(k, stride, padding, out=out, stats=stats, softmax=softmax)
-    return _Conv3dFn.apply(weight, bias, add, meta, x)
+        y = _Conv3dFn.apply(weight, bias, add, meta, *x.parts)
+    else:
+        meta = _ConvMeta(k, stride, padding, out=out, stats=stats, softmax=softmax)
+        y = _Conv3dFn.apply(weight, bias, add, meta, x)
+    if meta.h16_train and add is None:
+        # 16-bit training flow: the normalisation that follows may emit its input gradient (= this conv's output
+        # gradient) as c8 in the same pass (m355_norm_act_bwd_h16) -- not with a fused residual `add`, whose
+        # gradient is the same tensor and goes elsewhere
+        y._m355_c8_grad = meta.h16_train
+    return y
 
 
 # -------------------------------------------------------- conv-transpose3d
@@ -708,8 +730,19 @@ class _NormActFn(torch.autograd.Function):
             add, abs_ = _dense_channels(add)
         d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs, abs_)
         mean, rstd, use_batch = _norm_statistics(L, d, x, cfg, N, Cc)
-        check(L.m355_norm_act_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
-                                  _stream()), "norm_act_fwd")
+        # 16-bit training flow (H16_TRAIN_C8): a dense output also leaves as a c8 twin for the convolution that
+        # usually consumes it (handed over through `cfg.twin`, attached to the returned tensor by norm_act());
+        # ctx.dx_twin: the convolution that produced x wants its output gradient in c8 as well (see backward)
+        compute = _COMPUTE[_compute_mode]
+        ctx.dx_twin = getattr(cfg, "dx_twin", 0)
+        cfg.twin = None
+        if H16_TRAIN_C8 and compute != _lib.COMPUTE_F32 and cfg.out is None and ybs == Cc * S and Cc > 4:
+            cfg.twin = Act16.empty(N, Cc, tuple(x.shape[2:]), compute, x.device)
+            check(L.m355_norm_act_fwd_h16(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
+                                          cfg.twin.ptr(), cfg.twin.batch_stride(), compute, _stream()), "norm_act_fwd_h16")
+        else:
+            check(L.m355_norm_act_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
+                                      _stream()), "norm_act_fwd")
         ctx.desc, ctx.batch_stats, ctx.has_add = d, use_batch, add is not None
         ctx.has_affine = gamma is not None
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
@@ -726,9 +759,17 @@ class _NormActFn(torch.autograd.Function):
         dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
         dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
         ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
-        check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
-                                  _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
-                                  _stream()), "norm_act_bwd")
+        if ctx.dx_twin:   # dx is the output gradient of an h16-flow convolution: emit it as c8 too, in the same pass
+            dx16 = Act16.empty(d0.N, d0.C, tuple(x.shape[2:]), ctx.dx_twin, x.device)
+            check(L.m355_norm_act_bwd_h16(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                          _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, dx16.ptr(),
+                                          dx16.batch_stride(), ctx.dx_twin, _p(ws), ws.numel(), _stream()),
+                  "norm_act_bwd_h16")
+            dx._m355_c8 = dx16
+        else:
+            check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                      _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
+                                      _stream()), "norm_act_bwd")
         dadd = dy if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return dx, dgamma, dbeta, dadd, None
 
@@ -739,7 +780,13 @@ def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
     precision mode under no_grad) the result is an `Act16` and nothing is written in fp32."""
     if cfg.c8 and not torch.is_grad_enabled():
         return _norm_act_c8(x, gamma, beta, add, cfg)
-    return _NormActFn.apply(as_f32(x), gamma, beta, as_f32(add) if add is not None else None, cfg)
+    x = as_f32(x)
+    cfg.dx_twin = getattr(x, "_m355_c8_grad", 0) if torch.is_grad_enabled() else 0
+    y = _NormActFn.apply(x, gamma, beta, as_f32(add) if add is not None else None, cfg)
+    if getattr(cfg, "twin", None) is not None:
+        y._m355_c8 = cfg.twin
+        cfg.twin = None
+    return y
 
 
 # ------------------------------------------------------------- pool / upsample

@@ -371,6 +371,22 @@ class RawOps:
                   "norm_act_bwd")
         return dx, dg, db
 
+    def norm_act_bwd_h16(self, x, dy, mean, rstd, gamma, beta, groups, act, compute, training=1, eps=1e-5, slope=0.01):
+        """norm backward that also emits dx as c8 -> (dx, dgamma, dbeta, dx16 [N, CB, S, 8])"""
+        x, dy, mean, rstd, gamma, beta = map(self.to, (x, dy, mean, rstd, gamma, beta))
+        d = self.norm_desc(x, groups, act, eps, slope)
+        N, Cc = x.shape[:2]
+        S = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        dg = self.empty(Cc) if gamma is not None else None
+        db = self.empty(Cc) if gamma is not None else None
+        dx16 = torch.empty((N, (Cc + 7) // 8, S, 8), dtype=torch.bfloat16 if compute == 1 else torch.float16, device=self.device)
+        ws = self._ws("norm_workspace", d)
+        self._chk(self.fn("norm_act_bwd_h16")(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                              _p(dg), _p(db), training, _p(dx16), 0, compute, _p(ws), ws.numel(),
+                                              self._stream()), "norm_act_bwd_h16")
+        return dx, dg, db, dx16
+
     # -------------------------------------------------- pool / upsample / softmax
     def avgpool_fwd(self, x):
         x = self.to(x)

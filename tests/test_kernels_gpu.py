@@ -596,6 +596,24 @@ def _c8_to_ncdhw(x16, Cc, spatial):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_norm_act_bwd_with_c8_twin(hip, oracle, compute):
+    """m355_norm_act_bwd_h16: dx / dgamma / dbeta bit-identical to m355_norm_act_bwd, and the c8 twin of dx == dx
+    rounded once (GroupNorm and BatchNorm geometry, channel counts that are no multiple of 8, N = 2, eval mode)."""
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    for (N, Cc, D, H, W, groups, act, training) in [(2, 16, 4, 6, 8, 4, 1, 1), (1, 12, 2, 4, 6, 0, 2, 1), (1, 40, 4, 4, 32, 8, 1, 1),
+                                                    (2, 13, 3, 5, 7, 0, 1, 0)]:
+        x, dy = rnd(N, Cc, D, H, W, seed=1), rnd(N, Cc, D, H, W, seed=6)
+        gamma, beta = rnd(Cc, seed=2) * 0.5 + 1.0, rnd(Cc, seed=3) * 0.1
+        mean, rstd = oracle.norm_stats(x, groups)[:2]
+        dx0, dg0, db0 = hip.norm_act_bwd(x, dy, mean, rstd, gamma, beta, groups, act, training=training)
+        dx, dg, db, dx16 = hip.norm_act_bwd_h16(x, dy, mean, rstd, gamma, beta, groups, act, compute, training=training)
+        assert torch.equal(dx, dx0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+        assert torch.equal(_c8_to_ncdhw(dx16, Cc, (D, H, W)), dx.cpu().to(dt).float())
+        if Cc % 8:
+            assert (dx16[:, -1, :, Cc % 8:].float() == 0).all()
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
 def test_norm_act_and_avgpool_c8_outputs(hip, oracle, compute):
     """m355_norm_act_fwd_h16 == the fp32 pass followed by one rounding to the 16-bit type (GroupNorm and BatchNorm
     geometry, residual add, channel counts that are no multiple of 8, optional fp32 twin output);
