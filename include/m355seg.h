@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define M355_ABI_VERSION 1
+/* 2: m355_conv3d_desc.reserved became `flags` (packed weights, fused softmax); c8 / 16-bit entry points; ensembles;
+ * padded sliding window; weight standardisation */
+#define M355_ABI_VERSION 2
 
 enum {
   M355_OK = 0,

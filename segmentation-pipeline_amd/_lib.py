@@ -40,6 +40,7 @@ class NormDesc(C.Structure):
 
 
 _P = C.c_void_p
+ABI_VERSION = 2   # M355_ABI_VERSION of include/m355seg.h this binding was written against
 _i32, _i64, _f32, _sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _CD, _ND = C.POINTER(ConvDesc), C.POINTER(NormDesc)
 
@@ -155,8 +156,8 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, no GPU). "
                 "There is no CPU or PyTorch fallback for the hot path.")
         _lib = bind(C.CDLL(LIB_PATH))
-        if _lib.m355_version() != 1:
-            raise M355Error(f"ABI version mismatch: library reports {_lib.m355_version()}, expected 1")
+        if _lib.m355_version() != ABI_VERSION:
+            raise M355Error(f"ABI version mismatch: library reports {_lib.m355_version()}, expected {ABI_VERSION}")
     return _lib
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_version():
     L = _lib.lib()
-    assert L.m355_version() == 1
+    assert L.m355_version() == 2
     assert L.m355_last_error() is not None
 
 
