@@ -15,10 +15,13 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 
 # Arithmetic of the 3x3x3 convolutions: "fp32" = exact fp32 MFMA (default, the mode every 1e-4 parity
 # claim refers to), "bf16" / "fp16" = operands rounded to 16 bits, fp32 accumulate (BASELINE cfg3 / cfg5).
-# In the 16-bit modes the forward / data-gradient kernels read the c8 activation layout (include/m355seg.h);
-# the weight gradient takes the 16-bit MFMA kernel when W % 32 == 0 and both channel counts exceed 4, and
-# exact fp32 otherwise.  Under torch.no_grad() the activations between conv -> norm/act -> conv (-> pool)
-# live ONLY in c8 (`Act16`): no fp32 copy is written or read.
+# In the 16-bit modes the forward / data-gradient / weight-gradient kernels of the 3x3x3 stride-1 convolutions with
+# more than 4 channels on both sides read the c8 activation layout (include/m355seg.h; `H16_TRAIN_C8` below); the
+# edge layers go through the fp32-tensor entry points, which round the operands while staging them (Cin <= 4
+# forward) or run the exact fp32 kernels (Cout <= 4 forward, <= 4-channel weight gradients); strided / 1x1x1
+# kernels always compute in fp32.
+# Under torch.no_grad() the activations between conv -> norm/act -> conv (-> pool) live ONLY in c8 (`Act16`):
+# no fp32 copy is written or read.
 _COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16}
 _DT16 = {_lib.COMPUTE_BF16: torch.bfloat16, _lib.COMPUTE_F16: torch.float16}
 _compute_mode = "fp32"
