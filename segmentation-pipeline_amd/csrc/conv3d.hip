@@ -2025,7 +2025,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
                          int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, void* ws,
                          size_t ws_bytes, hipStream_t st, int compute = M355_COMPUTE_F32, float* stat = nullptr,
                          const void* in16 = nullptr, int64_t in16_bs = 0, const void* prepacked = nullptr,
-                         bool out16 = false) {
+                         bool out16 = false, bool softmax = false) {
   // prepacked: weights already packed for this plan by m355_conv3d_pack (M355_CONV_W_PACKED); `w` is then unused
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
   M355_REQUIRE(!stat || p.ksplit == 1 || (out16 && compute != M355_COMPUTE_F32), M355_EINVALID_ARG,
@@ -2044,8 +2044,9 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
       in16 = stage;
     }
     return run_h16_conv(p, compute, in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin, mout, D, H, W,
-                        out_bs, ws, ws_bytes, st, stat, prepacked, out16);
+                        out_bs, ws, ws_bytes, st, stat, prepacked, out16, softmax);
   }
+  M355_REQUIRE(!softmax, M355_EUNSUPPORTED, "conv3d: no fused softmax in the fp32 MFMA kernels");
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d: workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
@@ -2245,8 +2246,10 @@ static void launch_pack_smallcout(const m355_conv3d_desc* d, const float* w, flo
 
 // softmax over the output channels in the epilogue: the fp32 packed-FMA kernel for Cout <= 4
 static bool fuses_softmax(const m355_conv3d_desc* d) {
-  return is_k3s1p1(d) && small_cout_fwd(d) && tuning().smallcout_valu && tuning().fuse_softmax &&
-         (int64_t)d->D * d->H * d->W < (1ll << 27);
+  if (!is_k3s1p1(d) || !tuning().fuse_softmax) return false;
+  if (d->compute != M355_COMPUTE_F32)   // 16-bit kernels (c8 input, m355_conv3d_fwd_h16): in-register epilogue, unsplit plans
+    return d->Cout <= 4 && plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute).ksplit == 1;
+  return small_cout_fwd(d) && tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27);
 }
 extern "C" int32_t m355_conv3d_fuses_softmax(const m355_conv3d_desc* d) { return d && fuses_softmax(d) ? 1 : 0; }
 
@@ -2292,7 +2295,7 @@ static int conv3d_fwd_impl(const m355_conv3d_desc* d, const float* x, const floa
     const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
     return run_mfma_conv(x, packed ? nullptr : w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
                          d->H, d->W, xbs, ybs, workspace, workspace_bytes, st, d->compute, stat, nullptr, 0,
-                         packed ? w : nullptr);
+                         packed ? w : nullptr, false, (d->flags & M355_CONV_SOFTMAX) != 0);
   }
   M355_REQUIRE(!(d->flags & M355_CONV_W_PACKED), M355_EINVALID_ARG, "conv3d_fwd: this descriptor has no packed weights");
   const int64_t total = (int64_t)d->N * d->Cout * OD * OH * OW;
@@ -2395,12 +2398,15 @@ extern "C" int m355_conv3d_fwd_h16(const m355_conv3d_desc* d, const void* x16, i
   M355_REQUIRE(x16 && w && y && workspace, M355_EINVALID_ARG, "conv3d_fwd_h16: null pointer");
   M355_REQUIRE(!stat_partials || conv_stats_slots(d) > 0, M355_EINVALID_ARG,
                "conv3d_fwd_h16: this descriptor has no fused statistics (m355_conv3d_stats_slots() == 0)");
+  const bool softmax = (d->flags & M355_CONV_SOFTMAX) != 0;
+  M355_REQUIRE(!softmax || fuses_softmax(d), M355_EUNSUPPORTED,
+               "conv3d_fwd_h16: M355_CONV_SOFTMAX needs m355_conv3d_fuses_softmax(desc) != 0");
   const int64_t S = (int64_t)d->D * d->H * d->W;
   const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
   return run_mfma_conv(nullptr, packed ? nullptr : w, false, d->Cout, d->Cin, bias, add, y, d->N, d->Cin, d->Cout, d->D,
                        d->H, d->W, 0, dense_or(d->y_batch_stride, (int64_t)d->Cout * S), workspace, workspace_bytes,
                        (hipStream_t)stream, d->compute, stat_partials, x16,
-                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8), packed ? w : nullptr);
+                       dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8), packed ? w : nullptr, false, softmax);
 }
 
 extern "C" int m355_conv3d_fwd_h16_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,

@@ -150,7 +150,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M
 int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
                  int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
-                 const void* prepacked = nullptr, bool out16 = false);
+                 const void* prepacked = nullptr, bool out16 = false, bool softmax = false);
 void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
                         hipStream_t st);
 // weight gradient on the 16-bit MFMA (fp32 NCDHW operands rounded while staged; W % 32 == 0)

@@ -257,6 +257,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_c8_kernel(const float* __re
   }
 }
 
+// Output conv of the network (Cout <= 4) with nn.Softmax(dim=1) as its epilogue (models/modular_unet.py:83-84,99-100):
+// rows 0..3 of the 32-row tile -- all channels of a voxel -- are registers 0..3 of the lower lane half, so the
+// softmax is in-register arithmetic and the logits never travel to HBM (same expressions as softmax_fwd_kernel).
+template <int NTW, int GY>
+__device__ __forceinline__ void store_conv_tile_softmax(const f32x16 (&acc)[NTW], float* __restrict__ dst,
+                                                        const float* __restrict__ bias, int Cout, int z, int y0, int xg,
+                                                        int ly, int half, int D, int H, int W, bool lane_ok) {
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  float bb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bb[c] = (bias && c < Cout) ? bias[c] : 0.f;
+#pragma unroll
+  for (int g = 0; g < NTW; ++g) {
+    const int yg = y0 + g * GY + ly;
+    if (!(lane_ok && half == 0 && yg < H)) continue;
+    float v[4], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v[c] = acc[g][c] + bb[c];
+      if (c < Cout) mx = fmaxf(mx, v[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < Cout) sum += expf(v[c] - mx);
+    const float inv = 1.f / sum;
+    const int64_t base = (int64_t)z * HW + (int64_t)yg * W + xg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < Cout) dst[base + (int64_t)c * DHW] = expf(v[c] - mx) * inv;
+  }
+}
+
 // ------------------------------------------------------------------ the kernel
 #ifdef M355_H16_STAMPS
 // Diagnostic build only (tools/h16_stamps.py): per-workgroup cycle sums of the phases of a chunk, wave 0.
@@ -278,7 +310,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
     int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int nchunks, int ksplit, int nbatch,
     int64_t xbs16, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int* __restrict__ work_counter,
-    int stagger) {
+    int stagger, int softmax) {
   using T = FwdTile<NTW, GX>;
   using hx8 = typename H16<HT>::x8;
   constexpr int GY = T::GY, TZ = NW, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = (TZ + 2) * PS;
@@ -585,6 +617,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
         if constexpr (OUT16)
           store_conv_tile_c8<NTW, GY, HT>(acc, reinterpret_cast<HT*>(y) + (int64_t)cur.n * ybs, bias, cur.o0, Cout, z,
                                           cur.y0, xg, ly, half, H, W, (int64_t)S, lane_ok, st);
+        else if (softmax)   // (host: Cout <= 4, one channel tile, no residual, no statistics)
+          store_conv_tile_softmax<NTW, GY>(acc, y + (int64_t)cur.n * ybs, bias, Cout, z, cur.y0, xg, ly, half, D, H, W,
+                                           lane_ok);
         else
           store_conv_tile<NTW, GY>(acc, y + (int64_t)cur.n * ybs, add ? add + (int64_t)cur.n * ybs : nullptr, bias,
                                    cur.o0, Cout, z, cur.y0, xg, ly, half, D, H, W, lane_ok, st);
@@ -614,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
 template <int NTW, int GX, typename HT>
 static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
-                       int64_t ybs, hipStream_t st, float* stat, int* work_counter, bool out16) {
+                       int64_t ybs, hipStream_t st, float* stat, int* work_counter, bool out16, int softmax) {
   const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
   const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (p.nw == 8 ? 1 : (NTW <= 4 ? 2 : 1)) * num_cus();
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, slots));
@@ -624,22 +659,22 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
       if (out16 && p.ksplit == 1)
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
       else
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
       return;
     }
   }
   if (out16 && p.ksplit == 1)
     hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
                        (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger);
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax);
   else
     hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
                        (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger);
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax);
 }
 
 template <typename HT>
@@ -662,7 +697,7 @@ template <typename HT>
 static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, const float* w, bool transpose,
                           int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin,
                           int mout, int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st,
-                          float* stat, const void* prepacked, bool out16) {
+                          float* stat, const void* prepacked, bool out16, bool softmax) {
   // out16: `out` is a c8 tensor of the same 16-bit type (out_bs in elements of it); `add` must be null
   M355_REQUIRE(ws_bytes >= p.wp_bytes + p.slab_bytes, M355_EWORKSPACE,
                "conv3d(16-bit operands): workspace too small (%zu < %zu)", ws_bytes, p.wp_bytes + p.slab_bytes);
@@ -674,6 +709,8 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
                "conv3d(16-bit operands): fused statistics of a split-K plan exist only for the c8 output");
   M355_REQUIRE(!out16 || (!add && ((uintptr_t)out & 15) == 0 && out_bs % 8 == 0), M355_EINVALID_ARG,
                "conv3d(16-bit operands): a c8 output takes no fused `add` and must be 16B aligned");
+  M355_REQUIRE(!softmax || (mout <= 4 && p.ksplit == 1 && !add && !stat && !out16), M355_EUNSUPPORTED,
+               "conv3d(16-bit operands): the softmax epilogue needs Cout <= 4, an unsplit plan, fp32 output, no add / statistics");
   HT* wpb = prepacked ? (HT*)prepacked : (HT*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
   int* work_counter = (int*)((char*)wpb + p.wp_bytes - 256);  // last 256 B of the packed-weight region
@@ -683,7 +720,7 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
 #define M355_H16_CASE(NTW, GX)                                                                               \
   if (p.ntw == NTW && p.gx == GX) {                                                                          \
     launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st,       \
-                            p.ksplit == 1 ? stat : nullptr, work_counter, out16);                                                          \
+                            p.ksplit == 1 ? stat : nullptr, work_counter, out16, softmax ? 1 : 0);                                                          \
   } else
   M355_H16_CASE(4, 32) M355_H16_CASE(2, 32) M355_H16_CASE(1, 32)
   M355_H16_CASE(4, 16) M355_H16_CASE(2, 16) M355_H16_CASE(1, 16)
@@ -710,12 +747,12 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
 int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_bs, const float* w, bool transpose,
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
                  int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
-                 const void* prepacked, bool out16) {
+                 const void* prepacked, bool out16, bool softmax) {
   if (compute == M355_COMPUTE_BF16)
     return run_h16_conv_t<__bf16>(p, (const __bf16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N, kin,
-                                  mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16);
+                                  mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16, softmax);
   return run_h16_conv_t<_Float16>(p, (const _Float16*)in16, in16_bs, w, transpose, Cout_w, Cin_w, bias, add, out, N,
-                                  kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16);
+                                  kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16, softmax);
 }
 
 // ------------------------------------------------ bwd-weight, bf16 compute mode (W % 32 == 0)

@@ -292,9 +292,10 @@ def _c8_channel_partials(x16: Act16, stats: dict):
     stats["partials"], stats["slots"] = part, slots
 
 
-def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False):
+def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False, softmax=False):
     """3x3x3 / s1 / p1 forward on a c8 input (no autograd: the c8 flow only exists under no_grad).  c8_out: the
-    result (a pre-norm tensor) is written by the conv epilogue as c8 too and returned as an Act16."""
+    result (a pre-norm tensor) is written by the conv epilogue as c8 too and returned as an Act16.  softmax:
+    nn.Softmax(dim=1) of the result (the conv's epilogue where the kernel variant has one, else a separate pass)."""
     L = _lib.lib()
     _require(weight, bias, add)
     weight = weight.contiguous()
@@ -305,7 +306,9 @@ def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False):
         add = add.contiguous()
     d = _conv_desc(N, Cin, Cout, D, H, W, 3, 1, 1, 0, 0, compute=x16.compute)
     wbuf, flags = _packed_weight(weight, d, 0)
-    d = _with_flags(d, flags)
+    fuse_sm = (softmax and not c8_out and add is None and stats is None
+               and L.m355_conv3d_fuses_softmax(C.byref(d)) != 0)
+    d = _with_flags(d, flags | (_lib.CONV_SOFTMAX if fuse_sm else 0))
     ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0), x16.device)
     prof, plan = _prof_gate("conv3d_fwd", d, 0)
     if prof is not None:
@@ -332,6 +335,8 @@ def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False):
                      _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 2 if c8_out else 4)))
     if c8_out and stats is not None and slots == 0:
         _c8_channel_partials(y, stats)
+    if softmax and not fuse_sm:
+        y = softmax_channels(as_f32(y))
     return y
 
 
@@ -543,8 +548,8 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
         return pack_act16(conv3d(x, weight, bias, add, stride, padding, None, stats), out.buf16.compute, out.act16())
     if isinstance(x, Act16):
         if k == 3 and stride == 1 and padding == 1:
-            y = _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out and not softmax)
-            return softmax_channels(y) if softmax else y
+            return _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out and not softmax,
+                                 softmax)
         x = x.to_f32()
     if isinstance(x, Concat):
         meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats, softmax=softmax)

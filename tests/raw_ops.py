@@ -135,12 +135,16 @@ class RawOps:
         self._chk(self.lib.m355_conv3d_plan(C.byref(d), which, out), "conv3d_plan")
         return tuple(out)
 
-    def conv3d_fwd_h16(self, x16, Cin, spatial, w, bias=None, add=None, compute=1, groups=None, eps=1e-5):
-        """forward on a c8 input; groups != None also returns the fused statistics (mean, rstd)"""
+    def conv3d_fwd_h16(self, x16, Cin, spatial, w, bias=None, add=None, compute=1, groups=None, eps=1e-5, softmax=False):
+        """forward on a c8 input; groups != None also returns the fused statistics (mean, rstd); softmax: the
+        M355_CONV_SOFTMAX epilogue (asserts that the library offers it for this descriptor)"""
         w, bias, add = map(self.to, (w, bias, add))
         N, CBp, S, _ = x16.shape
         Cout = w.shape[0]
         d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 3, 1, 1, compute=compute)
+        if softmax:
+            assert self.lib.m355_conv3d_fuses_softmax(C.byref(d)) == 1
+            d.flags |= 2
         y = self.empty(N, Cout, *spatial)
         n = self.lib.m355_conv3d_h16_workspace(C.byref(d), 0)
         ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)

@@ -212,6 +212,22 @@ def test_out_conv_softmax_fused_epilogue(hip, oracle):
         assert (fused.sum(dim=1) - 1).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_out_conv_softmax_fused_epilogue_16bit(hip, oracle, compute, tuning):
+    """M355_CONV_SOFTMAX on m355_conv3d_fwd_h16 (c8 input, Cout <= 4: the out conv of the 16-bit inference flow): the
+    softmax is the kernel's epilogue (all channels of a voxel are registers of one lane) == the same conv followed
+    by m355_softmax_fwd, bit for bit; 4-wave and 8-wave kernel variants, ragged volumes, N = 2."""
+    for w8 in (0, 2):
+        tuning(M355_H16_W8=w8, M355_CONV_KSPLIT=1)
+        for (N, ci, co, D, H, W) in [(1, 32, 3, 8, 16, 64), (2, 8, 2, 9, 10, 36), (1, 16, 4, 8, 8, 32)]:
+            x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+            x16 = hip.act16_pack(x, compute)
+            fused = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute, softmax=True)
+            assert torch.equal(fused, hip.softmax_fwd(hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute)))
+            close(fused, oracle.softmax_fwd(oracle.conv3d_fwd(x, w, b, compute=compute)), 1e-4, 1e-5, "conv + softmax")
+            assert (fused.sum(dim=1) - 1).abs().max().item() <= 1e-5
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
