@@ -911,6 +911,39 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float
   }
 }
 
+// The same with the statistics partials of the following normalisation (what the unsplit kernels emit from their
+// epilogue): grid (voxel chunks, Cout, N), one (sum, sum of squares) slot per block:
+// stat[((n * gridDim.x + blockIdx.x) * Cout + o) * 2 + {0,1}] -- the norm then never re-reads y for its statistics.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slab,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ add, float* __restrict__ y,
+                                                                  int Cout, int64_t S, int ksplit, int64_t slab_stride,
+                                                                  int64_t ybs, float* __restrict__ stat) {
+  __shared__ float scratch[4];
+  const int o = blockIdx.y, n = blockIdx.z;
+  const float* sp = slab + ((int64_t)n * Cout + o) * S;
+  const float b = bias ? bias[o] : 0.f;
+  float* yp = y + (int64_t)n * ybs + (int64_t)o * S;
+  const float* ap = add ? add + (int64_t)n * ybs + (int64_t)o * S : nullptr;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
+    float v = sp[i];
+    for (int k = 1; k < ksplit; ++k) v += sp[(int64_t)k * slab_stride + i];
+    v += b;
+    if (ap) v += ap[i];
+    yp[i] = v;
+    s1 += v;
+    s2 = fmaf(v, v, s2);
+  }
+  s1 = block_sum<float, 256>(s1, scratch);
+  s2 = block_sum<float, 256>(s2, scratch);
+  if (threadIdx.x == 0) {
+    float* q = stat + (((int64_t)n * gridDim.x + blockIdx.x) * Cout + o) * 2;
+    q[0] = s1;
+    q[1] = s2;
+  }
+}
+
 // ------------------------------------------------------- MFMA bwd-weight kernel
 // dW[o, c, tap] = sum_v dy[o, v] * x[c, v + off(tap)]
 // MFMA view: i = o (A = dy tile [32 o][256 voxels]), j = c (B = x halo tile
@@ -2028,7 +2061,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
                          bool out16 = false, bool softmax = false) {
   // prepacked: weights already packed for this plan by m355_conv3d_pack (M355_CONV_W_PACKED); `w` is then unused
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
-  M355_REQUIRE(!stat || p.ksplit == 1 || (out16 && compute != M355_COMPUTE_F32), M355_EINVALID_ARG,
+  M355_REQUIRE(!stat || p.ksplit == 1 || compute == M355_COMPUTE_F32 || out16, M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
   if (compute != M355_COMPUTE_F32) {
     if (!in16) {
@@ -2059,7 +2092,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
 #define M355_FWD_CASE(NTW, GX)                                                              \
   if (p.ntw == NTW && p.gx == GX) {                                                         \
     launch_fwd<NTW, GX>(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, \
-                        st, stat, work_counter);                                            \
+                        st, p.ksplit == 1 ? stat : nullptr, work_counter);                  \
   } else
   M355_FWD_CASE(8, 32)
   M355_FWD_CASE(4, 32)
@@ -2077,7 +2110,12 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
     return M355_EUNSUPPORTED;
   }
 #undef M355_FWD_CASE
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && stat) {   // split plan + fused statistics: the reduction pass emits the partials
+    const int64_t S = (int64_t)D * H * W;
+    dim3 grid((unsigned)splitk_c8_slots(S), (unsigned)mout, (unsigned)N);
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, st, slab, bias, add, out, mout, S, p.ksplit,
+                       (int64_t)N * mout * S, out_bs, stat);
+  } else if (p.ksplit > 1) {
     const int64_t S = (int64_t)D * H * W;
     const int64_t total = (int64_t)N * mout * S;
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
@@ -2219,7 +2257,9 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
 static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || small_cout_fwd(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
-  if (p.ksplit != 1) return 0;
+  if (p.ksplit != 1)   // split-K: the fp32 reduction pass emits the partials (one slot per block of it); the 16-bit
+    return d->compute == M355_COMPUTE_F32 && d->N <= 65535 && d->Cout <= 65535   // kernels only with a c8 output
+               ? splitk_c8_slots((int64_t)d->D * d->H * d->W) : 0;
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }

@@ -129,11 +129,13 @@ def test_conv3d_bwd_weight_remainder_pair_classes(hip, oracle, env, tuning):
         close(dw, hip.conv3d_bwd_weight(x, dy, 3)[0], 1e-5, tol / 3, "vs padded 32 x 32 pairs")
 
 
-@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}, {"M355_CONV_KSPLIT": "2"}, {"M355_CONV_KSPLIT": "0"}])
 def test_conv3d_fused_statistics(hip, oracle, env, tuning):
     """m355_conv3d_fwd_stats + m355_norm_stats_from_partials == statistics of the conv output (GroupNorm and
-    BatchNorm geometry, ragged volumes with overhanging tiles, N = 2, one-shot and persistent kernels)."""
-    tuning(M355_CONV_KSPLIT=1, **env)  # split-K plans (what these small volumes would get) have no fusion
+    BatchNorm geometry, ragged volumes with overhanging tiles, N = 2, one-shot and persistent kernels: partials from
+    the conv epilogue; split-K plans -- forced, and whatever the planner picks for these small volumes: partials from
+    the reduction pass)."""
+    tuning(**{"M355_CONV_KSPLIT": 1, **env})
     for (N, ci, co, D, H, W, groups) in [(2, 8, 16, 9, 10, 36, 4), (1, 5, 40, 6, 21, 16, 8), (2, 8, 24, 12, 9, 8, 0),
                                         (1, 16, 32, 16, 16, 32, 8)]:
         x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
