@@ -928,7 +928,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
   float s1 = 0.f, s2 = 0.f;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < S; i += gridDim.x * 256ll) {
     float v = sp[i];
-    for (int k = 1; k < ksplit; ++k) v += sp[(int64_t)k * slab_stride + i];
+    int k = 1;
+    for (; k + 8 <= ksplit; k += 8) {   // eight splits' loads in flight together; summed in split order all the same
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = sp[(int64_t)(k + u) * slab_stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; k < ksplit; ++k) v += sp[(int64_t)k * slab_stride + i];
     v += b;
     if (ap) v += ap[i];
     yp[i] = v;

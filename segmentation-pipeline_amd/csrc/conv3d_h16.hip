@@ -220,7 +220,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_c8_kernel(const float* __re
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = j < nc ? sp[(int64_t)j * S + i] : 0.f;
-    for (int k = 1; k < ksplit; ++k) {
+    int k = 1;
+    for (; k + 4 <= ksplit; k += 4) {   // four splits' loads in flight together; summed in split order all the same
+      float t[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[u][j] = j < nc ? sp[(int64_t)(k + u) * slab_stride + (int64_t)j * S + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += t[u][j];
+    }
+    for (; k < ksplit; ++k) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < nc) v[j] += sp[(int64_t)k * slab_stride + (int64_t)j * S + i];
