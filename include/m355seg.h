@@ -258,6 +258,13 @@ int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const float* mean
  * recomputed from it.  Produces dx (x's layout), dgamma[C], dbeta[C] (either may
  * be NULL when gamma is NULL).  `training` = 0 for BN eval mode (statistics are
  * constants, no mean-subtraction terms). */
+/* normalise + activation with nn.AvgPool3d(2, 2) of the result as a second output (an encoder block's output
+ * continues into the skip connection and, pooled, into the next level: models/modular_unet.py:90-92).  y as in
+ * m355_norm_act_fwd (no residual add); pooled: fp32 [N, C, D/2, H/2, W/2] with its own batch stride (0 = dense).
+ * D * H * W must equal desc->S, all even.  Bit-identical to m355_norm_act_fwd followed by m355_avgpool3d_2x_fwd. */
+int m355_norm_act_pool_fwd(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, float* y, float* pooled, int64_t pooled_batch_stride,
+                           int32_t D, int32_t H, int32_t W, void* stream);
 int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,
                       const float* mean, const float* rstd, const float* gamma,
                       const float* beta, float* dx, float* dgamma, float* dbeta,

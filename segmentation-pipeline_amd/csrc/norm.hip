@@ -245,6 +245,46 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(
   }
 }
 
+// The same pass with nn.AvgPool3d(2, 2) of the result as a SECOND output (models/modular_unet.py:90-92: an encoder
+// block's output continues both into the skip connection and, pooled, into the next level): one thread per pooled
+// voxel normalises + activates its 2x2x2 window (four 8-byte row pairs), stores the eight values and their mean --
+// the pool's own pass over the activated tensor (a full re-read of the level) disappears.  Summation order and the
+// normalise expression are those of avgpool2_fwd_kernel / norm_act_fwd_kernel: bit-identical to the two-pass result.
+// grid: (chunks over pooled voxels, C, N)
+__global__ __launch_bounds__(256) void norm_act_pool_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ pooled,
+    int C, int D, int H, int W, int groups, int act, float slope, int64_t xbs, int64_t ybs, int64_t pbs) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t s = groups == 0 ? c : (int64_t)n * groups + c / (C / groups);
+  const float m = mean[s], r = rstd[s];
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = r * g;
+  const float sh = b - m * sc;
+  const int OD = D / 2, OH = H / 2, OW = W / 2;
+  const int64_t S = (int64_t)D * H * W, OS = (int64_t)OD * OH * OW;
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c * S;
+  float* yp = y + (int64_t)n * ybs + (int64_t)c * S;
+  float* pp = pooled + (int64_t)n * pbs + (int64_t)c * OS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < OS; i += gridDim.x * 256ll) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH), oz = (int)(t / OH);
+    const int64_t r00 = ((int64_t)(2 * oz) * H + 2 * oy) * W + 2 * ox;
+    const int64_t off[4] = {r00, r00 + W, r00 + (int64_t)H * W, r00 + (int64_t)H * W + W};
+    float2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float2*>(xp + off[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q].x = act_fwd(fmaf(v[q].x, sc, sh), act, slope);
+      v[q].y = act_fwd(fmaf(v[q].y, sc, sh), act, slope);
+      *reinterpret_cast<float2*>(yp + off[q]) = v[q];
+    }
+    pp[i] = (((((((v[0].x + v[0].y) + v[1].x) + v[1].y) + v[2].x) + v[2].y) + v[3].x) + v[3].y) * 0.125f;
+  }
+}
+
 // Backward pass 1: per (n,c) partial sums A = sum g, B = sum g*xhat with
 // g = dy * act'(pre).  partial[((n*C + c)*nblk + b)*2 + {0,1}]
 template <bool VEC>
@@ -568,6 +608,27 @@ static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const floa
                        gamma, beta, stat_m, dx, d->C, d->S, d->groups, d->act, d->act_slope, xbs,
                        ybs);
   return check_launch("norm_act_bwd");
+}
+
+extern "C" int m355_norm_act_pool_fwd(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, float* y, float* pooled,
+                                      int64_t pooled_batch_stride, int32_t D, int32_t H, int32_t W, void* stream) {
+  if (int rc = validate_norm(d, "norm_act_pool_fwd")) return rc;
+  M355_REQUIRE(x && mean && rstd && y && pooled, M355_EINVALID_ARG, "norm_act_pool_fwd: null pointer");
+  M355_REQUIRE(D > 0 && H > 0 && W > 0 && (int64_t)D * H * W == d->S, M355_EINVALID_ARG,
+               "norm_act_pool_fwd: D*H*W != desc->S");
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED, "norm_act_pool_fwd: odd spatial size (%d,%d,%d)",
+               D, H, W);
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
+  const int64_t pbs = dense_or(pooled_batch_stride, (int64_t)d->C * (d->S / 8));
+  M355_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 7) == 0 && xbs % 2 == 0 && ybs % 2 == 0, M355_EINVALID_ARG,
+               "norm_act_pool_fwd: x / y not 8B aligned");
+  const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S / 8, 256 * 2), 1024));
+  dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
+  hipLaunchKernelGGL(norm_act_pool_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, pooled,
+                     d->C, D, H, W, d->groups, d->act, d->act_slope, xbs, ybs, pbs);
+  return check_launch("norm_act_pool_fwd");
 }
 
 extern "C" int m355_norm_act_bwd(const m355_norm_desc* d, const float* x, const float* dy,

@@ -193,26 +193,31 @@ def wants_batch_stats(norm):
     return isinstance(norm, nn.BatchNorm3d) and (norm.training or norm.running_mean is None)
 
 
-def run_norm_act(norm, act, x, add=None, out=None, stats=None, c8=0):
+def run_norm_act(norm, act, x, add=None, out=None, stats=None, c8=0, pool=False):
     """normalization + activation (+ residual add) through the fused HIP passes.  `stats`: partial
     sums emitted by the conv that produced `x` (saves the statistics pass over x).  `c8`: 16-bit compute
-    code -> the result is written only in the c8 layout the next convolution reads (ops.Act16)."""
+    code -> the result is written only in the c8 layout the next convolution reads (ops.Act16).  `pool`: also
+    return nn.AvgPool3d(2, 2) of the result, computed in the same pass -> (y, pooled)."""
     code, slope = _act_code(act)
+    fn = ops.norm_act
+    if pool:
+        assert add is None and not c8
+        fn = lambda x_, g_, b_, cfg_, add=None: ops.norm_act_pool(x_, g_, b_, cfg_)
     if norm is None:
         # activation only: identity statistics
         Cc = x.shape[1]
         cfg = ops.NormCfg(groups=0, eps=0.0, act=code, slope=slope, training=False,
                           running_mean=torch.zeros(Cc, device=x.device),
                           running_var=torch.ones(Cc, device=x.device), out=out, c8=c8)
-        return ops.norm_act(x, None, None, cfg, add=add)
+        return fn(x, None, None, cfg, add=add)
     if isinstance(norm, nn.GroupNorm):
         cfg = ops.NormCfg(groups=norm.num_groups, eps=norm.eps, act=code, slope=slope, out=out, stats=stats, c8=c8)
-        return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
+        return fn(x, norm.weight, norm.bias, cfg, add=add)
     if isinstance(norm, nn.InstanceNorm3d):
         if norm.track_running_stats:
             raise NotImplementedError("InstanceNorm3d(track_running_stats=True) has no HIP kernel")
         cfg = ops.NormCfg(groups=x.shape[1], eps=norm.eps, act=code, slope=slope, out=out, stats=stats, c8=c8)
-        return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
+        return fn(x, norm.weight, norm.bias, cfg, add=add)
     # BatchNorm3d: batch statistics in training mode (and whenever no running stats exist)
     training = norm.training or norm.running_mean is None
     momentum = norm.momentum
@@ -224,7 +229,7 @@ def run_norm_act(norm, act, x, add=None, out=None, stats=None, c8=0):
                       momentum=0.0 if momentum is None else momentum,
                       running_mean=norm.running_mean, running_var=norm.running_var, out=out,
                       stats=stats if training else None, c8=c8)
-    return ops.norm_act(x, norm.weight, norm.bias, cfg, add=add)
+    return fn(x, norm.weight, norm.bias, cfg, add=add)
 
 
 class Block3d(nn.Module):
@@ -283,9 +288,12 @@ class Block3d(nn.Module):
         if dropout_p != 0.0:
             self.dropout = nn.Dropout3d(p=dropout_p)
 
-    def forward(self, x, out: Optional[ops.OutSlot] = None, c8_out: bool = False):
+    def forward(self, x, out: Optional[ops.OutSlot] = None, c8_out: bool = False, pool: bool = False):
         """`c8_out` (or an `out` slot of a c8 concat buffer): in a 16-bit precision mode under no_grad the
-        block's result is returned as an `ops.Act16`; the activations BETWEEN its convolutions always are."""
+        block's result is returned as an `ops.Act16`; the activations BETWEEN its convolutions always are.
+        `pool`: the caller wants nn.AvgPool3d(2, 2) of the result as well; where the block can produce it from its
+        last normalise + activation pass (fp32 tensors, no residual branch, no dropout, even sizes) it returns
+        (result, pooled) -- otherwise just the result, and the caller pools."""
         drop = self.dropout is not None and self.training and self.dropout.p > 0.0
         final_out = None if drop else out
         flow = ops.h16_flow()
@@ -310,6 +318,9 @@ class Block3d(nn.Module):
                 stats = {} if wants_batch_stats(norm) else None
                 c8 = flow if (not last or c8_out) else 0
                 h = run_conv(conv, h, stats=stats, c8_out=bool(c8))   # c8 flow: the pre-norm tensor is c8 as well
+                if (pool and ops.FUSE_POOL and last and add is None and not drop and not c8 and ops.get_precision() == "fp32"
+                        and isinstance(h, torch.Tensor) and all(v % 2 == 0 for v in h.shape[2:])):
+                    return run_norm_act(norm, act, h, out=slot, stats=stats, pool=True)   # -> (result, pooled)
                 h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats, c8=c8)
         if self._num_convs == 0 and res is not None:
             h = ops.add(res, h)

@@ -31,6 +31,17 @@ def _run_downsample(m, x):
     raise NotImplementedError(f"downsample_class {type(m).__name__} has no HIP kernel")
 
 
+def _is_avgpool2(m):
+    """nn.AvgPool3d(kernel_size=2, stride=2) -- the pool an encoder block can emit from its last pass"""
+    if not isinstance(m, nn.AvgPool3d) or m.ceil_mode:
+        return False
+    try:
+        return (_uniform_int(m.kernel_size, "kernel_size") == 2 and _uniform_int(m.stride, "stride") == 2
+                and _uniform_int(m.padding, "padding") == 0)
+    except (NotImplementedError, ValueError, TypeError):
+        return False
+
+
 def _run_upsample(m, x, out=None):
     if isinstance(m, nn.Upsample):
         sf = m.scale_factor
@@ -157,8 +168,11 @@ class ModularUNet(nn.Module):
                 else:
                     buf = torch.empty((N, c_up + f[i]) + spatial, dtype=torch.float32, device=x.device)
                     slot = ops.OutSlot(buf, c_up, c_up + f[i])
-                x = self.down_blocks[i](x, out=slot)
-                if (isinstance(self.downsampling[i], nn.AvgPool3d) and isinstance(x, torch.Tensor)
+                fuse_pool = (not flow and _is_avgpool2(self.downsampling[i]) and isinstance(self.down_blocks[i], Block3d))
+                x = self.down_blocks[i](x, out=slot, pool=True) if fuse_pool else self.down_blocks[i](x, out=slot)
+                if isinstance(x, tuple):
+                    x_skip, x = x      # AvgPool3d(2, 2) came out of the block's last norm + activation pass
+                elif (isinstance(self.downsampling[i], nn.AvgPool3d) and isinstance(x, torch.Tensor)
                         and x.requires_grad and torch.is_grad_enabled()):
                     _run_downsample(self.downsampling[i], None)          # validates the module's geometry
                     x_skip, x = ops.avgpool3d_2x_with_skip(x)            # one fused gradient for both uses

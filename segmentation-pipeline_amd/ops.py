@@ -5,6 +5,7 @@ stream, and the autograd graph.  Every tensor op on the hot path is a call
 through the C ABI of libm355seg.so; nothing falls back to torch or to the CPU.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -237,6 +238,8 @@ PACK_CACHE = True
 # 16-bit precision modes, training: pack the conv input / output gradient to c8 once in the autograd function and run
 # forward, data gradient and weight gradient on the c8 entry points (False: fp32 operands, staged inside the library)
 H16_TRAIN_C8 = True
+# an encoder block's last norm + activation pass also emits the AvgPool3d(2, 2) the next level consumes
+FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"
 
 
 def _packed_weight(weight, d, which):
@@ -780,6 +783,65 @@ class _NormActFn(torch.autograd.Function):
                                       _stream()), "norm_act_bwd")
         dadd = dy if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return dx, dgamma, dbeta, dadd, None
+
+
+class _NormActPoolFn(torch.autograd.Function):
+    """norm + activation with AvgPool3d(2, 2) of the result as a second output (m355_norm_act_pool_fwd): the last
+    pass of an encoder block also produces the next level's input, so the pool never re-reads the activated tensor.
+    Backward: the two incoming gradients (skip path, pooled path) are summed in the pool-backward pass
+    (m355_avgpool3d_2x_bwd_add), then the usual normalisation backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, cfg: NormCfg):
+        L = _lib.lib()
+        _require(x, gamma, beta)
+        x, xbs = _dense_channels(x)
+        N, Cc, D, H, W = x.shape
+        S = D * H * W
+        if xbs != Cc * S:
+            x, xbs = x.contiguous(), Cc * S
+        y = _alloc_out(cfg.out, x.shape, x)
+        y, ybs = _dense_channels(y)
+        pooled = torch.empty((N, Cc, D // 2, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, xbs, ybs, 0)
+        mean, rstd, use_batch = _norm_statistics(L, d, x, cfg, N, Cc)
+        check(L.m355_norm_act_pool_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _p(pooled), 0,
+                                       D, H, W, _stream()), "norm_act_pool_fwd")
+        ctx.desc, ctx.batch_stats, ctx.has_affine, ctx.dims = d, use_batch, gamma is not None, (D, H, W)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y, pooled
+
+    @staticmethod
+    def backward(ctx, dy, dpool):
+        L = _lib.lib()
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        d0 = ctx.desc
+        D, H, W = ctx.dims
+        if dpool is not None:   # gradient of the activated tensor = skip-path gradient + un-pooled gradient, one pass
+            dpool, gpbs = _dense_channels(dpool)
+            tot = torch.empty_like(x)
+            if dy is None:
+                check(L.m355_avgpool3d_2x_bwd(_p(dpool), _p(tot), d0.N, d0.C, D, H, W, gpbs, 0, _stream()), "avgpool3d_2x_bwd")
+            else:
+                dy, gsbs = _dense_channels(dy)
+                check(L.m355_avgpool3d_2x_bwd_add(_p(dpool), _p(dy), _p(tot), d0.N, d0.C, D, H, W, gpbs, gsbs, 0,
+                                                  _stream()), "avgpool3d_2x_bwd_add")
+            dy = tot
+        dy, dybs = _dense_channels(dy)
+        d = NormDesc(d0.N, d0.C, d0.S, d0.groups, d0.act, d0.eps, d0.act_slope, d0.x_batch_stride, dybs, 0)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+        check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                  _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
+                                  _stream()), "norm_act_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def norm_act_pool(x, gamma, beta, cfg: NormCfg):
+    """act(norm(x)) AND AvgPool3d(2, 2) of it from one pass -> (y, pooled); fp32 tensors, even spatial sizes."""
+    return _NormActPoolFn.apply(x, gamma, beta, cfg)
 
 
 def norm_act(x, gamma, beta, cfg: NormCfg, add=None):

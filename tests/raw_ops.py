@@ -375,6 +375,16 @@ class RawOps:
                   "norm_act_bwd")
         return dx, dg, db
 
+    def norm_act_pool_fwd(self, x, mean, rstd, gamma, beta, groups, act, eps=1e-5, slope=0.01):
+        """norm + activation with AvgPool3d(2, 2) of the result as second output -> (y, pooled)"""
+        x, mean, rstd, gamma, beta = map(self.to, (x, mean, rstd, gamma, beta))
+        d = self.norm_desc(x, groups, act, eps, slope)
+        N, Cc, D, H, W = x.shape
+        y, pooled = torch.empty_like(x), self.empty(N, Cc, D // 2, H // 2, W // 2)
+        self._chk(self.fn("norm_act_pool_fwd")(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _p(pooled),
+                                               0, D, H, W, self._stream()), "norm_act_pool_fwd")
+        return y, pooled
+
     def norm_act_bwd_h16(self, x, dy, mean, rstd, gamma, beta, groups, act, compute, training=1, eps=1e-5, slope=0.01):
         """norm backward that also emits dx as c8 -> (dx, dgamma, dbeta, dx16 [N, CB, S, 8])"""
         x, dy, mean, rstd, gamma, beta = map(self.to, (x, dy, mean, rstd, gamma, beta))

@@ -613,6 +613,20 @@ def _c8_to_ncdhw(x16, Cc, spatial):
     return x16.float().cpu().permute(0, 1, 3, 2).reshape(N, CB * 8, S)[:, :Cc].reshape(N, Cc, *spatial)
 
 
+def test_norm_act_with_pooled_second_output(hip, oracle):
+    """m355_norm_act_pool_fwd: the encoder block's last normalise + activation pass also emits AvgPool3d(2, 2) of its
+    result == m355_norm_act_fwd followed by m355_avgpool3d_2x_fwd, bit for bit (GroupNorm / BatchNorm geometry,
+    ReLU / LeakyReLU, N = 2, non-cubic even sizes), and == the oracle."""
+    for (N, Cc, D, H, W, groups, act) in [(2, 16, 4, 6, 8, 4, 1), (1, 12, 2, 4, 6, 0, 2), (1, 40, 8, 4, 32, 8, 1), (1, 3, 6, 2, 2, 0, 0)]:
+        x = rnd(N, Cc, D, H, W, seed=1)
+        gamma, beta = rnd(Cc, seed=2) * 0.5 + 1.0, rnd(Cc, seed=3) * 0.1
+        mean, rstd = oracle.norm_stats(x, groups)[:2]
+        y, pooled = hip.norm_act_pool_fwd(x, mean, rstd, gamma, beta, groups, act)
+        y2 = hip.norm_act_fwd(x, mean, rstd, gamma, beta, groups, act)
+        assert torch.equal(y, y2) and torch.equal(pooled, hip.avgpool_fwd(y2))
+        close(pooled, oracle.avgpool_fwd(oracle.norm_act_fwd(x, mean, rstd, gamma, beta, groups, act)), 1e-5, 1e-6, "pooled")
+
+
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
 def test_norm_act_bwd_with_c8_twin(hip, oracle, compute):
     """m355_norm_act_bwd_h16: dx / dgamma / dbeta bit-identical to m355_norm_act_bwd, and the c8 twin of dx == dx
