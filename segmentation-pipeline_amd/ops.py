@@ -649,6 +649,9 @@ class NormCfg:
     out: Optional[OutSlot] = None
     stats: Optional[dict] = None   # partial sums from the producing conv (ops.conv3d(..., stats=...))
     c8: int = 0                    # 16-bit no-grad flow: emit the result ONLY in the c8 layout (compute code)
+    # 16-bit TRAINING flow (H16_TRAIN_C8), set by norm_act() / its autograd function:
+    dx_twin: int = 0               # compute code when the conv that produced x wants its output gradient as c8 too
+    twin: Optional["Act16"] = None  # c8 twin of the fp32 result, handed from the forward to norm_act()
 
 
 def _norm_statistics(L, d, x, cfg, N, Cc, device=None):
@@ -745,7 +748,7 @@ class _NormActFn(torch.autograd.Function):
         # usually consumes it (handed over through `cfg.twin`, attached to the returned tensor by norm_act());
         # ctx.dx_twin: the convolution that produced x wants its output gradient in c8 as well (see backward)
         compute = _COMPUTE[_compute_mode]
-        ctx.dx_twin = getattr(cfg, "dx_twin", 0)
+        ctx.dx_twin = cfg.dx_twin
         cfg.twin = None
         if H16_TRAIN_C8 and compute != _lib.COMPUTE_F32 and cfg.out is None and ybs == Cc * S and Cc > 4:
             cfg.twin = Act16.empty(N, Cc, tuple(x.shape[2:]), compute, x.device)
@@ -853,7 +856,8 @@ def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
     x = as_f32(x)
     cfg.dx_twin = getattr(x, "_m355_c8_grad", 0) if torch.is_grad_enabled() else 0
     y = _NormActFn.apply(x, gamma, beta, as_f32(add) if add is not None else None, cfg)
-    if getattr(cfg, "twin", None) is not None:
+    if cfg.twin is not None:
+        # (the twin describes y as written by this pass; nothing in this package modifies an activation in place)
         y._m355_c8 = cfg.twin
         cfg.twin = None
     return y
