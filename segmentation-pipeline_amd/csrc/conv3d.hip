@@ -1984,8 +1984,11 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     // resident workgroups (LDS + registers: 2 per CU up to NTW = 4); the override exists for the tests
     const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (p.nw == 8 ? 1 : (p.ntw <= 4 ? 2 : 1)) * num_cus());
     const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N * p.ksplit;
+    // single-chunk items (Cin <= 4: the first conv of the network, the data gradient of the output conv) have no
+    // second chunk to hide the queue ticket's round trip or the next item's prefetch behind: the one-shot grid is
+    // faster there (4->32 @128^3: 0.187 vs 0.248 ms)
     p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
-                   tuning().conv_persistent;
+                   tuning().conv_persistent && (ceil_div(p.nchunks, p.ksplit) > 1 || tuning().conv_persistent > 1);
     (void)wtiles;
   }
   // packed weights + 256 B for the work counter of the persistent kernel

@@ -20,10 +20,10 @@ CASES = [  # (N, Cin, Cout, D, H, W, env)
     (1, 96, 32, 64, 64, 64, {"M355_CONV_SLOTS": "37"}),
     (2, 24, 72, 20, 36, 40, {"M355_CONV_SLOTS": "11"}),
     (1, 8, 40, 16, 24, 32, {"M355_CONV_SLOTS": "5", "M355_CONV_KSPLIT": "2"}),
-    (1, 4, 32, 32, 32, 32, {"M355_CONV_SLOTS": "9"}),
+    (1, 4, 32, 32, 32, 32, {"M355_CONV_SLOTS": "9", "M355_CONV_PERSISTENT": "2"}),   # 2: queue-driven even for single-chunk items
 ]
 for N, ci, co, D, H, W, env in CASES:
-    for k in ("M355_CONV_SLOTS", "M355_CONV_KSPLIT"):
+    for k in ("M355_CONV_SLOTS", "M355_CONV_KSPLIT", "M355_CONV_PERSISTENT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     _reload()
