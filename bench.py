@@ -79,8 +79,10 @@ def pmc_traffic(kernel_substr):
             doc = json.load(f)
         if doc.get("source_hash") != source_hash():
             return None
+        # "conv3_mfma_fwd_p_kernel<4, 32>" also has to find "...<4, 32, false>" (trailing template arguments)
+        stem = kernel_substr[:-1] if kernel_substr.endswith(">") else kernel_substr
         for name, rec in doc["kernels"].items():
-            if kernel_substr in name:
+            if kernel_substr in name or (stem + ",") in name:
                 return rec["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass

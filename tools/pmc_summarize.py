@@ -8,6 +8,7 @@ usage: python tools/pmc_summarize.py [gpurun_out/pmc] [profiles/r01_pmc_traffic.
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -15,7 +16,10 @@ from collections import defaultdict
 
 def load(pattern):
     per = defaultdict(lambda: [0.0, 0, 0.0])  # kernel -> [sum counter, launches, sum ms]
-    for fn in glob.glob(pattern, recursive=True):
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    # gpurun MERGES a call's output into the local gpurun_out/: passes of earlier calls (other PIDs in the file name)
+    # pile up next to the new one -- only the newest file of a pass is this measurement
+    for fn in files[-1:]:
         for r in csv.DictReader(open(fn)):
             name = re.sub(r"\(.*", "", r["Kernel_Name"])
             rec = per[name]
