@@ -32,7 +32,7 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}
 HBM_PEAK_GBS = 8000.0
 # m355_conv3d_plan(): kernel family -> kernel name
 PLAN_KERNEL = {1: "conv3_mfma_fwd_kernel", 3: "conv3_mfma_fwd_p_kernel", 2: "conv3_valu_smallcout_kernel",
-               4: "conv3_h16_kernel", 5: "conv3_h16_kernel(8 waves)", 0: "conv3d_direct_kernel"}
+               4: "conv3_h16_kernel", 5: "conv3_h16_kernel(8 waves)", 6: "conv3_h16_kernel(one-shot)", 0: "conv3d_direct_kernel"}
 WORKLOADS = {
     # name: (in_ch, out_ch, filters, depth, patch)
     "cfg2": (4, 3, [32, 64, 128, 256, 320], 5, (128, 128, 128)),
@@ -120,9 +120,17 @@ def kernel_groups(prof, precision):
 
 
 def dominant_keys(prof, precision):
-    """(tag, plan) pairs of the launches of the kernel that accumulates the most time"""
+    """(tag, plan) pairs of the launches of the kernel that accumulates the most time, and a sampling stride: at most
+    ~12 event-timed launches per step (a stride coprime with the launch count walks through all layers over the steps)"""
+    import math
     groups = kernel_groups(prof, precision)
-    return groups[max(groups, key=lambda k: groups[k][2])][4] if groups else None
+    if not groups:
+        return None, 1
+    g = groups[max(groups, key=lambda k: groups[k][2])]
+    n, every = g[3], max(1, -(-g[3] // 12))
+    while every > 1 and math.gcd(every, n) != 1:
+        every += 1
+    return g[4], every
 
 
 def conv_summary_of(prof, steps):
@@ -272,7 +280,7 @@ def main():
     if ops.CONV_PROFILE is not None:
         torch.cuda.synchronize()
         prof_w, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        ops.CONV_PROFILE_KEYS = dominant_keys(prof_w, args.precision)
+        ops.CONV_PROFILE_KEYS, ops.CONV_PROFILE_EVERY = dominant_keys(prof_w, args.precision)
     # A full (generation-2) collection of CPython's cyclic GC walks every object alive -- ~90 ms with torch
     # imported -- and lands at an arbitrary step (measured with tools/step_trace.py: one such host stall drains
     # the launch queue and idles the GPU for ~8 ms; on a 12 ms step that is +2..4 ms/step of noise in a 10-20 step
@@ -306,22 +314,29 @@ def main():
     if not args.no_infer:
         model.eval()
         with torch.no_grad():
-            ops.CONV_PROFILE_KEYS = None
+            ops.CONV_PROFILE_KEYS, ops.CONV_PROFILE_EVERY = None, 1
             for i in range(max(1, args.warmup)):
                 if i == max(1, args.warmup) - 1 and rank == 0:
                     ops.CONV_PROFILE = []
                 model(x)
             if ops.CONV_PROFILE is not None:
                 torch.cuda.synchronize()
-                ops.CONV_PROFILE_KEYS = dominant_keys(ops.CONV_PROFILE, args.precision)
-            ops.CONV_PROFILE = [] if rank == 0 else None
+                ops.CONV_PROFILE_KEYS, _ = dominant_keys(ops.CONV_PROFILE, args.precision)
+            ops.CONV_PROFILE = None
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 model(x)
             barrier()
             ti = time.perf_counter() - t0
+            # roofline of the inference path: the same K forwards once more with the dominant kernel's launches
+            # event-timed (outside the timed loop: in the 16-bit modes ~20 launches of a 2.3 ms forward carry events)
+            ops.CONV_PROFILE = [] if rank == 0 else None
+            for _ in range(args.steps):
+                model(x)
+            torch.cuda.synchronize()
             prof_inf, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+            ops.CONV_PROFILE_KEYS = None
         ti_t = torch.tensor([ti], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(ti_t, op=dist.ReduceOp.MAX)

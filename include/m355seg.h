@@ -166,7 +166,7 @@ int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
  * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA
  * implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel (workgroups walk
- * several tiles), 2 z-Toeplitz small-Cout kernel, 4 the 16-bit operand kernel (persistent), 5 its 8-wave double-buffered variant; out[1] = voxel groups per wave (NTW), out[2] = lanes
+ * several tiles), 2 z-Toeplitz small-Cout kernel, 4 the 16-bit operand kernel (persistent), 5 its 8-wave double-buffered variant, 6 its one-item-per-workgroup variant; out[1] = voxel groups per wave (NTW), out[2] = lanes
  * along x per group (GX), out[3] = split-K factor.  Pure host function. */
 int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4);
 

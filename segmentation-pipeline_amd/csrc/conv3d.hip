@@ -1909,8 +1909,40 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   int chosen = 1, chosen_ks = 1;
   double best = 1e30;
   const int cus = num_cus();
-  for (int i = 0; i < 4 && h16; ++i) {
-    // 16-bit operand modes (LDS / staging-bound kernel, conv3d_h16.hip): fill the chip once, largest tile
+  const bool h16_one = h16 && tuning().h16_oneshot && tuning().h16_oneshot != 3;
+  if (h16_one) {
+    // 16-bit kernels, one item per workgroup (conv3_h16_kernel, ONE): cost model over (tile height, split-K).
+    //   time ~ residencies x (chunks per item x chunk time(NTW) x share + fixed(NTW)) + split-K reduction
+    // chunk time per workgroup with two resident per CU (measured: ~44 % of the MFMA rate at NTW = 4; narrower tiles
+    // re-read the weights more often), `share` < 1 when the launch leaves CUs with a single workgroup, the reduction
+    // pass ~12 us + its slab traffic.  Constants fitted on the cfg2 layers (tools/plan_sweep_h16.py).
+    double best_h = 1e30;
+    for (int ntw : {4, 2, 1}) {
+      if (p.gx == 8 && ntw == 4) continue;                 // not instantiated
+      if (force_ntw && ntw != force_ntw && force_ntw != 8 && !(p.gx == 8 && force_ntw == 4)) continue;
+      const int ty = ntw * gy;
+      if (ty > H && ntw > 1 && !force_ntw) continue;
+      const double chunk_us = ntw == 4 ? 5.8 : (ntw == 2 ? 3.5 : 2.8), fixed_us = ntw == 4 ? 6.0 : (ntw == 2 ? 3.5 : 2.5);
+      const int64_t nwg1 = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+      for (int ks = 1; ks <= std::min(p.nchunks, 8); ++ks) {
+        if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;   // an empty split
+        if (ks > 1 && ks * out_bytes > (128ll << 20)) break;
+        const int64_t nwg = nwg1 * ks;
+        const double per_cu = (double)nwg / cus;
+        const double share = 0.58 + 0.42 * std::min(1.0, std::max(0.0, per_cu - 1.0));
+        const double rounds = std::max(1.0, (double)ceil_div(nwg, 2 * (int64_t)cus));
+        double cost = rounds * ((double)ceil_div(p.nchunks, ks) * chunk_us * share + fixed_us);
+        if (ks > 1) cost += 14.0 + (double)(ks + 1) * (double)out_bytes / 2.5e6;
+        if (cost < best_h * 0.97) {
+          best_h = cost;
+          chosen = ntw;
+          chosen_ks = ks;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < 4 && h16 && !h16_one; ++i) {
+    // 16-bit operand modes, queue-driven kernels (M355_H16_ONESHOT=0 / 3): fill the chip once, largest tile
     // first; the instantiated tiles are NTW <= 4 (<= 2 for 8 lanes along x)
     const int ntw = cands[i];
     if (ntw == 8 || (p.gx == 8 && ntw == 4)) continue;
@@ -1956,7 +1988,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
       }
     }
   }
-  if (h16 && p.gx == 32 && tuning().h16_w8 && D >= 8 && H >= 2) {
+  if (h16 && !h16_one && p.gx == 32 && tuning().h16_w8 && D >= 8 && H >= 2) {
     // 8-wave double-buffered variant (tile 8 x 2 x 32, one workgroup per CU) for SHORT items (<= 4 chunks = 64
     // input channels) whose tiles fill the chip without split-K: there the single-buffered kernel spends as long
     // on chunk boundaries and item switches as on MFMAs (32->32 @128^3: 0.194 -> 0.167 ms, 32->64 @64^3: 0.088 ->
@@ -1971,6 +2003,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
       chosen_ks = 1;
     }
   }
+  if (h16_one) p.oneshot = 1;
   if (force_ks) {
     chosen_ks = std::min(force_ks, p.nchunks);
     while (chosen_ks > 1 && (chosen_ks - 1) * (int)ceil_div(p.nchunks, chosen_ks) >= p.nchunks)
@@ -2564,7 +2597,7 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  out4[0] = d->compute != M355_COMPUTE_F32 ? (p.nw == 8 ? 5 : 4) : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  out4[0] = d->compute != M355_COMPUTE_F32 ? (p.oneshot ? 6 : (p.nw == 8 ? 5 : 4)) : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 

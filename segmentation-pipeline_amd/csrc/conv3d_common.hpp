@@ -139,6 +139,7 @@ struct FwdPlan {
   int otiles, kin_pad, mout_pad, nchunks, ksplit;   // otiles: 32-row output tiles
   int tile16;       // + one 16-row remainder tile at channel 32 * otiles (fp32 path, mout % 32 in 1..16)
   int nw;           // waves per workgroup = z slices of a tile: 4, or 8 (16-bit kernels, double-buffered variant)
+  int oneshot;      // 16-bit kernels: one item per workgroup instead of the work queue (items of 1-2 chunks)
   size_t wp_bytes, slab_bytes;
 };
 

@@ -316,7 +316,11 @@ __device__ unsigned long long m355_h16_stamps[1024][8];
 // chunk is written into the other buffer as soon as its loads have landed, while the other waves keep issuing
 // MFMAs, and a chunk costs one barrier -- the structure of the fp32 kernel (conv3d.hip), which the 16-bit
 // chunks (16x shorter in MFMA time) need even more.
-template <int NTW, int GX, typename HT, bool OUT16, int NW = 4>
+// ONE: one item per workgroup (grid = items), no queue and no prefetch across items.  For items of one or two chunks
+// the chain ticket -> loads -> commit -> MFMAs -> stores of a persistent workgroup is mostly latency (a single-chunk
+// item has ~1 us of MFMAs but costs ~8 us), and what hides latency there is simply MORE independent workgroups:
+// two resident per CU, the next one dispatched by the hardware the moment one retires.
+template <int NTW, int GX, typename HT, bool OUT16, int NW = 4, bool ONE = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void conv3_h16_kernel(
     const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
@@ -457,8 +461,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     const int k = region_static(xl) + taken;
     return k < region_size(xl) ? xl * cpx + k : steal();
   };
-  int it = xl * cpx + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= region_size(xl)) {  // more workgroups than items in this region (uniform)
+  int it = ONE ? (int)blockIdx.x : xl * cpx + (int)(blockIdx.x >> 3);
+  if (!ONE && (int)(blockIdx.x >> 3) >= region_size(xl)) {  // more workgroups than items in this region (uniform)
     if (tid == 0) next_item_s = steal();
     __syncthreads();
     it = next_item_s;
@@ -498,10 +502,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
   f32x16 acc[NTW];
   while (true) {
     int pending = 0;
-    if (tid == 0) pending = atomicAdd(work_counter + xl, 1);
-    if (cur.ch_end - cur.ch_begin == 1) {  // single-chunk items: no chunk to hide the ticket's round trip behind
-      if (tid == 0) next_item_s = resolve(pending);
-      __syncthreads();
+    if constexpr (!ONE) {
+      if (tid == 0) pending = atomicAdd(work_counter + xl, 1);
+      if (cur.ch_end - cur.ch_begin == 1) {  // single-chunk items: no chunk to hide the ticket's round trip behind
+        if (tid == 0) next_item_s = resolve(pending);
+        __syncthreads();
+      }
     }
 #pragma unroll
     for (int g = 0; g < NTW; ++g)
@@ -513,11 +519,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
       if (ch + 1 < cur.ch_end) {
         chunk_setup(cur, ch + 1, true);
       } else {  // last chunk of this item: prefetch the first chunk of the next one
-        nit = next_item_s;
-        const bool live = nit < total;
-        nxt = decode(live ? nit : it);
-        compute_goff(nxt);
-        chunk_setup(nxt, nxt.ch_begin, live);
+        if constexpr (ONE) {
+          nit = total;
+          chunk_setup(cur, cur.ch_begin, false);   // zero-sized descriptor: the unconditional prefetch moves nothing
+        } else {
+          nit = next_item_s;
+          const bool live = nit < total;
+          nxt = decode(live ? nit : it);
+          compute_goff(nxt);
+          chunk_setup(nxt, nxt.ch_begin, live);
+        }
       }
       STAMP(t0);
       const hx8* xb = xs[buf] + xoff;
@@ -589,7 +600,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
+      if constexpr (!ONE) {
+        if (ch == cur.ch_begin && cur.ch_end - cur.ch_begin > 1 && tid == 0) next_item_s = resolve(pending);
+      }
       STAMP(t1);
       if constexpr (DB) {
         STAMP(t2);
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     o[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
   }
 #endif
-  queue_leave(work_counter);
+  if constexpr (!ONE) queue_leave(work_counter);
 }
 
 template <int NTW, int GX, typename HT>
@@ -666,6 +679,20 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
   const int64_t slots = tuning().conv_slots ? tuning().conv_slots : (p.nw == 8 ? 1 : (NTW <= 4 ? 2 : 1)) * num_cus();
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, slots));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
+  {
+    if (p.oneshot) {  // one item per workgroup
+      const unsigned g1 = (unsigned)items;
+      if (out16 && p.ksplit == 1)
+        hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
+                           slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+      else
+        hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
+                           slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+      return;
+    }
+  }
   if constexpr (NTW == 2 && GX == 32) {
     if (p.nw == 8) {  // 8-wave double-buffered variant
       if (out16 && p.ksplit == 1)

@@ -60,6 +60,10 @@ CONV_PROFILE: Optional[list] = None
 # inside its timed region (two timing events around each of the ~56 conv launches of a step are a measurable
 # perturbation of a 12 ms step)
 CONV_PROFILE_KEYS: Optional[set] = None
+# ... and only every CONV_PROFILE_EVERY-th of those launches (a stride coprime with their count per step walks through
+# all layers over a few steps)
+CONV_PROFILE_EVERY = 1
+_prof_seen = 0
 
 
 def _prof_gate(tag, desc=None, which=0):
@@ -70,6 +74,11 @@ def _prof_gate(tag, desc=None, which=0):
     plan = conv_plan(desc, which) if desc is not None else None
     if CONV_PROFILE_KEYS is not None and (tag, plan) not in CONV_PROFILE_KEYS:
         return None, plan
+    if CONV_PROFILE_EVERY > 1:
+        global _prof_seen
+        _prof_seen += 1
+        if _prof_seen % CONV_PROFILE_EVERY:
+            return None, plan
     return prof, plan
 
 

@@ -219,8 +219,8 @@ def test_out_conv_softmax_fused_epilogue_16bit(hip, oracle, compute, tuning):
     """M355_CONV_SOFTMAX on m355_conv3d_fwd_h16 (c8 input, Cout <= 4: the out conv of the 16-bit inference flow): the
     softmax is the kernel's epilogue (all channels of a voxel are registers of one lane) == the same conv followed
     by m355_softmax_fwd, bit for bit; 4-wave and 8-wave kernel variants, ragged volumes, N = 2."""
-    for w8 in (0, 2):
-        tuning(M355_H16_W8=w8, M355_CONV_KSPLIT=1)
+    for w8, one in ((0, 3), (2, 3), (0, 1)):   # queue-driven 4-wave / 8-wave kernels, and the default one-shot variant
+        tuning(M355_H16_W8=w8, M355_H16_ONESHOT=one, M355_CONV_KSPLIT=1)
         for (N, ci, co, D, H, W) in [(1, 32, 3, 8, 16, 64), (2, 8, 2, 9, 10, 36), (1, 16, 4, 8, 8, 32)]:
             x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
             x16 = hip.act16_pack(x, compute)
@@ -540,13 +540,16 @@ def test_act16_pack_unpack_roundtrip(hip, compute):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5"}, {"M355_CONV_SLOTS": "3", "M355_CONV_KSPLIT": "2"},
-                                 {"M355_CONV_NTW": "1"}, {"M355_CONV_NTW": "2", "M355_CONV_SLOTS": "7"}])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_SLOTS": "5", "M355_H16_ONESHOT": "3"},
+                                 {"M355_CONV_SLOTS": "3", "M355_CONV_KSPLIT": "2", "M355_H16_ONESHOT": "3"},
+                                 {"M355_CONV_NTW": "1"}, {"M355_CONV_NTW": "2", "M355_CONV_SLOTS": "7", "M355_H16_ONESHOT": "3"},
+                                 {"M355_CONV_KSPLIT": "3"}])
 def test_conv3d_h16_c8_input_persistent_and_fused_statistics(hip, oracle, compute, env, tuning):
     """m355_conv3d_fwd_h16 / m355_conv3d_bwd_data_h16 on c8 tensors (the model path of the 16-bit modes): equal to
     the oracle run with operands rounded to the same 16-bit type (only the fp32 accumulation order differs);
     ragged volumes, N = 2, odd channel-block counts, strided batches, tiny residencies (every workgroup walks
-    many queue items), split-K, and the statistics of the following normalisation fused into the epilogue."""
+    many queue items: M355_H16_ONESHOT=3 selects the queue-driven kernels, the default is one item per workgroup),
+    split-K, and the statistics of the following normalisation fused into the epilogue."""
     tuning(**{"M355_CONV_KSPLIT": 1, **env})  # the planner would split K on volumes this small: no fused statistics
     for (N, ci, co, D, H, W, groups) in [(2, 12, 40, 9, 10, 36, 8), (1, 24, 33, 6, 21, 16, None), (1, 8, 8, 12, 9, 8, 0),
                                         (1, 40, 16, 8, 8, 32, 4)]:
@@ -586,7 +589,8 @@ def test_conv3d_h16_eight_wave_double_buffered_variant(hip, oracle, compute, env
         x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
         out = {}
         for w8 in (2, 0):
-            tuning(**{"M355_H16_W8": w8, "M355_CONV_KSPLIT": 1, **env})  # (the planner would split K on these volumes)
+            # queue-driven plans (M355_H16_ONESHOT=3); the planner would split K on these volumes
+            tuning(**{"M355_H16_W8": w8, "M355_H16_ONESHOT": 3, "M355_CONV_KSPLIT": 1, **env})
             fused = groups is not None and "M355_CONV_KSPLIT" not in env
             if fused:
                 y, mean, rstd = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute, groups=groups)
@@ -606,6 +610,15 @@ def test_conv3d_h16_eight_wave_double_buffered_variant(hip, oracle, compute, env
                     close(rstd, r2, 1e-5, 1e-6, "fused rstd")
         for a, bb, what in zip(out[2], out[0], ("fwd", "c8 out", "bwd_data")):
             assert torch.equal(a, bb), f"8-wave {what} != 4-wave {what} (same k order: must be bit-identical)"
+        # and the default one-item-per-workgroup variant of the same kernel
+        tuning(**{"M355_H16_ONESHOT": 2, "M355_CONV_KSPLIT": 1, **{k: v for k, v in env.items() if k != "M355_CONV_SLOTS"}})
+        assert hip.conv_plan((N, ci, D, H, W), co, compute)[0] == 6
+        one = (hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute),
+               hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute),
+               hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
+        if "M355_CONV_KSPLIT" not in env:
+            for a, bb, what in zip(one, out[0], ("fwd", "c8 out", "bwd_data")):
+                assert torch.equal(a, bb), f"one-shot {what} != queue-driven {what}"
 
 
 def _c8_to_ncdhw(x16, Cc, spatial):
@@ -674,8 +687,8 @@ def test_norm_act_and_avgpool_c8_outputs(hip, oracle, compute):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("env", [{"M355_CONV_KSPLIT": "1"}, {"M355_CONV_KSPLIT": "2", "M355_CONV_SLOTS": "5"},
-                                 {"M355_CONV_KSPLIT": "1", "M355_CONV_NTW": "1"}])
+@pytest.mark.parametrize("env", [{"M355_CONV_KSPLIT": "1"}, {"M355_CONV_KSPLIT": "2", "M355_CONV_SLOTS": "5", "M355_H16_ONESHOT": "3"},
+                                 {"M355_CONV_KSPLIT": "1", "M355_CONV_NTW": "1"}, {"M355_CONV_KSPLIT": "2"}])
 def test_conv3d_h16_c8_output_and_c8_norm(hip, oracle, compute, env, tuning):
     """m355_conv3d_fwd_h16_c8: the epilogue writes c8 (lanes exchange channel halves with v_permlane32_swap) ==
     the fp32-output kernel's result rounded once; statistics fused (fp32, before rounding: conv epilogue, or the

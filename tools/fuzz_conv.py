@@ -54,7 +54,7 @@ def fuzz_h16(cases, rng):
     variants, tiny residencies, split-K, tile heights) against the oracle on rounded operands."""
     hip, oracle = RawOps("hip"), RawOps("oracle")
     worst = 0.0
-    knobs = ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_H16_W8", "M355_BWW_NSPLIT")
+    knobs = ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_H16_W8", "M355_H16_ONESHOT", "M355_BWW_NSPLIT")
     for i in range(cases):
         compute = rng.choice([1, 2])
         dt = torch.bfloat16 if compute == 1 else torch.float16
@@ -68,7 +68,8 @@ def fuzz_h16(cases, rng):
             env["M355_CONV_NTW"] = str(rng.choice([1, 2, 4]))
         if rng.random() < 0.5:
             env["M355_CONV_KSPLIT"] = str(rng.choice([1, 1, 2, 3]))
-        if rng.random() < 0.6:
+        if rng.random() < 0.5:   # the queue-driven kernels (4-wave / 8-wave) instead of the default one-shot variant
+            env["M355_H16_ONESHOT"] = "3"
             env["M355_H16_W8"] = str(rng.choice([0, 2, 2]))
         if rng.random() < 0.4:
             env["M355_BWW_NSPLIT"] = str(rng.choice([1, 2, 5]))
