@@ -2020,8 +2020,11 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     // single-chunk items (Cin <= 4: the first conv of the network, the data gradient of the output conv) have no
     // second chunk to hide the queue ticket's round trip or the next item's prefetch behind: the one-shot grid is
     // faster there (4->32 @128^3: 0.187 vs 0.248 ms)
-    p.persistent = compute == M355_COMPUTE_F32 && items > slots && items < (1ll << 31) &&
-                   tuning().conv_persistent && (ceil_div(p.nchunks, p.ksplit) > 1 || tuning().conv_persistent > 1);
+    // ... and the queue only pays from ~4 residencies of items on (128^3 levels): with 1.5-3 residencies the one-shot
+    // grid, whose workgroups the hardware hands out as CUs free up, is 3-7 % faster (192->64 @64^3: 1.237 -> 1.195 ms)
+    p.persistent = compute == M355_COMPUTE_F32 && items < (1ll << 31) && tuning().conv_persistent &&
+                   (tuning().conv_persistent > 1 ? items > slots
+                                                 : (items >= 4 * slots && ceil_div(p.nchunks, p.ksplit) > 1));
     (void)wtiles;
   }
   // packed weights + 256 B for the work counter of the persistent kernel
