@@ -2020,11 +2020,12 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     // single-chunk items (Cin <= 4: the first conv of the network, the data gradient of the output conv) have no
     // second chunk to hide the queue ticket's round trip or the next item's prefetch behind: the one-shot grid is
     // faster there (4->32 @128^3: 0.187 vs 0.248 ms)
-    // ... and the queue only pays from ~4 residencies of items on (128^3 levels): with 1.5-3 residencies the one-shot
-    // grid, whose workgroups the hardware hands out as CUs free up, is 3-7 % faster (192->64 @64^3: 1.237 -> 1.195 ms)
+    // ... and the queue only pays beyond two residencies of items: up to there the one-shot grid, whose workgroups
+    // the hardware hands out as CUs free up, is 3-7 % faster (192->64 @64^3, 2.0 residencies: 1.237 -> 1.195 ms;
+    // 128->384 @32^3, 1.5: 0.672 -> 0.628); from 3.4 residencies (40->40 @96^3) the queue wins by 7-9 %
     p.persistent = compute == M355_COMPUTE_F32 && items < (1ll << 31) && tuning().conv_persistent &&
                    (tuning().conv_persistent > 1 ? items > slots
-                                                 : (items >= 4 * slots && ceil_div(p.nchunks, p.ksplit) > 1));
+                                                 : (items > 2 * slots && ceil_div(p.nchunks, p.ksplit) > 1));
     (void)wtiles;
   }
   // packed weights + 256 B for the work counter of the persistent kernel
@@ -2079,7 +2080,9 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
   if constexpr (NTW <= 4) {
     if (p.tile16) {  // the 16-row remainder tile: queue-driven kernel over (spatial tile x sample x split) items
       const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * N * p.ksplit;
-      hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, true>), dim3((unsigned)std::min<int64_t>(items, slots)),
+      // (up to two residencies one workgroup per item: see plan_mfma)
+      const int64_t g16 = (items <= 2 * slots && tuning().conv_persistent < 2) ? items : std::min<int64_t>(items, slots);
+      hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, true>), dim3((unsigned)g16),
                          dim3(256), 0, st, x, wp, bias, add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles,
                          p.ty_tiles, p.tx_tiles, 1, p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter,
                          32 * p.otiles);
