@@ -153,17 +153,17 @@ __global__ __launch_bounds__(256) void norm_from_partials_kernel(
 // The same for statistics with few partial items (<= 8192: every level below 64^3 of a U-Net), finalize included:
 // one block per statistic sums ALL its items and writes mean / rstd (and the BatchNorm running statistics) itself,
 // so the pair of latency-bound launches (~8 + ~5 us) is one.
-__global__ __launch_bounds__(256) void norm_from_partials_final_kernel(
+__global__ __launch_bounds__(1024) void norm_from_partials_final_kernel(
     const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, int groups, int N, int C, int64_t slots, int64_t count) {
-  __shared__ double scratch[4];
+  __shared__ double scratch[16];   // 1024 threads: the pass is a latency chain, 8 items per thread keep it short
   const int64_t s = blockIdx.x;
   const int cg = groups == 0 ? 1 : C / groups;
   const int c_begin = groups == 0 ? (int)s : (int)(s % groups) * cg;
   const int64_t n_begin = groups == 0 ? 0 : s / groups, runs = groups == 0 ? N : 1;
   const int64_t per_n = slots * cg, items = runs * per_n;
   double t1 = 0.0, t2 = 0.0;
-  for (int64_t i = threadIdx.x; i < items; i += 256) {
+  for (int64_t i = threadIdx.x; i < items; i += 1024) {
     const int64_t run = i / per_n, j = i - run * per_n;
     const int64_t slot = j / cg;
     const int c = c_begin + (int)(j - slot * cg);
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void norm_from_partials_final_kernel(
     t1 += (double)v.x;
     t2 += (double)v.y;
   }
-  t1 = block_sum<double, 256>(t1, scratch);
-  t2 = block_sum<double, 256>(t2, scratch);
+  t1 = block_sum<double, 1024>(t1, scratch);
+  t2 = block_sum<double, 1024>(t2, scratch);
   if (threadIdx.x != 0) return;
   const double m = t1 / (double)count;
   double var = t2 / (double)count - m * m;
@@ -514,7 +514,7 @@ extern "C" int m355_norm_stats_from_partials(const m355_norm_desc* d, const floa
   // blocks per statistic: ~2048 partial items each, never more than the workspace of norm_stats holds
   const int64_t items = (d->groups == 0 ? (int64_t)d->N : 1) * slots * (d->groups == 0 ? 1 : d->C / d->groups);
   if (items <= 8192) {
-    hipLaunchKernelGGL(norm_from_partials_final_kernel, dim3((unsigned)g.nstats), dim3(256), 0, st, stat_partials, mean,
+    hipLaunchKernelGGL(norm_from_partials_final_kernel, dim3((unsigned)g.nstats), dim3(1024), 0, st, stat_partials, mean,
                        rstd, running_mean, running_var, momentum, d->eps, d->groups, d->N, d->C, slots, g.count);
     return check_launch("norm_stats_from_partials");
   }
