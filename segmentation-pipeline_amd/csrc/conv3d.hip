@@ -2536,15 +2536,20 @@ static int bww_c8_nsplit(const m355_conv3d_desc* d) {
   const int64_t pairs = ceil_div(d->Cin, 32) * ceil_div(d->Cout, 32);
   const int64_t slots = 2 * (int64_t)num_cus();
   if (const int force = tuning().bww_nsplit) return (int)std::min<int64_t>(force, ntiles);
-  // time ~ residencies x (tiles per split x ~1.8 us (two workgroups share a CU) + ~4 us pipeline fill and slab
-  // write) + the reduction's read of nsplit slabs at ~4 TB/s
-  const double slab_us = (double)d->Cout * d->Cin * 27 * 4 / 4.0e6;
+  // time ~ residencies x (tiles per split x tile time + ~4 us pipeline fill and slab write) + the slab traffic (written
+  // by the kernel, read by the reduction).  Tile time ~1.8 us with two workgroups sharing a CU, ~1.1 us alone: for few
+  // pairs one workgroup per CU with half the slabs wins (32->32 @128^3: 256 splits 170 us, 512 splits 184 us), for many
+  // tiles per pair two per CU do (tools/plan_sweep_bww_c8.py).
+  const double slab_us = 2.0 * (double)d->Cout * d->Cin * 27 * 4 / 4.0e6;
   double best = 1e30;
   int64_t best_ns = 1;
-  for (int r = 1; r <= 4; ++r) {
-    const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots * r / pairs));
-    const double rounds = (double)ceil_div(pairs * ns, slots);
-    const double cost = rounds * ((double)ceil_div(ntiles, ns) * 1.8 + 4.0) + (double)ns * slab_us;
+  for (int h = pairs <= 2 ? 1 : 2; h <= 8; ++h) {   // h half-residencies: 256, 512, 768, ... workgroups (one per CU
+                                                    // only pays for one or two pairs: more pairs share tiles in L2)
+    const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots * h / (2 * pairs)));
+    const int64_t wgs = pairs * ns;
+    const double rounds = (double)ceil_div(wgs, slots);
+    const double tile_us = wgs * 2 <= slots ? 1.1 : (wgs >= slots ? 1.8 : 1.1 + 0.7 * (double)(wgs * 2 - slots) / (double)slots);
+    const double cost = rounds * ((double)ceil_div(ntiles, ns) * tile_us + 4.0) + (double)ns * slab_us;
     if (cost < best * 0.97) {
       best = cost;
       best_ns = ns;
