@@ -280,10 +280,13 @@ def _packed_weight(weight, d, which):
 def _c8_twin(t, compute):
     """the c8 twin a producer pass attached to this fp32 tensor (norm_act forward / backward in the 16-bit
     training flow), if it describes exactly this tensor"""
-    tw = getattr(t, "_m355_c8", None)
-    if tw is not None and tw.compute == compute and tw.shape == tuple(t.shape) and tw.device == t.device:
+    rec = getattr(t, "_m355_c8", None)
+    if rec is None:
+        return None
+    tw, version = rec
+    if (version == t._version and tw.compute == compute and tw.shape == tuple(t.shape) and tw.device == t.device):
         return tw
-    return None
+    return None   # (an in-place op on the fp32 tensor since the twin was written bumps _version: the twin is stale)
 
 
 def _with_flags(d, flags):
@@ -788,7 +791,7 @@ class _NormActFn(torch.autograd.Function):
                                           _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, dx16.ptr(),
                                           dx16.batch_stride(), ctx.dx_twin, _p(ws), ws.numel(), _stream()),
                   "norm_act_bwd_h16")
-            dx._m355_c8 = dx16
+            dx._m355_c8 = (dx16, dx._version)
         else:
             check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
                                       _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
@@ -866,8 +869,8 @@ def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
     cfg.dx_twin = getattr(x, "_m355_c8_grad", 0) if torch.is_grad_enabled() else 0
     y = _NormActFn.apply(x, gamma, beta, as_f32(add) if add is not None else None, cfg)
     if cfg.twin is not None:
-        # (the twin describes y as written by this pass; nothing in this package modifies an activation in place)
-        y._m355_c8 = cfg.twin
+        # the twin describes y as written by this pass: recorded with y's version, so an in-place op on y voids it
+        y._m355_c8 = (cfg.twin, y._version)
         cfg.twin = None
     return y
 

@@ -828,6 +828,25 @@ def test_fp16_precision_mode_end_to_end(golden):
         assert cos > 0.98, (k, cos.item())   # bf16 mode: 0.95
 
 
+def test_c8_twin_of_the_training_flow_is_voided_by_in_place_modification():
+    """16-bit training flow: norm_act attaches the c8 twin of its fp32 result for the convolution that follows
+    (ops._c8_twin).  The convolution must use it (same bits as packing the tensor itself) and must NOT use it after the
+    fp32 tensor was modified in place (the twin is recorded with the tensor's version)."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd import ops, _lib
+    with sp.precision("bf16"):
+        x = rnd(1, 16, 8, 8, 32, seed=1).cuda().requires_grad_()
+        gamma, beta = torch.ones(16, device="cuda"), torch.zeros(16, device="cuda")
+        w = (rnd(8, 16, 3, 3, 3, seed=2) * 0.1).cuda().requires_grad_()
+        y = ops.norm_act(x, gamma, beta, ops.NormCfg(groups=4, eps=1e-5, act=_lib.ACT_RELU))
+        assert ops._c8_twin(y, _lib.COMPUTE_BF16) is not None, "norm_act did not attach a twin in the 16-bit training flow"
+        assert torch.equal(ops.conv3d(y, w), ops.conv3d(y.detach().clone(), w)), "conv from the twin != conv from the packed tensor"
+        with torch.no_grad():
+            y.mul_(2.0)
+        assert ops._c8_twin(y, _lib.COMPUTE_BF16) is None, "a stale twin survived an in-place modification"
+        assert torch.equal(ops.conv3d(y, w), ops.conv3d(y.detach().clone(), w))
+
+
 def test_bf16_precision_mode_end_to_end(golden):
     """cfg3-family precision mode on the small north-star model: probabilities within 2e-2 and soft
     Dice within 1e-3 of the fp32 reference golden (tolerances stated for the bf16 configs in SURVEY §8d);
