@@ -14,7 +14,7 @@ S = 128
 x4 = hip.act16_pack(torch.randn(1, 4, S, S, S, device="cuda"), 1); w4 = torch.randn(32, 4, 3, 3, 3, device="cuda") * .05
 x32 = hip.act16_pack(torch.randn(1, 32, S, S, S, device="cuda"), 1); w3 = torch.randn(3, 32, 3, 3, 3, device="cuda") * .05
 x32b = hip.act16_pack(torch.randn(1, 32, S, S, S, device="cuda"), 1); w32 = torch.randn(32, 32, 3, 3, 3, device="cuda") * .05
-for env in ({}, {"M355_H16_ONESHOT": "0"}, {"M355_H16_ONESHOT": "0", "M355_H16_W8": "0"}):
+for env in ({}, {"M355_CONV_NTW": "2"}, {"M355_CONV_NTW": "1"}, {"M355_H16_ONESHOT": "3"}):
     for k in ("M355_H16_W8", "M355_CONV_NTW", "M355_CONV_SLOTS", "M355_H16_ONESHOT"): os.environ.pop(k, None)
     os.environ.update(env); _lib.reload_tuning()
     a = t(lambda: hip.conv3d_fwd_h16_c8(x4, 4, (S, S, S), w4, compute=1))
