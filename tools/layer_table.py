@@ -39,20 +39,25 @@ def step():
     opt.step()
 
 
-for _ in range(2):
+import gc  # noqa: E402
+import statistics  # noqa: E402
+for _ in range(4):
     step()
+gc.collect()
+gc.freeze()          # (a full collection of the cyclic GC stalls the launch thread ~90 ms: see bench.py)
+STEPS = 5
 ops.CONV_PROFILE = []
-for _ in range(3):
+for _ in range(STEPS):
     step()
 torch.cuda.synchronize()
 prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-groups = {}
+samples = {}
 for (tag, flops, e0, e1, plan, nbytes) in prof:
-    g = groups.setdefault((tag, round(flops / 1e9, 2), round(nbytes / 1e6, 1), plan), [0.0, 0])
-    g[0] += e0.elapsed_time(e1)
-    g[1] += 1
-tot = sum(g[0] for g in groups.values()) / 3
+    samples.setdefault((tag, round(flops / 1e9, 2), round(nbytes / 1e6, 1), plan), []).append(e0.elapsed_time(e1))
+# per launch: the MEDIAN over the steps (an event pair also spans host-side stalls between the two records)
+groups = {k: [statistics.median(v) * len(v), len(v)] for k, v in samples.items()}
+tot = sum(g[0] for g in groups.values()) / STEPS
 print(f"{which}: conv launches of one train step, {tot:.2f} ms (event-timed, includes packing / reductions)")
 for (tag, gf, mb, plan), (ms, n) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
-    print(f"  {tag:18s} {gf:8.2f} GF {mb:7.1f} MB plan {str(plan):18s} x{n // 3:<3d} {ms / n:7.3f} ms  {gf / (ms / n):7.1f} TF/s  "
-          f"{ms / 3:7.2f} ms/step")
+    print(f"  {tag:18s} {gf:8.2f} GF {mb:7.1f} MB plan {str(plan):18s} x{n // STEPS:<3d} {ms / n:7.3f} ms  {gf / (ms / n):7.1f} TF/s  "
+          f"{ms / STEPS:7.2f} ms/step")
