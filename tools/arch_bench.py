@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Step time of the two architectures the reference actually trained."""
+"""Step time of the two architectures the reference actually trained.
+usage: python tools/arch_bench.py [msseg2|dmri_hippo|all] [fp32|bf16|fp16]"""
 import os, sys, time, torch
 from torch import nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +26,12 @@ def run(name, model, shape, ncls, cw=None, steps=3):
         torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
     print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)", flush=True)
 
-only = sys.argv[1] if len(sys.argv) > 1 else ""   # "msseg2" / "dmri_hippo": run one of the two (profiling)
+only = sys.argv[1] if len(sys.argv) > 1 else ""   # "msseg2" / "dmri_hippo" / "all": run one of the two (profiling)
+only = "" if only == "all" else only
+if len(sys.argv) > 2:                              # precision mode: fp32 (default) | bf16 | fp16
+    import segmentation_pipeline_amd as sp
+    sp.set_precision(sys.argv[2])
+    print(f"[precision {sys.argv[2]}]", flush=True)
 torch.manual_seed(0)
 if only in ("", "msseg2"):
   run("msseg2 ModularUNet(2,2,[40,40,80,80,120,120],6,residual,Blur) 1x2x96^3",

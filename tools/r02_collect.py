@@ -43,6 +43,7 @@ if "b" in which:
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summarize.py"), os.path.join(ROOT, "gpurun_out", "pmc"),
                            os.path.join(DST, "r02_pmc_traffic.json")], stdout=subprocess.DEVNULL)
     text("arch.log", "r02_arch_bench.txt")
+    text("arch_bf16.log", "r02_arch_bench_bf16.txt")
     text("layers_cfg2.log", "r02_cfg2_fp32_per_layer.txt")
     text("layers_msseg2.log", "r02_msseg2_per_layer.txt")
     text("conv_fp32.log", "r02_fp32_conv_per_layer.txt")

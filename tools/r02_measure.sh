@@ -18,6 +18,7 @@ case "${1:-a}" in
   b)
     step pmc 900 bash tools/pmc_collect.sh
     step arch 300 python tools/arch_bench.py
+    step arch_bf16 300 python tools/arch_bench.py all bf16
     step layers_cfg2 200 python tools/layer_table.py cfg2
     step layers_msseg2 200 python tools/layer_table.py msseg2
     step conv_fp32 200 python tools/conv_bench.py
