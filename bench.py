@@ -144,7 +144,7 @@ def conv_summary_of(prof, steps):
             for k, v in by_tag.items()}
 
 
-def roofline_of(prof, precision):
+def roofline_of(prof, precision, full_prof=None):
     """Roofline object of the dominant conv kernel of a timed region.  prof: ops.CONV_PROFILE entries
     (tag, flops, e0, e1, plan, bytes).  Kernels are grouped by (kernel name, tile variant); the group with
     the most accumulated time is the dominant kernel.  bound = whichever of algorithmic-bytes / 8 TB/s and
@@ -154,6 +154,10 @@ def roofline_of(prof, precision):
         return None
     key = max(groups, key=lambda k: groups[k][2])
     flops, nbytes, ms, n = groups[key][:4]
+    # share of the conv time: from the launch-by-launch profile of a whole step when there is one (inside the timed
+    # region only this kernel carries events)
+    fg = kernel_groups(full_prof, precision) if full_prof else groups
+    share = (fg[key][2] if key in fg else ms) / sum(g[2] for g in fg.values())
     peak_tf = PEAK_TFLOPS[precision]
     t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
     kname = key[0] + key[1]
@@ -166,7 +170,7 @@ def roofline_of(prof, precision):
     out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", ")), "kernel": kname, "launches": n,
                 "avg_launch_ms": ms / n, "avg_gflop_per_launch": flops / n / 1e9,
                 "avg_algorithmic_mb_per_launch": nbytes / n / 1e6,
-                "time_share_of_conv": ms / sum(g[2] for g in groups.values())})
+                "time_share_of_conv": share})
     return out
 
 
@@ -345,7 +349,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant conv kernel of the timed train region (and of the inference region) ----
-        roofline = roofline_of(prof, args.precision)
+        roofline = roofline_of(prof, args.precision, prof_w)
         if infer is not None and prof_inf:
             infer["roofline"] = roofline_of(prof_inf, args.precision)
         # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
