@@ -31,6 +31,7 @@ static Tuning read_tuning() {
   t.convt_h16 = env_int("M355_CONVT_H16", 1);
   t.h16_w8 = env_int("M355_H16_W8", 1);
   t.h16_oneshot = env_int("M355_H16_ONESHOT", 1);
+  t.h16_xcd = env_int("M355_H16_XCD", 1);
   t.fuse_softmax = env_int("M355_FUSE_SOFTMAX", 1);
   t.h16_stagger = env_int("M355_H16_STAGGER", 2);
   return t;

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   const int l32 = lane & 31;
   const int ly = l32 / GX, lx = l32 % GX;
 
+  // XCD-aware placement (speed only, a bijection of the grid's x range): workgroups are dealt to the 8 XCDs round-robin
+  // in launch order (x fastest); when the spatial-tile count is a multiple of 8 every XCD gets a contiguous run of
+  // tiles, whose shared halos then hit in its L2
   int bt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bt = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
   const int txt = bt % tx_tiles;
   bt /= tx_tiles;
   const int tyt = bt % ty_tiles;
@@ -751,7 +755,15 @@ __global__ __launch_bounds__(256, 2) void conv3_valu_smallcout_kernel(
   __shared__ __attribute__((aligned(16))) float xs[XE];
   const int tid = threadIdx.x;
   const int tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
-  int bt = blockIdx.x;
+  // XCD-aware placement (speed only, a bijection of the grid): blocks b and b + 8 share an XCD and its L2; give each
+  // XCD a contiguous run of tiles, so that the 1.9x halo overlap of neighbouring tiles hits in that L2 instead of
+  // being fetched from HBM again (PMC: 543 MB per launch for 293 MB of algorithmic bytes before)
+  int bt;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int txt = bt % tx_tiles;
   bt /= tx_tiles;
   const int tyt = bt % ty_tiles;

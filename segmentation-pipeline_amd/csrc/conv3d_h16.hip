@@ -461,7 +461,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     const int k = region_static(xl) + taken;
     return k < region_size(xl) ? xl * cpx + k : steal();
   };
-  int it = ONE ? (int)blockIdx.x : xl * cpx + (int)(blockIdx.x >> 3);
+  // (ONE: XCD-aware placement -- blocks b and b + 8 share an XCD and its L2, so every XCD gets a contiguous run of
+  // items and the halos that neighbouring tiles share hit in that L2)
+  int it = xl * cpx + (int)(blockIdx.x >> 3);
+  if constexpr (ONE) {
+    const int q = G >> 3, r = G & 7;
+    it = stagger ? (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  }
   if (!ONE && (int)(blockIdx.x >> 3) >= region_size(xl)) {  // more workgroups than items in this region (uniform)
     if (tid == 0) next_item_s = steal();
     __syncthreads();
@@ -685,11 +691,11 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
       if (out16 && p.ksplit == 1)
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax);
       else
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax);
       return;
     }
   }
