@@ -32,6 +32,8 @@ static Tuning read_tuning() {
   t.h16_w8 = env_int("M355_H16_W8", 1);
   t.h16_oneshot = env_int("M355_H16_ONESHOT", 1);
   t.h16_xcd = env_int("M355_H16_XCD", 1);
+  t.conv_cube = env_int("M355_CONV_CUBE", 3);
+  t.h16_order = env_int("M355_H16_ORDER", 3);
   t.fuse_softmax = env_int("M355_FUSE_SOFTMAX", 1);
   t.h16_stagger = env_int("M355_H16_STAGGER", 2);
   return t;

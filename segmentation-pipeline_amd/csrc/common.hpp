@@ -67,6 +67,7 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
 struct Tuning {
   int conv_ntw = 0, conv_ksplit = 0, conv_slots = 0, conv_persistent = 1;
   int no_small = 0, smallcout_valu = 1, bww_nsplit = 0, bww_gen = 2, bww_queue = 1, h16_persistent = 1, tile16 = 1, convt_h16 = 1, h16_w8 = 1, h16_oneshot = 1, h16_xcd = 1;
+  int conv_cube = 3, h16_order = 3;   // item order of the conv kernels: bit 0 = (y, z) tiles in 4x4 cubes, bit 1 = channel tile fastest
   int fuse_softmax = 1;
   int h16_stagger = 2;   // 16-bit conv kernel: start offset of the odd workgroup of a CU, in units of 1024 cycles
 };

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int ty_tiles, int tx_tiles, int nchunks,
-    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride, float* __restrict__ stat) {
+    int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int otiles, int order) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS = T::CS, CC = T::CC;
@@ -73,16 +73,22 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   const int ly = l32 / GX, lx = l32 % GX;
 
   // XCD-aware placement (speed only, a bijection of the grid's x range): workgroups are dealt to the 8 XCDs round-robin
-  // in launch order (x fastest); when the spatial-tile count is a multiple of 8 every XCD gets a contiguous run of
-  // tiles, whose shared halos then hit in its L2
+  // in launch order (x fastest); when the workgroup count along x is a multiple of 8 every XCD gets a contiguous run
+  // of tiles, whose shared halos then hit in its L2.  The channel tile is the FASTEST index of x: the workgroups that
+  // need the same input tile for different output channels run side by side on one XCD (the channel tile as the
+  // outer index made every pass over the channel tiles re-read the whole input from HBM).
   int bt = blockIdx.x;
   if ((gridDim.x & 7) == 0) bt = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int sp_count = (int)gridDim.x / otiles;
+  const int otile = (order & 2) ? bt % otiles : bt / sp_count;
+  bt = (order & 2) ? bt / otiles : bt % sp_count;
+  const int sp_index = bt;   // spatial tile (statistics slot)
   const int txt = bt % tx_tiles;
   bt /= tx_tiles;
   const int tyt = bt % ty_tiles;
   const int tzt = bt / ty_tiles;
   const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
-  const int o0 = blockIdx.y * 32;
+  const int o0 = otile * 32;
   const int n = blockIdx.z / ksplit;
   const int ks = blockIdx.z % ksplit;
 
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   const bool lane_ok = z < D && xg < W;
   if (ksplit == 1) {
     // statistics slot of this wave: stat[n][spatial tile * 4 + wave][Cout][2]
-    float* st = stat ? stat + (((int64_t)n * gridDim.x + blockIdx.x) * 4 + wave) * Cout * 2 : nullptr;
+    float* st = stat ? stat + (((int64_t)n * sp_count + sp_index) * 4 + wave) * Cout * 2 : nullptr;
     store_conv_tile<NTW, GY>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z,
                              y0, xg, ly, half, D, H, W, lane_ok, st);
   } else {
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin,
     int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles,
     int nchunks, int ksplit, int nbatch, int64_t xbs, int64_t ybs, int64_t slab_stride,
-    float* __restrict__ stat, int* __restrict__ work_counter, int o_base) {
+    float* __restrict__ stat, int* __restrict__ work_counter, int o_base, int order) {
   using T = FwdTile<NTW, GX>;
   constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS,
                 CS0 = T::CS, CC = T::CC;
@@ -339,17 +345,33 @@ __global__ __launch_bounds__(256, (NTW <= 4 ? 2 : 1)) void conv3_mfma_fwd_p_kern
   struct Item {
     int z0, y0, x0, o0, n, ks, ch_begin, ch_end, sp;
   };
+  // Tile order inside a region: the ~64 items in flight on one XCD should form a CUBE of tiles (all x, 4 y, 4 z), not
+  // a slab one tile thick: with the linear (x, y, z) order every tile's two z-halo planes (a third of its input) are
+  // re-read from HBM when the next slab comes around (PMC: 1.6x the algorithmic bytes); in the blocked order they
+  // are shared with a z neighbour that is in flight at the same time.  A bijection of the item range: results unchanged.
+  const bool cube = (ty_tiles & 3) == 0 && (tz_tiles & 3) == 0 && (order & 1);
   auto decode = [&](int it) {
     Item q;
-    int sp = it % sp_tiles, r = it / sp_tiles;
-    q.sp = sp;
+    // channel tile fastest (the items that share an input tile are adjacent: same XCD, same time), then the spatial tile
+    const int ot = (order & 2) ? it % otiles : (it / sp_tiles) % otiles;
+    int sp = (order & 2) ? (it / otiles) % sp_tiles : it % sp_tiles, r = it / (otiles * sp_tiles);
     const int txt = sp % tx_tiles;
     sp /= tx_tiles;
+    int tyt, tzt;
+    if (cube) {   // sp = ((tz_hi * (ty_tiles / 4) + ty_hi) * 4 + tz_lo) * 4 + ty_lo
+      const int ty_lo = sp & 3, tz_lo = (sp >> 2) & 3, hi = sp >> 4;
+      const int tyh = ty_tiles >> 2;
+      tyt = (hi % tyh) * 4 + ty_lo;
+      tzt = (hi / tyh) * 4 + tz_lo;
+    } else {
+      tyt = sp % ty_tiles;
+      tzt = sp / ty_tiles;
+    }
+    q.sp = (tzt * ty_tiles + tyt) * tx_tiles + txt;   // canonical tile index (statistics slot)
     q.x0 = txt * TX;
-    q.y0 = (sp % ty_tiles) * TY;
-    q.z0 = (sp / ty_tiles) * TZ;
-    q.o0 = o_base + (r % otiles) * 32;
-    r /= otiles;
+    q.y0 = tyt * TY;
+    q.z0 = tzt * TZ;
+    q.o0 = o_base + ot * 32;
     q.ks = r % ksplit;
     q.n = r / ksplit;
     q.ch_begin = q.ks * cps;
@@ -2074,19 +2096,18 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D,
                        int H, int W, int64_t xbs, int64_t ybs, hipStream_t st, float* stat = nullptr,
                        int* work_counter = nullptr) {
-  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles), (unsigned)p.otiles,
-            (unsigned)(N * p.ksplit));
+  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles * std::max(1, p.otiles)), 1u, (unsigned)(N * p.ksplit));
   const int64_t slab_stride = (int64_t)N * mout * D * H * W;
   const int64_t slots = (tuning().conv_slots ? tuning().conv_slots : (NTW <= 4 ? 2 : 1) * num_cus());
   if (p.otiles > 0) {
     if (p.persistent) {
       hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, false>), dim3((unsigned)slots), dim3(256), 0, st, x, wp, bias,
                          add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                         p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter, 0);
+                         p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter, 0, tuning().conv_cube);
     } else {
       hipLaunchKernelGGL((conv3_mfma_fwd_kernel<NTW, GX>), grid, dim3(256), 0, st, x, wp, bias, add,
                          y, slab, kin, mout, D, H, W, p.mout_pad, p.ty_tiles, p.tx_tiles, p.nchunks,
-                         p.ksplit, xbs, ybs, slab_stride, stat);
+                         p.ksplit, xbs, ybs, slab_stride, stat, p.otiles, tuning().conv_cube);
     }
   }
   if constexpr (NTW <= 4) {
@@ -2097,7 +2118,7 @@ static void launch_fwd(const FwdPlan& p, const float* x, const float* wp, const 
       hipLaunchKernelGGL((conv3_mfma_fwd_p_kernel<NTW, GX, true>), dim3((unsigned)g16),
                          dim3(256), 0, st, x, wp, bias, add, y, slab, kin, mout, D, H, W, p.mout_pad, p.tz_tiles,
                          p.ty_tiles, p.tx_tiles, 1, p.nchunks, p.ksplit, N, xbs, ybs, slab_stride, stat, work_counter,
-                         32 * p.otiles);
+                         32 * p.otiles, tuning().conv_cube);
     }
   }
 }

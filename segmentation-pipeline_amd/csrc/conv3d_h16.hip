@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int CB, int Cout, int D, int H,
     int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int nchunks, int ksplit, int nbatch,
     int64_t xbs16, int64_t ybs, int64_t slab_stride, float* __restrict__ stat, int* __restrict__ work_counter,
-    int stagger, int softmax) {
+    int stagger, int softmax, int order) {
   using T = FwdTile<NTW, GX>;
   using hx8 = typename H16<HT>::x8;
   constexpr int GY = T::GY, TZ = NW, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS, HV = (TZ + 2) * PS;
@@ -360,15 +360,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
   };
   auto decode = [&](int it) {
     Item q;
-    int sp = it % sp_tiles, r = it / sp_tiles;
-    q.sp = sp;
+    // order bit 1: the output-channel tile is the fastest index (the items sharing an input tile are adjacent in
+    // time and on one XCD); bit 0: the (y, z) tiles are walked in 4x4 cubes (z-halos shared in L2 as well)
+    const int ot = (order & 2) ? it % otiles : (it / sp_tiles) % otiles;
+    int sp = (order & 2) ? (it / otiles) % sp_tiles : it % sp_tiles, r = it / (otiles * sp_tiles);
     const int txt = sp % tx_tiles;
     sp /= tx_tiles;
+    int tyt, tzt;
+    if ((order & 1) && (ty_tiles & 3) == 0 && (tz_tiles & 3) == 0) {
+      const int ty_lo = sp & 3, tz_lo = (sp >> 2) & 3, hi = sp >> 4;
+      const int tyh = ty_tiles >> 2;
+      tyt = (hi % tyh) * 4 + ty_lo;
+      tzt = (hi / tyh) * 4 + tz_lo;
+    } else {
+      tyt = sp % ty_tiles;
+      tzt = sp / ty_tiles;
+    }
+    q.sp = (tzt * ty_tiles + tyt) * tx_tiles + txt;   // canonical tile index (statistics slot)
     q.x0 = txt * TX;
-    q.y0 = (sp % ty_tiles) * TY;
-    q.z0 = (sp / ty_tiles) * TZ;
-    q.o0 = (r % otiles) * 32;
-    r /= otiles;
+    q.y0 = tyt * TY;
+    q.z0 = tzt * TZ;
+    q.o0 = ot * 32;
     q.ks = r % ksplit;
     q.n = r / ksplit;
     q.ch_begin = q.ks * cps;
@@ -691,11 +703,11 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
       if (out16 && p.ksplit == 1)
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax, tuning().h16_order);
       else
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 4, true>), dim3(g1), dim3(256), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_xcd, softmax, tuning().h16_order);
       return;
     }
   }
@@ -704,22 +716,22 @@ static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT*
       if (out16 && p.ksplit == 1)
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax, tuning().h16_order);
       else
         hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false, 8>), dim3(grid), dim3(512), 0, st, x16, wp, bias, add, y,
                            slab, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles,
-                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax);
+                           p.otiles, p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, 0, softmax, tuning().h16_order);
       return;
     }
   }
   if (out16 && p.ksplit == 1)
     hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, true>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
                        (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax);
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax, tuning().h16_order);
   else
     hipLaunchKernelGGL((conv3_h16_kernel<NTW, GX, HT, false>), dim3(grid), dim3(256), 0, st, x16, wp, bias, add, y, slab,
                        (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles,
-                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax);
+                       p.nchunks, p.ksplit, N, xbs16, ybs, slab_stride, stat, work_counter, tuning().h16_stagger, softmax, tuning().h16_order);
 }
 
 template <typename HT>
