@@ -277,6 +277,29 @@ int m355_norm_act_bwd_h16(const m355_norm_desc* d, const float* x, const float* 
                           float* dbeta, int training, void* dx16, int64_t dx16_batch_stride, int32_t compute,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Synchronised batch norm: BatchNorm3d statistics over the batch of ALL ranks of a data-parallel job, so that a model
+ * trained with its batch sharded over GPUs normalises exactly as the reference's single-process run of the whole batch
+ * (models/nested_residual_unet.py:19-23 is BatchNorm; segmentation_trainer.py:189-262 is one process).  The library
+ * provides the local halves, the caller all-reduces (SUM, RCCL) between them:
+ *   forward : m355_norm_sums -> all-reduce(sums) -> m355_norm_stats_from_sums
+ *   backward: m355_norm_act_bwd_reduce(total_count = &sums[2C]) -> all-reduce(stat_m) -> m355_norm_act_bwd_apply
+ * sums: double[2*C + 1] = {sum x, sum x^2} per channel, then the element count (N*S) that went into them; from x or from
+ * the producing conv's epilogue partials (stat_partials != NULL, x unused).  desc->groups must be 0.
+ * m355_norm_act_bwd_reduce divides by *total_count (device pointer; NULL = the local count), so the SUM over ranks of
+ * stat_m[C][2] is the global mean; dgamma / dbeta stay local sums (the gradient all-reduce averages them like any
+ * other parameter gradient).  m355_norm_act_bwd_apply: dx (and, dx16 != NULL, its c8 twin as m355_norm_act_bwd_h16). */
+int m355_norm_sums(const m355_norm_desc* d, const float* x, const float* stat_partials, int64_t slots, double* sums,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int m355_norm_stats_from_sums(const m355_norm_desc* d, const double* sums, float* mean, float* rstd,
+                              float* running_mean, float* running_var, float momentum, void* stream);
+int m355_norm_act_bwd_reduce(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                             int training, const double* total_count, float* stat_m, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int m355_norm_act_bwd_apply(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, const float* stat_m, float* dx,
+                            void* dx16, int64_t dx16_batch_stride, int32_t compute, void* stream);
+
 /* The passes that WRITE c8 tensors in the 16-bit modes (so that conv -> norm/act -> conv never converts):
  * m355_norm_act_fwd with a c8 output y16 (the layout transposer: reads the fp32 NCDHW conv output) and,
  * when y != NULL, the usual fp32 NCDHW output as well (desc->y_batch_stride) for non-conv consumers;

@@ -89,6 +89,10 @@ SIGNATURES = {
     "m355_norm_act_fwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P]),
     "m355_norm_act_pool_fwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _P]),
     "m355_norm_act_bwd": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _sz, _P]),
+    "m355_norm_sums": (C.c_int, [_ND, _P, _P, _i64, _P, _P, _sz, _P]),
+    "m355_norm_stats_from_sums": (C.c_int, [_ND, _P, _P, _P, _P, _P, _f32, _P]),
+    "m355_norm_act_bwd_reduce": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _sz, _P]),
+    "m355_norm_act_bwd_apply": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _P]),
     "m355_norm_act_bwd_h16": (C.c_int, [_ND, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _i64, _i32, _P, _sz, _P]),
     "m355_avgpool3d_2x_fwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),
     "m355_avgpool3d_2x_bwd": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _P]),

@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
 __global__ __launch_bounds__(64) void norm_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
                                      float* __restrict__ rstd, float* __restrict__ running_mean,
                                      float* __restrict__ running_var, float momentum, float eps,
-                                     int64_t nstats, int nblk, int64_t count) {
+                                     int64_t nstats, int nblk, int64_t count, const double* __restrict__ count_ptr) {
   const int64_t s = blockIdx.x;
+  if (count_ptr) count = (int64_t)count_ptr[0];   // synchronised batch norm: the element count summed over the ranks
   double t1 = 0.0, t2 = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 64) {
     t1 += partial[(s * nblk + b) * 2 + 0];
@@ -115,6 +116,24 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const double* __restr
     const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
     running_var[s] = (1.f - momentum) * running_var[s] + momentum * (float)unbiased;
   }
+}
+
+// Synchronised batch norm, local half: sums[s][2] = (sum x, sum x^2) of statistic s in double (one wave per statistic,
+// fixed order), sums[nstats*2] = the local element count.  The ranks all-reduce this buffer (SUM) and finalize from it.
+__global__ __launch_bounds__(64) void norm_sums_kernel(const double* __restrict__ partial, double* __restrict__ sums,
+                                                        int64_t nstats, int nblk, int64_t count) {
+  const int64_t s = blockIdx.x;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    t1 += partial[(s * nblk + b) * 2 + 0];
+    t2 += partial[(s * nblk + b) * 2 + 1];
+  }
+  t1 = wave_sum(t1);
+  t2 = wave_sum(t2);
+  if (threadIdx.x != 0) return;
+  sums[s * 2 + 0] = t1;
+  sums[s * 2 + 1] = t2;
+  if (s == 0) sums[nstats * 2] = (double)count;
 }
 
 // statistics from the conv epilogue partials part[n][slot][C][2] (float), stage 1: block (b, s) sums a
@@ -336,7 +355,10 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(
 __global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __restrict__ partial,
                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ stat_m, int N,
-                                                              int C, int groups, int nblk, int64_t count, int training) {
+                                                              int C, int groups, int nblk, int64_t count, int training,
+                                                              const double* __restrict__ count_ptr) {
+  // synchronised batch norm: divide by the element count over all ranks; the SUM all-reduce of stat_m is then the mean
+  if (count_ptr) count = (int64_t)count_ptr[0];
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
   const int64_t s = blockIdx.x;
   const int lane = threadIdx.x;
@@ -493,7 +515,7 @@ extern "C" int m355_norm_stats(const m355_norm_desc* d, const float* x, float* m
                        dim3(256), 0, st, x, partial, d->groups, d->C, d->S, xbs, g.runs, g.len,
                        g.nblk);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, mean,
-                     rstd, running_mean, running_var, momentum, d->eps, g.nstats, g.nblk, g.count);
+                     rstd, running_mean, running_var, momentum, d->eps, g.nstats, g.nblk, g.count, nullptr);
   return check_launch("norm_stats");
 }
 
@@ -523,7 +545,7 @@ extern "C" int m355_norm_stats_from_partials(const m355_norm_desc* d, const floa
   hipLaunchKernelGGL(norm_from_partials_kernel, dim3((unsigned)nblk, (unsigned)g.nstats), dim3(256), 0, st,
                      stat_partials, partial, d->groups, d->N, d->C, slots, nblk);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, mean, rstd,
-                     running_mean, running_var, momentum, d->eps, g.nstats, nblk, g.count);
+                     running_mean, running_var, momentum, d->eps, g.nstats, nblk, g.count, nullptr);
   return check_launch("norm_stats_from_partials");
 }
 
@@ -561,24 +583,21 @@ extern "C" int m355_norm_act_fwd(const m355_norm_desc* d, const float* x, const 
   return check_launch("norm_act_fwd");
 }
 
-static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
-                             const float* rstd, const float* gamma, const float* beta, float* dx, float* dgamma,
-                             float* dbeta, int training, void* workspace, size_t workspace_bytes, void* stream,
-                             void* dx16, int64_t dx16_batch_stride, int compute) {
-  if (int rc = validate_norm(d, "norm_act_bwd")) return rc;
-  M355_REQUIRE(x && dy && mean && rstd && dx && workspace, M355_EINVALID_ARG,
-               "norm_act_bwd: null pointer");
-  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE,
-               "norm_act_bwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
+// first half of the normalisation backward: partial sums + reduction -> stat_m[s][2] (means of dxhat and dxhat*xhat),
+// dgamma, dbeta.  stat_m may be the caller's buffer (synchronised batch norm: all-reduced before the second half).
+static int norm_act_bwd_reduce_impl(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                    int training, const double* count_ptr, float* stat_m, void* workspace,
+                                    size_t workspace_bytes, hipStream_t st, const char* who) {
+  if (int rc = validate_norm(d, who)) return rc;
+  M355_REQUIRE(x && dy && mean && rstd && workspace && stat_m, M355_EINVALID_ARG, "%s: null pointer", who);
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE, "%s: workspace too small", who);
   const NormGeom g = geom(d);
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
   const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
   double* partial = (double*)workspace;
-  float* stat_m = (float*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
-  const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) &&
-                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(norm_bwd_partial_kernel<true>,
                        dim3((unsigned)nblk_c, (unsigned)d->C, (unsigned)d->N), dim3(256), 0, st, x,
@@ -591,11 +610,24 @@ static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const floa
                        d->act_slope, xbs, ybs, nblk_c);
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)nthreads), dim3(64), 0, st, partial, gamma, dgamma, dbeta,
-                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training);
+                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training, count_ptr);
+  return check_launch(who);
+}
+
+// second half: dx (and its c8 twin) from x, dy and the per-statistic means
+static int norm_act_bwd_apply_impl(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, const float* stat_m, float* dx,
+                                   hipStream_t st, void* dx16, int64_t dx16_batch_stride, int compute, const char* who) {
+  if (int rc = validate_norm(d, who)) return rc;
+  M355_REQUIRE(x && dy && mean && rstd && dx && stat_m, M355_EINVALID_ARG, "%s: null pointer", who);
+  const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+  const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->C * d->S);
   if (dx16)   // 16-bit training flow: dx as fp32 and as c8 in one pass
     return launch_norm_bwd_apply_c8(x, dy, mean, rstd, gamma, beta, stat_m, dx, dx16, d->N, d->C, d->S, d->groups, d->act,
                                     d->act_slope, xbs, ybs, dense_or(dx16_batch_stride, c8_blocks(d->C) * d->S * 8), compute,
                                     st);
+  const bool vec = (d->S % 4 == 0) && (xbs % 4 == 0) && (ybs % 4 == 0) &&
+                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
   const int64_t work = vec ? d->S / 4 : d->S;
   const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work, 256 * 4), 1024));
   dim3 grid(bx, (unsigned)d->C, (unsigned)d->N);
@@ -607,7 +639,21 @@ static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const floa
     hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, grid, dim3(256), 0, st, x, dy, mean, rstd,
                        gamma, beta, stat_m, dx, d->C, d->S, d->groups, d->act, d->act_slope, xbs,
                        ybs);
-  return check_launch("norm_act_bwd");
+  return check_launch(who);
+}
+
+static int norm_act_bwd_impl(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, float* dx, float* dgamma,
+                             float* dbeta, int training, void* workspace, size_t workspace_bytes, void* stream,
+                             void* dx16, int64_t dx16_batch_stride, int compute) {
+  M355_REQUIRE(d && workspace && dx, M355_EINVALID_ARG, "norm_act_bwd: null pointer");
+  const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
+  float* stat_m = (float*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256));
+  if (int rc = norm_act_bwd_reduce_impl(d, x, dy, mean, rstd, gamma, beta, dgamma, dbeta, training, nullptr, stat_m,
+                                        workspace, workspace_bytes, (hipStream_t)stream, "norm_act_bwd"))
+    return rc;
+  return norm_act_bwd_apply_impl(d, x, dy, mean, rstd, gamma, beta, stat_m, dx, (hipStream_t)stream, dx16,
+                                 dx16_batch_stride, compute, "norm_act_bwd");
 }
 
 extern "C" int m355_norm_act_pool_fwd(const m355_norm_desc* d, const float* x, const float* mean, const float* rstd,
@@ -649,4 +695,66 @@ extern "C" int m355_norm_act_bwd_h16(const m355_norm_desc* d, const float* x, co
                M355_EINVALID_ARG, "norm_act_bwd_h16: needs an aligned c8 destination and a 16-bit compute type");
   return norm_act_bwd_impl(d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, training, workspace, workspace_bytes,
                            stream, dx16, dx16_batch_stride, compute);
+}
+
+// ---- synchronised batch norm (statistics over the batch of ALL ranks): the local halves around the all-reduce ----
+
+extern "C" int m355_norm_sums(const m355_norm_desc* d, const float* x, const float* stat_partials, int64_t slots,
+                              double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_norm(d, "norm_sums")) return rc;
+  M355_REQUIRE((x || stat_partials) && sums && workspace, M355_EINVALID_ARG, "norm_sums: null pointer");
+  M355_REQUIRE(!stat_partials || slots > 0, M355_EINVALID_ARG, "norm_sums: partials without slots");
+  M355_REQUIRE(d->groups == 0, M355_EINVALID_ARG, "norm_sums: batch norm only (group statistics never cross samples)");
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE, "norm_sums: workspace too small");
+  const NormGeom g = geom(d);
+  M355_REQUIRE(g.nstats <= 65535, M355_EUNSUPPORTED, "norm_sums: too many statistics");
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)workspace;
+  int nblk = g.nblk;
+  if (stat_partials) {   // the producing conv's epilogue partials [N][slots][C][2]
+    const int64_t items = (int64_t)d->N * slots;
+    nblk = (int)std::max<int64_t>(1, std::min<int64_t>(g.nblk, ceil_div(items, 2048)));
+    hipLaunchKernelGGL(norm_from_partials_kernel, dim3((unsigned)nblk, (unsigned)g.nstats), dim3(256), 0, st,
+                       stat_partials, partial, d->groups, d->N, d->C, slots, nblk);
+  } else {
+    const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->C * d->S);
+    const bool vec = (g.len % 4 == 0) && (d->S % 4 == 0) && (xbs % 4 == 0) && ((uintptr_t)x & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL(norm_partial_kernel<true>, dim3((unsigned)g.nblk, (unsigned)g.nstats), dim3(256), 0, st, x,
+                         partial, d->groups, d->C, d->S, xbs, g.runs, g.len, g.nblk);
+    else
+      hipLaunchKernelGGL(norm_partial_kernel<false>, dim3((unsigned)g.nblk, (unsigned)g.nstats), dim3(256), 0, st, x,
+                         partial, d->groups, d->C, d->S, xbs, g.runs, g.len, g.nblk);
+  }
+  hipLaunchKernelGGL(norm_sums_kernel, dim3((unsigned)g.nstats), dim3(64), 0, st, partial, sums, g.nstats, nblk, g.count);
+  return check_launch("norm_sums");
+}
+
+extern "C" int m355_norm_stats_from_sums(const m355_norm_desc* d, const double* sums, float* mean, float* rstd,
+                                         float* running_mean, float* running_var, float momentum, void* stream) {
+  if (int rc = validate_norm(d, "norm_stats_from_sums")) return rc;
+  M355_REQUIRE(sums && mean && rstd, M355_EINVALID_ARG, "norm_stats_from_sums: null pointer");
+  M355_REQUIRE(d->groups == 0, M355_EINVALID_ARG, "norm_stats_from_sums: batch norm only");
+  const NormGeom g = geom(d);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)g.nstats), dim3(64), 0, (hipStream_t)stream, sums, mean, rstd,
+                     running_mean, running_var, momentum, d->eps, g.nstats, 1, g.count, sums + g.nstats * 2);
+  return check_launch("norm_stats_from_sums");
+}
+
+extern "C" int m355_norm_act_bwd_reduce(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                                        float* dbeta, int training, const double* total_count, float* stat_m,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  return norm_act_bwd_reduce_impl(d, x, dy, mean, rstd, gamma, beta, dgamma, dbeta, training, total_count, stat_m,
+                                  workspace, workspace_bytes, (hipStream_t)stream, "norm_act_bwd_reduce");
+}
+
+extern "C" int m355_norm_act_bwd_apply(const m355_norm_desc* d, const float* x, const float* dy, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, const float* stat_m,
+                                       float* dx, void* dx16, int64_t dx16_batch_stride, int32_t compute, void* stream) {
+  M355_REQUIRE(!dx16 || ((compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16) && ((uintptr_t)dx16 & 15) == 0 &&
+                         dx16_batch_stride % 8 == 0),
+               M355_EINVALID_ARG, "norm_act_bwd_apply: the c8 destination needs alignment and a 16-bit compute type");
+  return norm_act_bwd_apply_impl(d, x, dy, mean, rstd, gamma, beta, stat_m, dx, (hipStream_t)stream, dx16,
+                                 dx16_batch_stride, compute, "norm_act_bwd_apply");
 }

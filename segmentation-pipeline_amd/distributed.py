@@ -76,13 +76,19 @@ class PatchParallel(nn.Module):
     Parameters that never receive a gradient (e.g. the unused `bias` of the reference's
     Blur / WS convolutions, components.py:86,119,152) are tolerated: their slice of the
     bucket stays zero and they keep `.grad is None`.
+
+    sync_batch_norm: BatchNorm layers in training mode normalise with the statistics of the batch over ALL ranks
+    (ops.batch_norm_sync: two per-channel all-reduces per layer and step), so a BatchNorm model
+    (models/nested_residual_unet.py:19-23) trained on a sharded batch follows the same trajectory as the reference's
+    single process on the whole batch.  Off: per-rank statistics, running buffers averaged (`sync_buffers`).
     """
 
     def __init__(self, module: nn.Module, bucket_bytes: int = 25 << 20, process_group=None,
-                 broadcast_parameters: bool = True, force_collectives: bool = False):
+                 broadcast_parameters: bool = True, force_collectives: bool = False, sync_batch_norm: bool = False):
         super().__init__()
         self.module = module
         self.group = process_group
+        self.sync_batch_norm = sync_batch_norm
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collectives: run the hooks / all-reduces even with one rank (exercises the RCCL path
         # on a single-GPU box; numerically a no-op)
@@ -165,6 +171,10 @@ class PatchParallel(nn.Module):
 
     # -- step protocol ---------------------------------------------------------
     def forward(self, *args, **kwargs):
+        if self.sync_batch_norm and self.active:
+            from . import ops
+            with ops.batch_norm_sync(self.group if self.group is not None else dist.group.WORLD):
+                return self.module(*args, **kwargs)
         return self.module(*args, **kwargs)
 
     def zero_grad(self, set_to_none: bool = True):

@@ -664,6 +664,31 @@ class NormCfg:
     # 16-bit TRAINING flow (H16_TRAIN_C8), set by norm_act() / its autograd function:
     dx_twin: int = 0               # compute code when the conv that produced x wants its output gradient as c8 too
     twin: Optional["Act16"] = None  # c8 twin of the fp32 result, handed from the forward to norm_act()
+    sync: Optional[tuple] = None   # synchronised batch norm: (process group, device-side total element count)
+
+
+# Synchronised batch norm: while a process group is set here (distributed.PatchParallel(sync_batch_norm=True) does so
+# around the forward), BatchNorm layers in training mode take their statistics over the batch of ALL ranks -- the
+# reference is one process normalising the whole batch (segmentation_trainer.py:189-262).  Two small all-reduces per
+# layer and step: the per-channel sums forward, the per-channel gradient means backward.
+_bn_sync_group = None
+
+
+class batch_norm_sync:
+    """Context manager: BatchNorm training statistics over all ranks of `group` (None = off)."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def __enter__(self):
+        global _bn_sync_group
+        self.prev, _bn_sync_group = _bn_sync_group, self.group
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_sync_group
+        _bn_sync_group = self.prev
+        return False
 
 
 def _norm_statistics(L, d, x, cfg, N, Cc, device=None):
@@ -677,6 +702,19 @@ def _norm_statistics(L, d, x, cfg, N, Cc, device=None):
     if fused is not None and tuple(fused.shape) != (N, cfg.stats["slots"], Cc, 2):
         raise _lib.M355Error(f"norm_act: statistics partials {tuple(fused.shape)} do not belong to this tensor")
     upd = cfg.groups == 0 and cfg.training and use_batch
+    cfg.sync = None
+    if upd and _bn_sync_group is not None:
+        import torch.distributed as dist
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), device)
+        sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=device)   # {sum, sum of squares} per channel, count
+        check(L.m355_norm_sums(C.byref(d), _p(x) if fused is None else None, _p(fused),
+                               int(cfg.stats["slots"]) if fused is not None else 0, _p(sums), _p(ws), ws.numel(),
+                               _stream()), "norm_sums")
+        dist.all_reduce(sums, group=_bn_sync_group)
+        check(L.m355_norm_stats_from_sums(C.byref(d), _p(sums), _p(mean), _p(rstd), _p(cfg.running_mean),
+                                          _p(cfg.running_var), float(cfg.momentum), _stream()), "norm_stats_from_sums")
+        cfg.sync = (_bn_sync_group, sums[2 * Cc:])
+        return mean, rstd, use_batch
     if use_batch and fused is not None:
         ws = _workspace(L.m355_norm_workspace(C.byref(d)), device)
         check(L.m355_norm_stats_from_partials(C.byref(d), _p(fused), int(cfg.stats["slots"]), _p(mean), _p(rstd),
@@ -739,6 +777,32 @@ def _norm_act_c8(x, gamma, beta, add, cfg: NormCfg) -> Act16:
     return out16
 
 
+def _norm_backward(L, d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, batch_stats, sync, dx16=None, compute=0):
+    """The normalisation backward; with `sync` (synchronised batch norm) as its two halves around the all-reduce of the
+    per-channel gradient means."""
+    ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
+    training = 1 if batch_stats else 0
+    if sync is not None:
+        import torch.distributed as dist
+        group, total = sync
+        stat_m = torch.empty(2 * d.C, dtype=torch.float32, device=x.device)
+        check(L.m355_norm_act_bwd_reduce(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma),
+                                         _p(dbeta), training, _p(total), _p(stat_m), _p(ws), ws.numel(), _stream()),
+              "norm_act_bwd_reduce")
+        dist.all_reduce(stat_m, group=group)
+        check(L.m355_norm_act_bwd_apply(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(stat_m),
+                                        _p(dx), dx16.ptr() if dx16 is not None else None,
+                                        dx16.batch_stride() if dx16 is not None else 0, compute, _stream()),
+              "norm_act_bwd_apply")
+    elif dx16 is not None:
+        check(L.m355_norm_act_bwd_h16(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                      _p(dgamma), _p(dbeta), training, dx16.ptr(), dx16.batch_stride(), compute,
+                                      _p(ws), ws.numel(), _stream()), "norm_act_bwd_h16")
+    else:
+        check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
+                                  _p(dgamma), _p(dbeta), training, _p(ws), ws.numel(), _stream()), "norm_act_bwd")
+
+
 class _NormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, add, cfg: NormCfg):
@@ -770,7 +834,7 @@ class _NormActFn(torch.autograd.Function):
             check(L.m355_norm_act_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
                                       _stream()), "norm_act_fwd")
         ctx.desc, ctx.batch_stats, ctx.has_add = d, use_batch, add is not None
-        ctx.has_affine = gamma is not None
+        ctx.has_affine, ctx.sync = gamma is not None, cfg.sync
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
 
@@ -784,18 +848,13 @@ class _NormActFn(torch.autograd.Function):
         dx = torch.empty_like(x)  # x was saved dense
         dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
         dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
-        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
         if ctx.dx_twin:   # dx is the output gradient of an h16-flow convolution: emit it as c8 too, in the same pass
             dx16 = Act16.empty(d0.N, d0.C, tuple(x.shape[2:]), ctx.dx_twin, x.device)
-            check(L.m355_norm_act_bwd_h16(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
-                                          _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, dx16.ptr(),
-                                          dx16.batch_stride(), ctx.dx_twin, _p(ws), ws.numel(), _stream()),
-                  "norm_act_bwd_h16")
+            _norm_backward(L, d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, ctx.batch_stats, ctx.sync, dx16,
+                           ctx.dx_twin)
             dx._m355_c8 = (dx16, dx._version)
         else:
-            check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
-                                      _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
-                                      _stream()), "norm_act_bwd")
+            _norm_backward(L, d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, ctx.batch_stats, ctx.sync)
         dadd = dy if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return dx, dgamma, dbeta, dadd, None
 
@@ -823,6 +882,7 @@ class _NormActPoolFn(torch.autograd.Function):
         check(L.m355_norm_act_pool_fwd(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _p(pooled), 0,
                                        D, H, W, _stream()), "norm_act_pool_fwd")
         ctx.desc, ctx.batch_stats, ctx.has_affine, ctx.dims = d, use_batch, gamma is not None, (D, H, W)
+        ctx.sync = cfg.sync
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y, pooled
 
@@ -847,10 +907,7 @@ class _NormActPoolFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
         dbeta = torch.empty(d0.C, dtype=torch.float32, device=x.device) if ctx.has_affine else None
-        ws = _workspace(L.m355_norm_workspace(C.byref(d)), x.device)
-        check(L.m355_norm_act_bwd(C.byref(d), _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx),
-                                  _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0, _p(ws), ws.numel(),
-                                  _stream()), "norm_act_bwd")
+        _norm_backward(L, d, x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, ctx.batch_stats, ctx.sync)
         return dx, dgamma, dbeta, None
 
 

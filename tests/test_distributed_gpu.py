@@ -1,0 +1,147 @@
+"""Two ranks on ONE GPU (gloo carries the device tensors through the host: RCCL refuses two ranks on a device, and the
+test box has one): the data-parallel path with the real kernels underneath.
+
+Synchronised batch norm: a BatchNorm model whose batch is sharded over the ranks must follow the single-process run
+on the whole batch -- the reference is one process (segmentation_trainer.py:189-262), its production dmri_hippo
+model is BatchNorm (models/nested_residual_unet.py:19-23)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (4, 3, 16, 16, 16)   # whole batch; each of the two ranks takes two samples
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(SHAPE, generator=g)
+    w = torch.randn((SHAPE[0], 2) + SHAPE[2:], generator=g)   # a loss that is a mean over samples: sum(p * w) / N
+    return x, w
+
+
+def _build(which):
+    from segmentation_pipeline_amd.models import ModularUNet, NestedResUNet
+    torch.manual_seed(7)
+    if which == "nested":
+        return NestedResUNet(3, 2, 8).cuda()
+    return ModularUNet(3, 2, [8, 16], 2).cuda()   # Block3d default: BatchNorm3d
+
+
+def _step(model, x, w, n_total, wrapper=None):
+    out = (wrapper or model)(x)
+    loss = (out * w).sum() / x.shape[0] / w[0].numel()
+    loss.backward()
+    if wrapper is not None:
+        wrapper.finish_gradient_sync()
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+    bufs = {k: b.detach().cpu().clone() for k, b in model.named_buffers() if b.is_floating_point()}
+    return out.detach().cpu(), loss.detach().cpu(), grads, bufs
+
+
+def _worker(rank, world, port, which, precision, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentation_pipeline_amd import distributed as D, ops
+        torch.cuda.set_device(0)
+        ops.set_precision(precision)
+        model = _build(which)
+        ddp = D.PatchParallel(model, sync_batch_norm=True)
+        x, w = _inputs()
+        per = SHAPE[0] // world
+        xs, ws = x[rank * per:(rank + 1) * per].cuda(), w[rank * per:(rank + 1) * per].cuda()
+        ret[rank] = _step(model, xs, ws, SHAPE[0], ddp)
+    finally:
+        dist.destroy_process_group()
+
+
+def _close(a, b, tol, what):
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= tol * scale + 1e-7, f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("which,precision,tol", [("unet_bn", "fp32", 1.0), ("nested", "fp32", 1.0),
+                                                 ("unet_bn", "bf16", 100.0)])
+def test_sync_batch_norm_two_ranks_match_one_process(which, precision, tol):
+    """bf16: the same operand roundings in both runs, only the fp32 statistics are summed in another order; the
+    16-bit training flow takes the split backward with the c8 gradient twin (m355_norm_act_bwd_apply, dx16)."""
+    from segmentation_pipeline_amd import ops
+    ops.set_precision(precision)
+    model = _build(which)
+    x, w = _inputs()
+    ref_out, ref_loss, ref_grads, ref_bufs = _step(model, x.cuda(), w.cuda(), SHAPE[0])
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ops.set_precision("fp32")
+    mp.spawn(_worker, args=(2, _free_port(), which, precision, ret), nprocs=2, join=True)
+    per = SHAPE[0] // 2
+    for rank in range(2):
+        out, loss, grads, bufs = ret[rank]
+        # forward: every rank's samples are normalised with the statistics of all four
+        _close(out, ref_out[rank * per:(rank + 1) * per], 2e-5 * tol, f"rank {rank} output")
+        # parameter gradients after the gradient all-reduce = gradient of the whole-batch mean loss
+        assert set(grads) == set(ref_grads)
+        for k in ref_grads:
+            _close(grads[k], ref_grads[k], 2e-4 * tol, f"rank {rank} grad {k}")
+        # running statistics: updated from the global batch on every rank (momentum, unbiased variance over N*S*world)
+        for k in ref_bufs:
+            _close(bufs[k], ref_bufs[k], 1e-5 * tol, f"rank {rank} buffer {k}")
+    _close(0.5 * (ret[0][1] + ret[1][1]), ref_loss, 1e-5 * tol, "mean of the rank losses")
+
+
+def test_per_rank_statistics_differ_without_sync():
+    """The control: with sync_batch_norm off the shards normalise with their own statistics, so the outputs do NOT
+    match the whole-batch run (what the option is for)."""
+    from segmentation_pipeline_amd import ops
+    ops.set_precision("fp32")
+    model = _build("unet_bn")
+    x, _ = _inputs()
+    with torch.no_grad():
+        model.train()
+        whole = model(x.cuda()).cpu()
+        half = model(x[:2].cuda()).cpu()
+    assert (whole[:2] - half).abs().max().item() > 1e-4
+
+
+def test_sync_halves_bit_identical_at_world_one():
+    """One rank: the split statistics / split backward (m355_norm_sums -> m355_norm_stats_from_sums,
+    m355_norm_act_bwd_reduce -> m355_norm_act_bwd_apply) sum in the same order as the fused entry points, so every
+    result is bit-identical -- from x and from the conv epilogue partials."""
+    from segmentation_pipeline_amd import ops
+    ops.set_precision("fp32")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x, w = _inputs()
+        x, w = x.cuda(), w.cuda()
+        res = []
+        for sync in (False, True):
+            model = _build("unet_bn")
+            if sync:
+                with ops.batch_norm_sync(dist.group.WORLD):
+                    out = model(x)
+            else:
+                out = model(x)
+            (out * w).sum().backward()
+            res.append((out.detach(), [p.grad for p in model.parameters() if p.grad is not None],
+                        [b.clone() for b in model.buffers() if b.is_floating_point()]))
+        assert torch.equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
