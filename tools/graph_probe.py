@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Can the no-grad forward be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed?  Prints eager vs
-graph latency and the max difference."""
+graph latency and the max difference.   usage: graph_probe.py [fp32|bf16|fp16]"""
 import os, sys, time, torch
 from functools import partial
 from torch import nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from segmentation_pipeline_amd.models import ModularUNet
 
+import segmentation_pipeline_amd as sp
+sp.set_precision(sys.argv[1] if len(sys.argv) > 1 else "fp32")
 torch.manual_seed(0)
 m = ModularUNet(4, 3, [32, 64, 128, 256, 320], 5, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
                 upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2}).cuda().eval()
