@@ -1,11 +1,10 @@
+#!/bin/bash
+# same-box A/B of the conv item order knobs (M355_CONV_CUBE for the fp32 kernels, M355_H16_ORDER for the 16-bit
+# ones; bit 0 = (y, z) tiles in 4x4 cubes, bit 1 = channel tile fastest) on an architecture of tools/arch_bench.py
+# usage: tools/ab_order.sh [msseg2|dmri_hippo|cfg2] [fp32|bf16|fp16]
 set -u
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/ab; mkdir -p $O
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -20 $O/tests.log; exit 1; }
-tail -2 $O/tests.log
-for v in 1 3 1 3; do
-  echo "== fp32 cube=$v"; M355_CONV_CUBE=$v timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('infer_ms'), d['roofline']['achieved'])"
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+A=${1:-msseg2}; P=${2:-bf16}
+for v in 0 1 2 3 0 3; do
+  echo "== $A $P order=$v"; M355_CONV_CUBE=$v M355_H16_ORDER=$v timeout -k 10 200 python tools/arch_bench.py $A $P 2>&1 | tail -1
 done
-for v in 0 3 0 3; do
-  echo "== bf16 order=$v"; M355_H16_ORDER=$v timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision bf16 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('infer_ms'), d['roofline']['achieved'])"
-done
-for v in 1 3; do echo "== msseg2 cube=$v"; M355_CONV_CUBE=$v timeout -k 10 200 python tools/arch_bench.py msseg2 2>&1 | tail -2; done

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Step time of the two architectures the reference actually trained.
 usage: python tools/arch_bench.py [msseg2|dmri_hippo|all] [fp32|bf16|fp16]"""
-import os, sys, time, torch
+import gc, os, sys, time, torch
 from torch import nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from segmentation_pipeline_amd.models import ModularUNet, NestedResUNet, BlurConv3d, BlurConvTranspose3d
 from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
 
-def run(name, model, shape, ncls, cw=None, steps=3):
+def run(name, model, shape, ncls, cw=None, steps=10, warmup=3):
     model = model.cuda()
     crit = HybridLogisticDiceLoss(logistic_class_weights=cw)
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)
@@ -16,12 +16,15 @@ def run(name, model, shape, ncls, cw=None, steps=3):
     y = torch.nn.functional.one_hot(lab, ncls).permute(0, 4, 1, 2, 3).float().contiguous()
     def step():
         model.train(); ld = crit(model(x), y); opt.zero_grad(); ld["loss"].backward(); opt.step(); model.eval()
-    step(); torch.cuda.synchronize()
+    for _ in range(warmup): step()
+    torch.cuda.synchronize()
+    gc.collect(); gc.freeze()   # keep a full collection (~90 ms of host stall) out of the timed steps, as bench.py does
     t0 = time.perf_counter()
     for _ in range(steps): step()
     torch.cuda.synchronize(); t_train = (time.perf_counter() - t0) / steps
     with torch.no_grad():
-        model(x); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(warmup): model(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): model(x)
         torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
     print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)", flush=True)
