@@ -107,6 +107,17 @@ int32_t m355_conv3d_fuses_softmax(const m355_conv3d_desc* d);
 /* which: 0 = forward, 1 = data gradient.  0 bytes = this descriptor has no packed form (generic direct kernels). */
 size_t m355_conv3d_packed_bytes(const m355_conv3d_desc* d, int32_t which);
 int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const float* w, void* packed, void* stream);
+/* The same for many weights in one launch: after optimizer.step (segmentation_trainer.py:259) every conv weight of a
+ * model needs its forward and data-gradient forms again -- ~37 packs of 5-15 us each, back to back on the critical
+ * path of a cfg2 train step.  Each item is packed exactly as m355_conv3d_pack(&item.desc, item.which, item.w,
+ * item.packed) would (identical bytes); `packed` must hold m355_conv3d_packed_bytes(&item.desc, item.which). */
+typedef struct m355_pack_item {
+  m355_conv3d_desc desc;
+  int32_t which;
+  const float* w;
+  void* packed;
+} m355_pack_item;
+int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, void* stream);
 
 size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d);
 int m355_conv3d_fwd(const m355_conv3d_desc* d, const float* x, const float* w,

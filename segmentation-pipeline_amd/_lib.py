@@ -29,6 +29,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    """m355_pack_item"""
+    _fields_ = [("desc", ConvDesc), ("which", C.c_int32), ("w", C.c_void_p), ("packed", C.c_void_p)]
+
+
 class NormDesc(C.Structure):
     """m355_norm_desc"""
     _fields_ = [
@@ -52,6 +57,7 @@ SIGNATURES = {
     "m355_conv3d_fuses_softmax": (_i32, [_CD]),
     "m355_conv3d_packed_bytes": (_sz, [_CD, _i32]),
     "m355_conv3d_pack": (C.c_int, [_CD, _i32, _P, _P, _P]),
+    "m355_conv3d_pack_batch": (C.c_int, [_P, _i32, _P]),
     "m355_conv3d_fwd_workspace": (_sz, [_CD]),
     "m355_conv3d_fwd": (C.c_int, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "m355_conv3d_stats_slots": (_i64, [_CD]),

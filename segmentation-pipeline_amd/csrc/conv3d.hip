@@ -25,22 +25,8 @@ namespace m355 {
 __global__ void pack_w3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
                                int Cin, int kin_pad, int mout_pad, int transpose, int* __restrict__ counter) {
   // logical conv being run: K-channels = kin (padded to kin_pad), M-channels = mout_pad
-  const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
   if (counter && blockIdx.x == 0 && threadIdx.x < 16) counter[threadIdx.x] = 0;  // work queues of the persistent conv kernel
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i % mout_pad);
-    const int64_t r = i / mout_pad;
-    const int tap = (int)(r % 27);
-    const int kc = (int)(r / 27);
-    float v = 0.f;
-    if (!transpose) {
-      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
-    } else {
-      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
-    }
-    wp[i] = v;
-  }
+  pack_w3_body(w, wp, Cout, Cin, kin_pad, mout_pad, transpose, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------ MFMA fwd kernel
@@ -2468,6 +2454,49 @@ extern "C" int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const 
   else
     launch_pack_w3_h16(p, d->compute, w, packed, d->Cout, d->Cin, which == 1, st);
   return check_launch("conv3d_pack");
+}
+
+extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, void* stream) {
+  M355_REQUIRE(items || n == 0, M355_EINVALID_ARG, "conv3d_pack_batch: null items");
+  hipStream_t st = (hipStream_t)stream;
+  PackBatch b;
+  int nb = 0;
+  for (int i = 0; i < n; ++i) {
+    const m355_pack_item& it = items[i];
+    const m355_conv3d_desc* d = &it.desc;
+    if (int rc = validate_conv(d, "conv3d_pack_batch")) return rc;
+    M355_REQUIRE(it.w && it.packed && ((uintptr_t)it.packed & 15) == 0, M355_EINVALID_ARG,
+                 "conv3d_pack_batch: item %d: null / unaligned pointer", i);
+    M355_REQUIRE(is_k3s1p1(d) && (it.which == 0 || it.which == 1), M355_EUNSUPPORTED,
+                 "conv3d_pack_batch: item %d: only the 3x3x3 / stride 1 / pad 1 kernels have packed weights", i);
+    if (it.which == 0 && small_cout_fwd(d)) {   // (the Cout <= 4 forward layouts: one per model, launched on its own)
+      launch_pack_smallcout(d, it.w, (float*)it.packed, st);
+      continue;
+    }
+    const FwdPlan p = it.which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
+                                    : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
+    const int kind = d->compute == M355_COMPUTE_F32 ? 0 : (d->compute == M355_COMPUTE_BF16 ? 1 : 2);
+    if (nb && (kind == 0) != (b.e[0].kind == 0)) {   // a launch holds fp32 entries or 16-bit entries, not both
+      launch_pack_batch(b, nb, st);
+      nb = 0;
+    }
+    PackEntry& e = b.e[nb++];
+    e.w = it.w;
+    e.wp = it.packed;
+    e.counter = (int*)((char*)it.packed + p.wp_bytes - 256);
+    e.Cout = d->Cout;
+    e.Cin = d->Cin;
+    e.kdim = d->compute == M355_COMPUTE_F32 ? p.kin_pad : p.nchunks;
+    e.mout_pad = p.mout_pad;
+    e.transpose = it.which == 1;
+    e.kind = kind;
+    if (nb == PACK_BATCH) {
+      launch_pack_batch(b, nb, st);
+      nb = 0;
+    }
+  }
+  if (nb) launch_pack_batch(b, nb, st);
+  return check_launch("conv3d_pack_batch");
 }
 
 // ---- 16-bit operand modes with c8 tensors handed over by the caller (h16.hpp) ----

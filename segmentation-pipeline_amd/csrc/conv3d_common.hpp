@@ -154,6 +154,45 @@ int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_b
                  const void* prepacked = nullptr, bool out16 = false, bool softmax = false);
 void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
                         hipStream_t st);
+
+// One entry of a batched weight pack (m355_conv3d_pack_batch): after optimizer.step every conv weight of a model is
+// re-packed (forward + data-gradient form), ~37 launches of 5-15 us each on the critical path of a train step; the batch
+// kernel does them in one launch, blockIdx.y = entry.  kind: 0 = fp32 MFMA layout, 1 = bf16, 2 = fp16 (c8 chunks).
+struct PackEntry {
+  const float* w;
+  void* wp;
+  int* counter;       // work queue in the tail of the packed region, zeroed like the single pack kernels do
+  int Cout, Cin;      // of the weight tensor
+  int kdim;           // fp32: kin_pad; 16-bit: nchunks
+  int mout_pad;
+  int transpose, kind;
+  int blk0, nblk;     // this entry's blocks [blk0, blk0 + nblk) of the launch: proportional to its element count
+};
+constexpr int PACK_BATCH = 64;   // 64 x 56 B of kernel arguments (< 4 KB)
+struct PackBatch {
+  PackEntry e[PACK_BATCH];
+  int n;
+};
+void launch_pack_batch(PackBatch& b, int n, hipStream_t st);
+
+// fp32 MFMA weight layout (see pack_w3_kernel): block `bid` of `nblk` of one tensor
+__device__ __forceinline__ void pack_w3_body(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                             int kin_pad, int mout_pad, int transpose, int64_t bid, int64_t nblk) {
+  const int64_t total = (int64_t)kin_pad * 27 * mout_pad;
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
+    const int m = (int)(i % mout_pad);
+    const int64_t r = i / mout_pad;
+    const int tap = (int)(r % 27);
+    const int kc = (int)(r / 27);
+    float v = 0.f;
+    if (!transpose) {
+      if (kc < Cin && m < Cout) v = w[((int64_t)m * Cin + kc) * 27 + tap];
+    } else {
+      if (kc < Cout && m < Cin) v = w[((int64_t)kc * Cin + m) * 27 + (26 - tap)];
+    }
+    wp[i] = v;
+  }
+}
 // weight gradient on the 16-bit MFMA (fp32 NCDHW operands rounded while staged; W % 32 == 0)
 int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
                    int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,

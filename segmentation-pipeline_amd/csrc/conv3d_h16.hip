@@ -88,12 +88,10 @@ int launch_unpack_act16(const void* x16, float* x, int N, int C, int64_t S, int6
 // the tensor.  transpose: the data-gradient filter (flipped taps, channels swapped).  Also zeroes the work
 // queues of the persistent kernel (every launch of it is preceded by this pack on the same stream).
 template <typename HT>
-__global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
-                                   int Cin, int nchunks, int mout_pad, int transpose, int* __restrict__ counter) {
+__device__ __forceinline__ void pack_w3_h16_body(const float* __restrict__ w, HT* __restrict__ wp, int Cout, int Cin,
+                                                 int nchunks, int mout_pad, int transpose, int64_t bid, int64_t nblk) {
   const int64_t total = (int64_t)nchunks * 27 * 2 * mout_pad * 8;
-  if (counter && blockIdx.x == 0 && threadIdx.x < 16) counter[threadIdx.x] = 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
     const int j = (int)(i & 7);
     int64_t r = i >> 3;
     const int m = (int)(r % mout_pad);
@@ -110,6 +108,145 @@ __global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__
     }
     wp[i] = (HT)v;
   }
+}
+
+template <typename HT>
+__global__ void pack_w3_h16_kernel(const float* __restrict__ w, HT* __restrict__ wp, int Cout,
+                                   int Cin, int nchunks, int mout_pad, int transpose, int* __restrict__ counter) {
+  if (counter && blockIdx.x == 0 && threadIdx.x < 16) counter[threadIdx.x] = 0;
+  pack_w3_h16_body<HT>(w, wp, Cout, Cin, nchunks, mout_pad, transpose, blockIdx.x, gridDim.x);
+}
+
+// All stale packed weights of a model in ONE launch (m355_conv3d_pack_batch).  The single-tensor kernels above gather
+// (each lane reads another row of w: ~1.3 TB/s of useful traffic); here every block moves one TILE through LDS so that
+// both the reads of w and the writes of the packed form are contiguous runs:
+//   fp32 forward   : a plain 2-D transpose  w[m][r] -> wp[r][m]         (r = c*27 + tap), 32 x 32 tiles
+//   fp32 transposed: per K-channel kc,      w[kc][m][tap] -> wp[kc][26-tap][m], tiles of 32 m x 27 taps
+//   16-bit forms   : per 16-channel chunk ch and 32 rows m, the (16 x 27)- resp. (32 x 27)-float runs of w
+//                    -> wp[ch][tap][half][m][8] (one 512-byte run per (tap, half))
+// Pure copies / one rounding per element, the same expressions as above: the packed bytes are identical (tested).
+// Every entry owns a run of blocks (its tile count), found by a scan of the <= 64 entries in the kernel arguments.
+constexpr int PACK_MT = 8;                       // rows m per tile of the 16-bit forms
+constexpr int PACK_LDS_H16 = 16 * (PACK_MT * 27 + 1);   // floats (>= PACK_MT * (16 * 27 + 1)): 13.9 KB, 8+ blocks per CU
+constexpr int PACK_LDS_F32 = 32 * 33;
+
+__device__ __forceinline__ void pack_tile_f32(const PackEntry& e, int bid, float* __restrict__ t) {
+  const float* __restrict__ w = e.w;
+  float* __restrict__ wp = (float*)e.wp;
+  const int tid = threadIdx.x;
+  const int ta = (e.mout_pad + 31) >> 5;
+  if (!e.transpose) {
+    // src[m][r], R = Cin*27 per row; dst[r][m], rows r < kdim*27, cols m < mout_pad
+    const int R = e.Cin * 27, Rp = e.kdim * 27;
+    const int a0 = (bid % ta) * 32, b0 = (bid / ta) * 32;
+    const int col = tid & 31, row = tid >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int a = a0 + row + 8 * p, b = b0 + col;
+      t[(row + 8 * p) * 33 + col] = (a < e.Cout && b < R) ? w[(int64_t)a * R + b] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int b = b0 + row + 8 * p, a = a0 + col;
+      if (b < Rp && a < e.mout_pad) wp[(int64_t)b * e.mout_pad + a] = t[col * 33 + row + 8 * p];
+    }
+  } else {
+    // kc = z over the weight's Cout (padded to kdim), m over its Cin (padded to mout_pad):
+    // src[(z*Cin + m)*27 + tap] -> dst[(z*27 + 26 - tap)*mout_pad + m]
+    const int z = bid / ta, a0 = (bid % ta) * 32;
+    const int na = min(32, e.Cin - a0);               // valid rows m of this tile (may be <= 0)
+    const float* src = w + ((int64_t)z * e.Cin + a0) * 27;
+    for (int i = tid; i < 32 * 27; i += 256) t[i] = (z < e.Cout && i < na * 27) ? src[i] : 0.f;
+    __syncthreads();
+    for (int i = tid; i < 27 * 32; i += 256) {
+      const int tp = i >> 5, aa = i & 31;             // destination tap row, column m
+      if (a0 + aa < e.mout_pad) wp[((int64_t)z * 27 + tp) * e.mout_pad + a0 + aa] = t[aa * 27 + (26 - tp)];
+    }
+  }
+}
+
+template <typename HT>
+__device__ __forceinline__ void pack_tile_h16(const PackEntry& e, int bid, float* __restrict__ t) {
+  const float* __restrict__ w = e.w;
+  HT* __restrict__ wp = (HT*)e.wp;
+  const int tid = threadIdx.x;
+  const int ta = (e.mout_pad + PACK_MT - 1) / PACK_MT;
+  const int ch = bid / ta, m0 = (bid % ta) * PACK_MT;
+  constexpr int RS = 16 * 27 + 1;        // forward: t[mm][cc*27 + tap]
+  constexpr int KS = PACK_MT * 27 + 1;   // transposed: t[kk][mm*27 + tap]
+  if (!e.transpose) {
+    // rows m (weight's Cout), K-channels c = ch*16 + half*8 + j (weight's Cin), cc = c - ch*16
+    const int nc = max(0, min(16, e.Cin - ch * 16));
+    for (int i = tid; i < PACK_MT * 16 * 27; i += 256) {
+      const int r = i / (16 * 27), q = i - r * (16 * 27);
+      const int m = m0 + r;
+      t[r * RS + q] = (m < e.Cout && q < nc * 27) ? w[((int64_t)m * e.Cin + ch * 16) * 27 + q] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 54 * PACK_MT * 8; i += 256) {   // (tap, half, mm, j): runs of PACK_MT * 8 elements
+      const int j = i & 7, mm = (i >> 3) % PACK_MT, th = i / (PACK_MT * 8);
+      const int tap = th >> 1, half = th & 1;
+      if (m0 + mm < e.mout_pad)
+        wp[((((int64_t)ch * 27 + tap) * 2 + half) * e.mout_pad + m0 + mm) * 8 + j] = (HT)t[mm * RS + (half * 8 + j) * 27 + tap];
+    }
+  } else {
+    // K-channels kc = ch*16 + kk (weight's Cout), rows m (weight's Cin)
+    const int nm = max(0, min(PACK_MT, e.Cin - m0));
+    for (int i = tid; i < 16 * PACK_MT * 27; i += 256) {
+      const int kk = i / (PACK_MT * 27), q = i - kk * (PACK_MT * 27);
+      const int kc = ch * 16 + kk;
+      t[kk * KS + q] = (kc < e.Cout && q < nm * 27) ? w[((int64_t)kc * e.Cin + m0) * 27 + q] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 54 * PACK_MT * 8; i += 256) {
+      const int j = i & 7, mm = (i >> 3) % PACK_MT, th = i / (PACK_MT * 8);
+      const int tap = th >> 1, half = th & 1;
+      if (m0 + mm < e.mout_pad)
+        wp[((((int64_t)ch * 27 + tap) * 2 + half) * e.mout_pad + m0 + mm) * 8 + j] =
+            (HT)t[(half * 8 + j) * KS + mm * 27 + (26 - tap)];
+    }
+  }
+}
+
+// KIND 0: fp32 entries; 1: 16-bit entries (bf16 / fp16 per entry)
+template <int KIND>
+__global__ __launch_bounds__(256) void pack_w3_batch_kernel(const PackBatch b) {
+  __shared__ float t[KIND == 0 ? PACK_LDS_F32 : PACK_LDS_H16];
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= b.e[k + 1].blk0) ++k;
+  const PackEntry& e = b.e[k];
+  const int bid = (int)blockIdx.x - e.blk0;
+  if (bid == 0 && threadIdx.x < 16) e.counter[threadIdx.x] = 0;
+  if constexpr (KIND == 0) {
+    pack_tile_f32(e, bid, t);
+  } else {
+    if (e.kind == 1)
+      pack_tile_h16<__bf16>(e, bid, t);
+    else
+      pack_tile_h16<_Float16>(e, bid, t);
+  }
+}
+
+// entries of one launch share the kind class (fp32 / 16-bit): the caller (m355_conv3d_pack_batch) flushes on a change
+void launch_pack_batch(PackBatch& b, int n, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    PackEntry& e = b.e[i];
+    e.blk0 = blocks;
+    if (e.kind == 0) {
+      const int ta = (e.mout_pad + 31) / 32;
+      e.nblk = e.transpose ? e.kdim * ta : (int)ceil_div((int64_t)e.kdim * 27, 32) * ta;
+    } else {
+      e.nblk = e.kdim * (int)ceil_div(e.mout_pad, PACK_MT);   // (chunk, PACK_MT-row tile)
+    }
+    blocks += e.nblk;
+  }
+  b.n = n;
+  if (b.e[0].kind == 0)
+    hipLaunchKernelGGL(pack_w3_batch_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  else
+    hipLaunchKernelGGL(pack_w3_batch_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, b);
 }
 
 // ---- c8 epilogue: the output tile of one wave as c8 items (the next pass reads the tensor in c8 anyway) ----

@@ -6,6 +6,7 @@ through the C ABI of libm355seg.so; nothing falls back to torch or to the CPU.
 """
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -251,6 +252,33 @@ H16_TRAIN_C8 = True
 FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"
 
 
+# Parameters that own packed forms (id -> weak reference).  optimizer.step changes every one of them at once; the first
+# conv that then finds its weight stale re-packs ALL stale registered forms in one launch (m355_conv3d_pack_batch)
+# instead of ~37 small packs spread over the step, each on the critical path in front of its conv.
+_pack_registry = {}
+PACK_BATCH = os.environ.get("M355_PACK_BATCH", "1") != "0"
+
+
+def _repack_stale(L, device):
+    """Refresh, in place and with one launch, every cached packed form whose parameter has a new version."""
+    items = []
+    for key, ref in list(_pack_registry.items()):
+        w = ref()
+        cache = getattr(w, "_m355_packed", None) if w is not None else None
+        if cache is None or cache[1] != w.data_ptr() or w.device != device:
+            if w is None or cache is None or cache[1] != w.data_ptr():
+                del _pack_registry[key]   # gone, or its storage moved: the per-weight path starts a new cache
+            continue
+        if cache[0] == w._version:
+            continue
+        for (which, *_), (buf, d) in cache[2].items():
+            items.append(_lib.PackItem(d, which, w.data_ptr(), buf.data_ptr()))
+        w._m355_packed = (w._version, cache[1], cache[2])
+    if items:
+        arr = (_lib.PackItem * len(items))(*items)
+        check(L.m355_conv3d_pack_batch(C.cast(arr, C.c_void_p), len(items), _stream()), "conv3d_pack_batch")
+
+
 def _packed_weight(weight, d, which):
     """-> (pointer argument, flags) for a conv entry point: the cached packed form of `weight` for descriptor
     `d` (which: 0 forward, 1 data gradient) with M355_CONV_W_PACKED, or the plain weight with flags 0."""
@@ -259,6 +287,9 @@ def _packed_weight(weight, d, which):
     L = _lib.lib()
     ver, ptr = weight._version, weight.data_ptr()
     cache = getattr(weight, "_m355_packed", None)
+    if (cache is not None and cache[0] != ver and cache[1] == ptr and PACK_BATCH and id(weight) in _pack_registry):
+        _repack_stale(L, weight.device)   # a parameter after optimizer.step: all stale forms of all parameters at once
+        cache = weight._m355_packed
     if cache is None or cache[0] != ver or cache[1] != ptr:
         cache = (ver, ptr, {})
         try:
@@ -266,15 +297,18 @@ def _packed_weight(weight, d, which):
         except (AttributeError, RuntimeError):
             return weight, 0
     key = (which, d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.compute)
-    buf = cache[2].get(key)
-    if buf is None:
+    ent = cache[2].get(key)
+    if ent is None:
         nbytes = L.m355_conv3d_packed_bytes(C.byref(d), which)
         if nbytes == 0:
             return weight, 0
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=weight.device)
         check(L.m355_conv3d_pack(C.byref(d), which, _p(weight), _p(buf), _stream()), "conv3d_pack")
-        cache[2][key] = buf
-    return buf, _lib.CONV_W_PACKED
+        d0 = ConvDesc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.out_pad, 0, 0, d.compute, 0)
+        ent = cache[2][key] = (buf, d0)
+        if weight.is_leaf and isinstance(weight, torch.nn.Parameter):   # (derived weights -- blur / WS -- are new tensors every step)
+            _pack_registry[id(weight)] = weakref.ref(weight)
+    return ent[0], _lib.CONV_W_PACKED
 
 
 def _c8_twin(t, compute):

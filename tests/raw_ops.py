@@ -80,9 +80,26 @@ class RawOps:
         d = self.conv_desc(x_shape, w.shape[0], w.shape[2], 1, 1, compute=compute)
         n = self.lib.m355_conv3d_packed_bytes(C.byref(d), which)
         assert n > 0
-        buf = torch.empty(int(n), dtype=torch.uint8, device=self.device)
+        buf = torch.full((int(n),), 0xA5, dtype=torch.uint8, device=self.device)   # (bytes a layout leaves unwritten compare equal)
         self._chk(self.lib.m355_conv3d_pack(C.byref(d), which, _p(w), _p(buf), self._stream()), "conv3d_pack")
         return buf
+
+    def pack_weights_batch(self, cases):
+        """m355_conv3d_pack_batch over cases [(w, x_shape, which, compute)] -> list of packed buffers"""
+        items, bufs, keep = [], [], []
+        for w, x_shape, which, compute in cases:
+            w = self.to(w)
+            d = self.conv_desc(x_shape, w.shape[0], w.shape[2], 1, 1, compute=compute)
+            n = self.lib.m355_conv3d_packed_bytes(C.byref(d), which)
+            assert n > 0
+            buf = torch.full((int(n),), 0xA5, dtype=torch.uint8, device=self.device)
+            items.append(_lib.PackItem(d, which, w.data_ptr(), buf.data_ptr()))
+            bufs.append(buf)
+            keep.append(w)
+        arr = (_lib.PackItem * len(items))(*items)
+        self._chk(self.lib.m355_conv3d_pack_batch(C.cast(arr, C.c_void_p), len(items), self._stream()), "conv3d_pack_batch")
+        torch.cuda.synchronize()
+        return bufs
 
     def conv3d_fwd(self, x, w, bias=None, add=None, stride=1, pad=1, compute=0, packed=None, softmax=False):
         """packed: buffer from pack_weights(w, x.shape, 0) -> the call uses M355_CONV_W_PACKED;

@@ -173,6 +173,63 @@ def test_conv3d_packed_weights_reused_across_launches(hip, compute, env, tuning)
             assert torch.equal(hip.conv3d_bwd_data(dy, w, x.shape, compute=compute, packed=pkd), refd)
 
 
+def test_conv3d_pack_batch_matches_single_packs(hip):
+    """m355_conv3d_pack_batch writes the very bytes of one m355_conv3d_pack per item: fp32 / bf16 / fp16 layouts, forward
+    and data-gradient forms, ragged channel counts, the Cout <= 4 forward layout, and more items than one launch holds
+    (64 per launch)."""
+    cases = []
+    for i, (ci, co, D, H, W) in enumerate([(12, 40, 9, 10, 36), (16, 3, 8, 8, 32), (32, 32, 8, 16, 64), (4, 32, 8, 8, 32),
+                                           (96, 32, 8, 8, 32), (40, 80, 6, 6, 12), (320, 320, 4, 4, 8)]):
+        w = rnd(co, ci, 3, 3, 3, seed=10 + i)
+        for compute in (0, 1, 2):
+            for which in (0, 1):
+                if ci <= 4 and which == 1 and compute:
+                    continue
+                cases.append((w, (1 + i % 2, ci, D, H, W), which, compute))
+    assert len(cases) > 32
+    got = hip.pack_weights_batch(cases)
+    for (w, shp, which, compute), buf in zip(cases, got):
+        ref = hip.pack_weights(w, shp, which, compute)
+        assert torch.equal(buf, ref), (tuple(w.shape), shp, which, compute)   # (incl. the zeroed work-queue tail)
+
+
+def test_model_batched_repack_after_optimizer_step(golden):
+    """After optimizer.step the first conv re-packs every stale cached form of every parameter with one launch
+    (ops._repack_stale); the SGD trajectory is bit-identical to per-conv packing (M355_PACK_BATCH=0 path)."""
+    from functools import partial
+    from torch import nn
+    from segmentation_pipeline_amd import ops
+    from segmentation_pipeline_amd.models import ModularUNet
+    g = golden("unet_gn_convt.npz")
+    outs = []
+    for batch in (True, False):
+        model = ModularUNet(4, 3, [8, 16, 32], 3, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                            upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+        model.load_state_dict(g.state_dict("m.sd."))
+        model = model.cuda().train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        x = g.t("x").cuda()
+        ops.PACK_BATCH = batch
+        try:
+            for _ in range(3):
+                opt.zero_grad()
+                p = model(x)
+                (p * p).sum().backward()
+                opt.step()
+            w = model.down_blocks[1].layers.conv0.weight
+            stale_before = w._m355_packed[0] != w._version
+            with torch.no_grad():
+                outs.append(model(x))
+            assert stale_before and w._m355_packed[0] == w._version
+            if batch:   # every registered parameter was refreshed by that one pass, not only the first conv's
+                for q in model.parameters():
+                    c = getattr(q, "_m355_packed", None)
+                    assert c is None or c[0] == q._version
+        finally:
+            ops.PACK_BATCH = True
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_model_packed_weight_cache_follows_parameter_versions(golden):
     """ops caches the packed weights per parameter version: same results as with the cache off, re-packed after an
     optimizer step (SGD trajectory golden stays green in test_model_gpu.py), and keyed by the data pointer."""
