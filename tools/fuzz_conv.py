@@ -54,7 +54,7 @@ def fuzz_h16(cases, rng):
     variants, tiny residencies, split-K, tile heights) against the oracle on rounded operands."""
     hip, oracle = RawOps("hip"), RawOps("oracle")
     worst = 0.0
-    knobs = ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_H16_W8", "M355_H16_ONESHOT", "M355_BWW_NSPLIT")
+    knobs = ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_H16_W8", "M355_H16_ONESHOT", "M355_BWW_NSPLIT", "M355_H16_ORDER")
     for i in range(cases):
         compute = rng.choice([1, 2])
         dt = torch.bfloat16 if compute == 1 else torch.float16
@@ -73,6 +73,8 @@ def fuzz_h16(cases, rng):
             env["M355_H16_W8"] = str(rng.choice([0, 2, 2]))
         if rng.random() < 0.4:
             env["M355_BWW_NSPLIT"] = str(rng.choice([1, 2, 5]))
+        if rng.random() < 0.4:
+            env["M355_H16_ORDER"] = str(rng.choice([0, 1, 2]))
         for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -126,7 +128,7 @@ def main():
     for i in range(cases):
         N = rng.choice([1, 1, 2, 3])
         ci, co = rng.choice([1, 2, 3, 4, 5, 8, 12, 17, 32, 40, 80]), rng.choice([1, 3, 4, 7, 16, 31, 32, 33, 40, 48, 70, 80, 120])
-        D, H, W = rng.randint(1, 14), rng.randint(1, 22), rng.choice([1, 3, 4, 7, 8, 12, 16, 20, 24, 31, 32, 36, 40, 64])
+        D, H, W = rng.choice([rng.randint(1, 14), 16, 32]), rng.choice([rng.randint(1, 22), 16, 32]), rng.choice([1, 3, 4, 7, 8, 12, 16, 20, 24, 31, 32, 36, 40, 64])
         env = {}
         if rng.random() < 0.5:
             env["M355_CONV_SLOTS"] = str(rng.choice([1, 2, 3, 7, 16]))
@@ -138,7 +140,12 @@ def main():
             env["M355_BWW_GEN"] = "1"
         if rng.random() < 0.25:
             env["M355_TILE16"] = "0"
-        for k in ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_BWW_GEN", "M355_TILE16"):
+        if rng.random() < 0.4:   # item order: bit 0 = (y, z) tiles in 4x4 cubes, bit 1 = channel tile fastest
+            env["M355_CONV_CUBE"] = str(rng.choice([0, 1, 2]))
+        if rng.random() < 0.3:
+            env["M355_CONV_PERSISTENT"] = "2"
+        for k in ("M355_CONV_SLOTS", "M355_CONV_NTW", "M355_CONV_KSPLIT", "M355_BWW_GEN", "M355_TILE16", "M355_CONV_CUBE",
+                  "M355_CONV_PERSISTENT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         _reload()
