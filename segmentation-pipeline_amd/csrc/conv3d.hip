@@ -1721,8 +1721,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 }
 
 // dbias[o] = sum_{n,s} dy[n,o,s]: grid (chunks, Cout) of partial sums, then a fixed-order
-// finalize (deterministic).  Short fp32 runs per thread, double across threads / blocks.
-constexpr int DBIAS_CHUNK = 32768;
+// finalize (deterministic).  Short fp32 runs per thread, double across threads / blocks.  Chunks of 8192 voxels
+// (float4 loads, 8 per thread and sample): the 32768-voxel chunks this started with gave the small volumes of the
+// reference's dmri_hippo net (40 channels x 48x88x24) 160 workgroups of scalar loads -- 303 us for a 130 MB tensor.
+template <bool VEC>
 __global__ __launch_bounds__(256) void dbias_partial_kernel(const float* __restrict__ dy,
                                                             double* __restrict__ partial, int N,
                                                             int64_t S, int64_t ybs, int nblk) {
@@ -1733,7 +1735,14 @@ __global__ __launch_bounds__(256) void dbias_partial_kernel(const float* __restr
   for (int n = 0; n < N; ++n) {
     const float* p = dy + (int64_t)n * ybs + (int64_t)o * S;
     float part = 0.f;
-    for (int64_t s = begin + threadIdx.x; s < end; s += 256) part += p[s];
+    if (VEC) {   // S, ybs multiples of 4 and dy 16-byte aligned: every chunk starts on a float4
+      for (int64_t s = begin + threadIdx.x * 4; s < end; s += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s);
+        part += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int64_t s = begin + threadIdx.x; s < end; s += 256) part += p[s];
+    }
     acc += part;
   }
   const double tot = block_sum<double, 256>(acc, scratch);
@@ -2715,8 +2724,12 @@ static size_t dbias_ws_bytes(int Cout, int64_t S) {
 int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int64_t ybs, void* ws,
                  hipStream_t st) {
   const int nblk = (int)ceil_div(S, DBIAS_CHUNK);
-  hipLaunchKernelGGL(dbias_partial_kernel, dim3((unsigned)nblk, (unsigned)Cout), dim3(256), 0, st, dy,
-                     (double*)ws, N, S, ybs, nblk);
+  if (S % 4 == 0 && ybs % 4 == 0 && ((uintptr_t)dy & 15) == 0)
+    hipLaunchKernelGGL(dbias_partial_kernel<true>, dim3((unsigned)nblk, (unsigned)Cout), dim3(256), 0, st, dy,
+                       (double*)ws, N, S, ybs, nblk);
+  else
+    hipLaunchKernelGGL(dbias_partial_kernel<false>, dim3((unsigned)nblk, (unsigned)Cout), dim3(256), 0, st, dy,
+                       (double*)ws, N, S, ybs, nblk);
   hipLaunchKernelGGL(dbias_finalize_kernel, dim3((unsigned)ceil_div(Cout, 64)), dim3(64), 0, st,
                      (const double*)ws, dbias, Cout, nblk);
   return M355_OK;

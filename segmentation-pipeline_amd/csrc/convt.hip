@@ -816,7 +816,7 @@ static size_t convt_slab_bytes(const m355_conv3d_desc* d) {
 }
 static size_t convt_dbias_bytes(const m355_conv3d_desc* d) {
   const int64_t OS = (int64_t)convt_out(d->D, d) * convt_out(d->H, d) * convt_out(d->W, d);
-  const int64_t generic = (int64_t)d->Cout * ceil_div(OS, 32768) * 8;                    // launch_dbias partials
+  const int64_t generic = (int64_t)d->Cout * ceil_div(OS, DBIAS_CHUNK) * 8;              // launch_dbias partials
   const int64_t fused = is_k2s2(d) ? (int64_t)convt_nsplit(d) * d->Cout * 8 : 0;        // bslab[split][Cout]
   return (size_t)round_up(std::max(generic, fused), 256);
 }

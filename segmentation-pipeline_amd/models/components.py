@@ -13,6 +13,7 @@ no kernel (there is no torch fallback).
 from collections import OrderedDict
 from numbers import Number
 from typing import Optional
+import weakref
 
 import torch
 from torch import nn
@@ -69,6 +70,28 @@ def _blur_scale(kernel, weight):
     return kernel.reshape(kernel.shape[0], -1)[:, 0].contiguous()
 
 
+# Derived filters (box blur + rearrangement, weight standardisation) depend only on the parameters: outside autograd
+# they are computed once per parameter version and module, so an inference forward neither re-derives nor re-packs them
+# (the same tensor object comes back, and ops caches its packed forms).  Keyed by module in a weak dictionary: nothing is
+# added to the module itself (state_dict / pickled checkpoints stay as the reference's).
+_DERIVED = weakref.WeakKeyDictionary()
+
+
+def _derived_weight(mod, tag, make):
+    w = mod.weight
+    if torch.is_grad_enabled() and w.requires_grad:
+        return make()
+    k = getattr(mod, "kernel", None)
+    key = (tag, w._version, w.data_ptr(), None if k is None else (k._version, k.data_ptr()),
+           getattr(mod, "weight_standardization", None))
+    hit = _DERIVED.get(mod)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, make())
+        _DERIVED[mod] = hit
+    return hit[1]
+
+
 class WSConv3d(nn.Conv3d):
     """Weight-standardised convolution (reference components.py:76-88)."""
 
@@ -78,7 +101,7 @@ class WSConv3d(nn.Conv3d):
 
     def effective(self):
         # the reference forwards only **kwargs to F.conv3d, so the bias is unused (:86)
-        return ops.weight_standardize(self.weight), None
+        return _derived_weight(self, "ws", lambda: ops.weight_standardize(self.weight)), None
 
     def forward(self, x):
         return run_conv(self, x)
@@ -107,7 +130,8 @@ class BlurConv3d(nn.Conv3d):
         if _uniform_int(self.kernel_size, "kernel_size") == 3 and stride == 2 and pad == 1 and even:
             # effective 4x4x4 / stride 2 / padding 1 = a stride-1 3x3x3 conv over the space-to-depth input
             # (MFMA path); standardisation + box blur + rearrangement of the filter in one HIP kernel
-            wexp = ops.blur_weight(self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization)
+            wexp = _derived_weight(self, "s2d", lambda: ops.blur_weight(
+                self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization))
             return ops.conv3d(ops.space_to_depth2(x), wexp, None, stride=1, padding=1)
         return run_conv(self, x)
 
@@ -130,8 +154,8 @@ class BlurConvTranspose3d(nn.ConvTranspose3d):
                 and _uniform_int(self.output_padding, "output_padding") == 0):
             # effective 4x4x4 / stride 2 / padding 1: a 3x3x3 conv producing the 8 output parities, then
             # depth-to-space (MFMA path); filter transform in one HIP kernel
-            wexp = ops.blur_weight(self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization,
-                                   transposed=True)
+            wexp = _derived_weight(self, "d2s", lambda: ops.blur_weight(
+                self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization, transposed=True))
             return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1), out=out)
         w = self.weight
         if self.weight_standardization:

@@ -460,3 +460,27 @@ def test_residual_blocks_with_batch_gt1_match_cpu_oracle(norm):
     ld["loss"].backward()
     for k, v in model.named_parameters():
         grad_close(v.grad, sd[k].grad, k)
+
+
+def test_derived_filters_cached_outside_autograd():
+    """Blur / WS convolutions derive their filter from the parameter (box blur + rearrangement, standardisation): under
+    no_grad the derived tensor is computed once per parameter version (same object on the next forward, so its packed
+    forms are reused too), re-derived after an in-place update, and never cached while autograd needs its graph."""
+    from segmentation_pipeline_amd.models import components as K
+    torch.manual_seed(3)
+    m = BlurConv3d(8, 8, 3, stride=2, padding=1).cuda()
+    t = BlurConvTranspose3d(8, 8, 3, stride=2, padding=1, output_padding=0).cuda()
+    ws = WSConv3d(8, 8, 3, padding=1).cuda()
+    x = torch.randn(1, 8, 8, 8, 16, device="cuda")
+    with torch.no_grad():
+        y1, u1, s1 = m(x), t(x), ws(x)
+        w1 = K._DERIVED[m][1]
+        y2, u2, s2 = m(x), t(x), ws(x)
+        assert K._DERIVED[m][1] is w1 and torch.equal(y1, y2) and torch.equal(u1, u2) and torch.equal(s1, s2)
+        m.weight.mul_(0.5)
+        y3 = m(x)
+        assert K._DERIVED[m][1] is not w1 and maxerr(y3, 0.5 * y1.cpu()) < 1e-5
+    y4 = m(x)                       # autograd on: derived inside the graph, gradient reaches the parameter
+    y4.sum().backward()
+    assert m.weight.grad is not None and torch.equal(y4.detach(), y3)
+    assert "kernel" in m.state_dict() and not any("DERIVED" in k or "wexp" in k for k in m.__dict__)
