@@ -50,4 +50,7 @@ if "b" in which:
     text("conv_bf16.log", "r02_bf16_c8_conv_per_layer.txt")
     text("sliding.log", "r02_cfg4_sliding_window_phases.txt")
     text("bww_classes.log", "r02_bww_pair_classes.txt")
+    text("layers_dmri.log", "r02_dmri_hippo_per_layer.txt")
+    text("train_breakdown.log", "r02_train_step_breakdown.txt")
+    text("arch_breakdown.log", "r02_arch_kernel_breakdown.txt")
 print("profiles/:", " ".join(sorted(f for f in os.listdir(DST) if f.startswith("r02_"))))

@@ -25,6 +25,11 @@ case "${1:-a}" in
     step conv_bf16 200 python tools/conv_bench.py --bf16
     step sliding 300 python tools/sliding_window_bench.py
     step bww_classes 200 python tools/bww_class_probe.py
+    step layers_dmri 200 python tools/layer_table.py dmri_hippo
+    ( echo "cfg2 train step only (rocprofv3 kernel stats of bench.py --no-infer, 12 train steps), fp32"; bash tools/train_breakdown.sh fp32 | grep -v "^W20\|^{";
+      echo; echo "bf16"; bash tools/train_breakdown.sh bf16 | grep -v "^W20\|^{" ) > $O/train_breakdown.log 2>&1
+    ( echo "dmri_hippo, fp32: 13 train steps + 13 no-grad forwards, per iteration"; bash tools/arch_breakdown.sh dmri_hippo fp32 | grep -v "^W20";
+      echo; echo "msseg2, fp32"; bash tools/arch_breakdown.sh msseg2 fp32 | grep -v "^W20" ) > $O/arch_breakdown.log 2>&1
     ;;
 esac
 echo done
