@@ -37,6 +37,11 @@ def _build(which):
     torch.manual_seed(7)
     if which == "nested":
         return NestedResUNet(3, 2, 8).cuda()
+    if which == "unet_gn":   # GroupNorm statistics never cross samples: N ranks == a batch of N without any extra exchange
+        from functools import partial
+        from torch import nn
+        return ModularUNet(3, 2, [8, 16], 2, block_params={'normalization_class': partial(nn.GroupNorm, 4)},
+                           upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2}).cuda()
     return ModularUNet(3, 2, [8, 16], 2).cuda()   # Block3d default: BatchNorm3d
 
 
@@ -59,7 +64,7 @@ def _worker(rank, world, port, which, precision, ret):
         torch.cuda.set_device(0)
         ops.set_precision(precision)
         model = _build(which)
-        ddp = D.PatchParallel(model, sync_batch_norm=True)
+        ddp = D.PatchParallel(model, sync_batch_norm=which != "unet_gn", bucket_bytes=16 << 10)   # several buckets
         x, w = _inputs()
         per = SHAPE[0] // world
         xs, ws = x[rank * per:(rank + 1) * per].cuda(), w[rank * per:(rank + 1) * per].cuda()
@@ -75,7 +80,7 @@ def _close(a, b, tol, what):
 
 
 @pytest.mark.parametrize("which,precision,tol", [("unet_bn", "fp32", 1.0), ("nested", "fp32", 1.0),
-                                                 ("unet_bn", "bf16", 100.0)])
+                                                 ("unet_bn", "bf16", 100.0), ("unet_gn", "fp32", 1.0)])
 def test_sync_batch_norm_two_ranks_match_one_process(which, precision, tol):
     """bf16: the same operand roundings in both runs, only the fp32 statistics are summed in another order; the
     16-bit training flow takes the split backward with the c8 gradient twin (m355_norm_act_bwd_apply, dx16)."""
