@@ -21,13 +21,16 @@ def run(name, model, shape, ncls, cw=None, steps=10, warmup=3):
     gc.collect(); gc.freeze()   # keep a full collection (~90 ms of host stall) out of the timed steps, as bench.py does
     t0 = time.perf_counter()
     for _ in range(steps): step()
+    t_host = (time.perf_counter() - t0) / steps   # enqueue only: the loop has not synchronised yet
     torch.cuda.synchronize(); t_train = (time.perf_counter() - t0) / steps
     with torch.no_grad():
         for _ in range(warmup): model(x)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): model(x)
+        t_hinf = (time.perf_counter() - t0) / steps
         torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
-    print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)", flush=True)
+    print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)"
+          f" [host enqueue {t_host*1e3:.1f} / {t_hinf*1e3:.1f} ms]", flush=True)
 
 only = sys.argv[1] if len(sys.argv) > 1 else ""   # "msseg2" / "dmri_hippo" / "all": run one of the two (profiling)
 only = "" if only == "all" else only
