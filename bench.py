@@ -254,7 +254,8 @@ def main():
     model = build_model(cfg).to(device)
     crit = HybridLogisticDiceLoss()
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)  # research/msseg2/msseg2.py:94
-    runner = D.PatchParallel(model, force_collectives=force_ddp) if (world > 1 or force_ddp) else model
+    ddp_kw = {"tail_bucket_bytes": int(os.environ["M355_DDP_TAIL"])} if "M355_DDP_TAIL" in os.environ else {}   # (A/B hook)
+    runner = D.PatchParallel(model, force_collectives=force_ddp, **ddp_kw) if (world > 1 or force_ddp) else model
     predictor = StandardPredict(image_names=["X", "y"])
     x, lab, y = synth((args.batch, cin) + patch, cout, 1234 + rank, device)
     batch = {"X": x, "y": y}

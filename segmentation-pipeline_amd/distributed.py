@@ -84,9 +84,11 @@ class PatchParallel(nn.Module):
     """
 
     def __init__(self, module: nn.Module, bucket_bytes: int = 25 << 20, process_group=None,
-                 broadcast_parameters: bool = True, force_collectives: bool = False, sync_batch_norm: bool = False):
+                 broadcast_parameters: bool = True, force_collectives: bool = False, sync_batch_norm: bool = False,
+                 tail_bucket_bytes: int = 4 << 20):
         super().__init__()
         self.module = module
+        self.tail_bucket_bytes = tail_bucket_bytes
         self.group = process_group
         self.sync_batch_norm = sync_batch_norm
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -126,6 +128,20 @@ class PatchParallel(nn.Module):
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
+        # The all-reduce of the LAST bucket (the first layers' gradients, produced at the very end of backward) cannot
+        # overlap with anything: optimizer.step waits for it.  Its members are the smallest parameters of a U-Net, but
+        # a 25 MB bucket also swallows the mid-level layers in front of them; peel the tail off into a bucket of its
+        # own (<= tail_bucket_bytes: 3.5 MB for cfg2's d0..d2 convs) so only that much ring time is exposed.
+        tail = getattr(self, "tail_bucket_bytes", 0)
+        if groups and tail > 0:
+            last, peeled, peeled_bytes = groups[-1], [], 0
+            while len(last) > 1 and peeled_bytes + self.params[last[-1]].numel() * 4 <= tail:
+                peeled_bytes += self.params[last[-1]].numel() * 4
+                peeled.insert(0, last.pop())
+            if peeled and sum(self.params[i].numel() * 4 for i in last) > tail:
+                groups.append(peeled)
+            else:
+                last.extend(peeled)   # nothing to gain: the bucket was small anyway
         for b, idxs in enumerate(groups):
             total = sum(self.params[i].numel() for i in idxs)
             dev = self.params[idxs[0]].device

@@ -439,3 +439,22 @@ def test_samplers_index_arithmetic_and_distribution():
     finally:
         S.torch.rand = orig
     assert (locs >= 0).all() and (locs[:, 0] <= 6).all() and (locs[:, 1] <= 6).all() and (locs[:, 2] <= 6).all()
+
+
+def test_tail_bucket_is_peeled_off():
+    """The last bucket's all-reduce is the one nothing overlaps with (optimizer.step waits for it): the small first-layer
+    parameters at the end of the reverse order get a bucket of their own, every parameter still lives in exactly one."""
+    layers = [nn.Conv3d(4, 8, 3), nn.Conv3d(8, 8, 3), nn.Conv3d(8, 64, 3), nn.Conv3d(64, 64, 3), nn.Conv3d(64, 128, 3)]
+    model = nn.Sequential(*layers)
+    size = lambda pp, b: sum(pp.params[i].numel() * 4 for i in pp.members[b])
+    plain = D.PatchParallel(model, bucket_bytes=2 << 20, tail_bucket_bytes=0)
+    peeled = D.PatchParallel(model, bucket_bytes=2 << 20, tail_bucket_bytes=64 << 10)
+    assert len(peeled.members) == len(plain.members) + 1
+    assert size(peeled, len(peeled.members) - 1) <= 64 << 10 < size(plain, len(plain.members) - 1)
+    seen = sorted(i for m in peeled.members for i in m)
+    assert seen == list(range(len(peeled.params)))
+    # reverse parameter order is kept: the peeled bucket holds the EARLIEST layers
+    assert peeled.members[-1][-1] == 0 and peeled.members[-1] == sorted(peeled.members[-1], reverse=True)
+    # a last bucket that is small anyway is left alone
+    small = D.PatchParallel(nn.Sequential(*layers[:2]), bucket_bytes=2 << 20, tail_bucket_bytes=4 << 20)
+    assert len(small.members) == 1
