@@ -96,20 +96,33 @@ struct Lin {
   int i0, i1;
   float l0, l1;
 };
-__device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
+__device__ __forceinline__ float lin_ratio(int in, int out) {
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+}
+// `ratio` = lin_ratio(in, out): a correctly rounded division is ~12 instructions, and the backward evaluates 24
+// coordinates per element
+__device__ __forceinline__ Lin lin_coord(int o, int in, int out, float ratio) {
   Lin r;
   if (in == out) {
     r.i0 = r.i1 = o; r.l0 = 1.f; r.l1 = 0.f;
     return r;
   }
-  const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-  const float src = ratio * (float)o;
-  r.i0 = min((int)floorf(src), in - 1);
-  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  // rounded product, then rounded difference, as ATen computes them: contracted into one fma the weight differs by up
+  // to half an ulp of src (4e-6 at index 64) and the interpolated value by that times the local slope
+  // (HIP's __fmul_rn / __fsub_rn are plain operators and contract like any other: the pragma is what keeps them apart)
+  float src, frac;
+  {
+#pragma clang fp contract(off)
+    src = ratio * (float)o;
+    r.i0 = min((int)floorf(src), in - 1);
+    frac = src - (float)r.i0;
+  }
+  r.l1 = fminf(fmaxf(frac, 0.f), 1.f);
   r.l0 = 1.f - r.l1;
   r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
   return r;
 }
+__device__ __forceinline__ Lin lin_coord(int o, int in, int out) { return lin_coord(o, in, out, lin_ratio(in, out)); }
 
 __global__ __launch_bounds__(256) void trilinear2_fwd_kernel(const float* __restrict__ x,
                                                              float* __restrict__ y, int N, int C,
@@ -181,10 +194,57 @@ __global__ __launch_bounds__(256) void trilinear2_fwd_q_kernel(const float* __re
   }
 }
 
+// The same through LDS: a workgroup owns 4 output planes x 16 output rows x all columns of one (n, c) volume, stages the
+// <= 4 x 10 input rows they read (coalesced) and takes its eight taps per output from LDS instead of eight scattered
+// global loads -- the quad kernel above is load-instruction-bound (32 L1 loads per thread, 1.9 TB/s of output).
+// Same expressions per output as the other two forward kernels.
+constexpr int TRI_TZ = 4, TRI_TY = 16, TRI_PZ = 4, TRI_PY = 10;
+__global__ __launch_bounds__(256) void trilinear2_fwd_lds_kernel(const float* __restrict__ x,
+                                                                 float* __restrict__ y, int C, int D, int H,
+                                                                 int W, int64_t xbs, int64_t ybs) {
+  extern __shared__ float tri_lds[];   // [TRI_PZ][TRI_PY][W]
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W, OW4 = OW >> 2;
+  const int nc = blockIdx.z, n = nc / C, c = nc % C;
+  const int oz0 = blockIdx.y * TRI_TZ, oy0 = blockIdx.x * TRI_TY;
+  const int zlo = lin_coord(oz0, D, OD).i0, ylo = lin_coord(oy0, H, OH).i0;
+  const float* xp = x + (int64_t)n * xbs + (int64_t)c * D * H * W;
+  // rows past the volume are clamped duplicates (never selected: the coordinates clamp the same way)
+  for (int i = threadIdx.x; i < TRI_PZ * TRI_PY * W; i += 256) {
+    const int xx = i % W, r = i / W;
+    const int py = r % TRI_PY, pz = r / TRI_PY;
+    tri_lds[i] = xp[((int64_t)min(zlo + pz, D - 1) * H + min(ylo + py, H - 1)) * W + xx];
+  }
+  __syncthreads();
+  float* yp = y + (int64_t)n * ybs + (int64_t)c * OD * OH * OW;
+  for (int i = threadIdx.x; i < TRI_TZ * TRI_TY * OW4; i += 256) {
+    const int q = i % OW4, r = i / OW4;
+    const int oy = oy0 + r % TRI_TY, oz = oz0 + r / TRI_TY;
+    if (oy >= OH || oz >= OD) continue;
+    const Lin lz = lin_coord(oz, D, OD), ly = lin_coord(oy, H, OH);
+    const float* p00 = tri_lds + ((lz.i0 - zlo) * TRI_PY + (ly.i0 - ylo)) * W;
+    const float* p01 = tri_lds + ((lz.i0 - zlo) * TRI_PY + (ly.i1 - ylo)) * W;
+    const float* p10 = tri_lds + ((lz.i1 - zlo) * TRI_PY + (ly.i0 - ylo)) * W;
+    const float* p11 = tri_lds + ((lz.i1 - zlo) * TRI_PY + (ly.i1 - ylo)) * W;
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Lin lx = lin_coord(4 * q + k, W, OW);
+      const float r00 = lx.l0 * p00[lx.i0] + lx.l1 * p00[lx.i1];
+      const float r01 = lx.l0 * p01[lx.i0] + lx.l1 * p01[lx.i1];
+      const float r10 = lx.l0 * p10[lx.i0] + lx.l1 * p10[lx.i1];
+      const float r11 = lx.l0 * p11[lx.i0] + lx.l1 * p11[lx.i1];
+      const float v0 = ly.l0 * r00 + ly.l1 * r01;
+      const float v1 = ly.l0 * r10 + ly.l1 * r11;
+      o[k] = lz.l0 * v0 + lz.l1 * v1;
+    }
+    *reinterpret_cast<float4*>(yp + ((int64_t)oz * OH + oy) * OW + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // weight with which output o (size out) reads input i (size in)
-__device__ __forceinline__ float lin_weight(int o, int i, int in, int out) {
+__device__ __forceinline__ float lin_weight(int o, int i, int in, int out, float ratio) {
   if (o < 0 || o >= out) return 0.f;
-  const Lin l = lin_coord(o, in, out);
+  const Lin l = lin_coord(o, in, out, ratio);
   return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
 }
 
@@ -196,6 +256,7 @@ __global__ __launch_bounds__(256) void trilinear2_bwd_kernel(const float* __rest
                                                              int64_t dxbs) {
   const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
   const int64_t total = (int64_t)N * C * D * H * W;
+  const float rz = lin_ratio(D, OD), ry = lin_ratio(H, OH), rx = lin_ratio(W, OW);
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
     const int ix = (int)(i % W);
     int64_t r = i / W;
@@ -209,13 +270,13 @@ __global__ __launch_bounds__(256) void trilinear2_bwd_kernel(const float* __rest
     float wx[8], wy[8];   // (the y weights once per element, not once per z tap: 24 weight evaluations instead of 80)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      wx[k] = lin_weight(2 * ix - 3 + k, ix, W, OW);
-      wy[k] = lin_weight(2 * iy - 3 + k, iy, H, OH);
+      wx[k] = lin_weight(2 * ix - 3 + k, ix, W, OW, rx);
+      wy[k] = lin_weight(2 * iy - 3 + k, iy, H, OH, ry);
     }
     float acc = 0.f;
     for (int kz = 0; kz < 8; ++kz) {
       const int oz = 2 * iz - 3 + kz;
-      const float wz = lin_weight(oz, iz, D, OD);
+      const float wz = lin_weight(oz, iz, D, OD, rz);
       if (wz == 0.f) continue;
 #pragma unroll
       for (int ky = 0; ky < 8; ++ky) {
@@ -463,7 +524,12 @@ extern "C" int m355_upsample_trilinear2x_fwd(const float* x, float* y, int32_t N
   const int64_t xbs = dense_or(x_batch_stride, (int64_t)C * D * H * W);
   const int64_t ybs = dense_or(y_batch_stride, (int64_t)C * D * H * W * 8);
   const int64_t total = (int64_t)N * C * D * H * W * 8;
-  if (W % 2 == 0 && ybs % 4 == 0 && ((uintptr_t)y & 15) == 0 && (int64_t)N * C * D * H * 4 < (1ll << 31))
+  const bool quads = W % 2 == 0 && ybs % 4 == 0 && ((uintptr_t)y & 15) == 0;
+  const size_t lds = (size_t)TRI_PZ * TRI_PY * W * sizeof(float);
+  if (quads && D >= 2 && H >= 2 && lds <= 48 * 1024 && (int64_t)N * C <= 65535 && ceil_div(2 * D, TRI_TZ) <= 65535) {
+    dim3 grid((unsigned)ceil_div(2 * H, TRI_TY), (unsigned)ceil_div(2 * D, TRI_TZ), (unsigned)(N * C));
+    hipLaunchKernelGGL(trilinear2_fwd_lds_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, C, D, H, W, xbs, ybs);
+  } else if (quads && (int64_t)N * C * D * H * 4 < (1ll << 31))
     hipLaunchKernelGGL(trilinear2_fwd_q_kernel, dim3(grid_for(total / 4, 256, 65536)), dim3(256), 0,
                        (hipStream_t)stream, x, y, N, C, D, H, W, xbs, ybs);
   else

@@ -365,7 +365,7 @@ def test_pool_upsample_softmax(hip, oracle):
         close(hip.avgpool_bwd(dy, x.shape), oracle.avgpool_bwd(dy, x.shape), 0, 0, "pool bwd")
     # (even W: four outputs per thread + float4 stores; odd W: the one-output-per-thread kernel)
     for shape in [(1, 2, 3, 4, 5), (2, 1, 1, 2, 2), (1, 3, 8, 8, 8), (1, 1, 2, 2, 2), (2, 3, 6, 11, 12), (1, 2, 5, 3, 7),
-                  (2, 5, 12, 22, 6)]:
+                  (2, 5, 12, 22, 6), (1, 2, 9, 17, 40), (2, 1, 5, 8, 33), (1, 1, 2, 3, 70)]:   # (several backward tiles per axis)
         x = rnd(*shape, seed=3)
         yo = oracle.upsample_fwd(x)
         close(hip.upsample_fwd(x), yo, 2e-6, 2e-6, "up fwd")
