@@ -183,3 +183,51 @@ def test_cfg4_sliding_window_full_size():
     assert (out.cpu() - ref).abs().max().item() <= 1e-5
     del out, acc, cnt, ref
     torch.cuda.empty_cache()
+
+
+def test_msseg2_full_size_residual_blur_bn_vs_cpu_oracle():
+    """The architecture the reference trained for MSSEG-2 (research/msseg2/msseg2.py:84-93,142: 6 levels of 40/40/80/80/
+    120/120 filters, residual blocks, BatchNorm, BlurConv3d / BlurConvTranspose3d, class weights [1, 100]) at its full
+    1x2x96^3 patch: probabilities, losses and every parameter gradient against the CPU oracle.  The widths are no
+    multiples of 32 (16-row remainder tiles, weight-gradient pair classes) and every level runs the space-to-depth form
+    of the Blur convolutions -- paths the BASELINE configs above never take at this size."""
+    from segmentation_pipeline_amd.models import BlurConv3d, BlurConvTranspose3d
+    filters = [40, 40, 80, 80, 120, 120]
+    torch.manual_seed(0)
+    model = ModularUNet(2, 2, filters, 6, block_params={'residual': True}, downsample_class=BlurConv3d,
+                        downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
+                        upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0})
+    x, lab, y = _synth((1, 2, 96, 96, 96), 2)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k and "kernel" not in k)
+          for k, v in model.state_dict().items()}
+    spec = R.UNetSpec(2, 2, filters, 6, norm="batch", residual=True, down="blur", up="blurT")
+    torch.set_num_threads(16)
+    p_ref = R.unet_forward(sd, spec, x, training=True)
+    ld_ref = R.hybrid_logistic_dice_loss(p_ref, y, class_weights=[1.0, 100.0])
+    ld_ref["loss"].backward()
+    model = model.cuda().train()
+    with sp.precision("fp32"):
+        p = model(x.cuda())
+        ld = HybridLogisticDiceLoss(logistic_class_weights=[1, 100])(p, y.cuda())
+        ld["loss"].backward()
+    assert (p.detach().cpu() - p_ref.detach()).abs().max().item() <= 1e-4
+    for k in ("loss", "dice_loss", "logistic_loss"):
+        assert abs(ld[k].item() - float(ld_ref[k].detach())) <= 1e-4 * max(1.0, abs(float(ld_ref[k].detach()))), k
+    checked = 0
+    # gradients that are analytically zero (a conv bias in front of BatchNorm) are rounding noise on both sides: the
+    # noise floor is set by the largest gradient of the network
+    floor = 1e-6 * max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+    for k, v in model.named_parameters():
+        ref = sd[k].grad
+        if ref is None:          # (the Blur convolutions never use their bias: no gradient on either side)
+            assert v.grad is None or v.grad.abs().max().item() == 0, k
+            continue
+        ref, got = ref.double(), v.grad.cpu().double()
+        err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+        assert abs(got.norm().item() - ref.norm().item()) <= 2e-3 * ref.norm().item() + floor * ref.numel() ** 0.5, \
+            (k, got.norm().item(), ref.norm().item())
+        assert err <= 1e-2 * scale + floor, (k, err, scale, floor)
+        checked += 1
+    assert checked >= 60
+    model.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
