@@ -231,3 +231,47 @@ def test_msseg2_full_size_residual_blur_bn_vs_cpu_oracle():
     assert checked >= 60
     model.zero_grad(set_to_none=True)
     torch.cuda.empty_cache()
+
+
+def test_dmri_hippo_full_size_nested_res_unet_vs_cpu_oracle():
+    """The reference's production hippocampus model (research/dmri_hippo/configs/main_config.py:123-127:
+    NestedResUNet(3, 2, 40), BatchNorm over the batch, AvgPool down, trilinear x2 up, 2-/3-way concats) on the batch its
+    inference feeds it -- the sagittal split of 4x3x96x88x24 into 8x3x48x88x24 (prediction.py:59-66): probabilities,
+    losses and every parameter gradient against the CPU oracle (oracle.torch_ref.nested_res_unet_forward, itself pinned
+    to the real module by tests/golden/nested_res_unet.npz)."""
+    from segmentation_pipeline_amd.models import NestedResUNet
+    torch.manual_seed(0)
+    model = NestedResUNet(3, 2, 40)
+    x, lab, y = _synth((8, 3, 48, 88, 24), 2)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in model.state_dict().items()}
+    torch.set_num_threads(16)
+    p_ref = R.nested_res_unet_forward(sd, x, training=True)
+    ld_ref = R.hybrid_logistic_dice_loss(p_ref, y)
+    ld_ref["loss"].backward()
+    model = model.cuda().train()
+    with sp.precision("fp32"):
+        p = model(x.cuda())
+        ld = HybridLogisticDiceLoss()(p, y.cuda())
+        ld["loss"].backward()
+    assert (p.detach().cpu() - p_ref.detach()).abs().max().item() <= 1e-4
+    for k in ("loss", "dice_loss", "logistic_loss"):
+        assert abs(ld[k].item() - float(ld_ref[k].detach())) <= 1e-4, k
+    floor = 1e-6 * max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+    checked = 0
+    for k, v in model.named_parameters():
+        ref, got = sd[k].grad.double(), v.grad.cpu().double()
+        err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+        assert abs(got.norm().item() - ref.norm().item()) <= 2e-3 * ref.norm().item() + floor * ref.numel() ** 0.5, \
+            (k, got.norm().item(), ref.norm().item())
+        assert err <= 1e-2 * scale + floor, (k, err, scale, floor)
+        checked += 1
+    assert checked >= 60
+    # running statistics after the step: BatchNorm's momentum update with the unbiased variance over N*S = 8*101376
+    with torch.no_grad():
+        bn = model.conv0_0.bn1
+        y1 = torch.nn.functional.conv3d(x, sd["conv0_0.conv1.weight"].detach(), None, padding=1)
+        assert (bn.running_mean.cpu() - 0.1 * y1.mean(dim=(0, 2, 3, 4))).abs().max().item() <= 1e-5
+        assert (bn.running_var.cpu() - (0.9 + 0.1 * y1.var(dim=(0, 2, 3, 4), unbiased=True))).abs().max().item() <= 1e-4
+    model.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()

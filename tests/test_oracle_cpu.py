@@ -391,6 +391,30 @@ def test_torch_ref_reproduces_reference_unet(golden, name):
     np.testing.assert_allclose(pe.numpy(), g["m.probs_eval"], rtol=0, atol=2e-6)
 
 
+def test_torch_ref_reproduces_reference_nested_res_unet(golden):
+    """oracle.torch_ref.nested_res_unet_forward against the outputs of the REAL NestedResUNet (tools/gen_golden.py):
+    training-mode probabilities, loss, every gradient, eval-mode probabilities after the step."""
+    g = golden("nested_res_unet.npz")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in g.state_dict("m.sd.").items()}
+    x, y = g.t("x"), g.t("y")
+    p = R.nested_res_unet_forward(sd, x, training=True)
+    np.testing.assert_allclose(p.detach().numpy(), g["m.probs_train"], rtol=0, atol=2e-6)
+    ld = R.hybrid_logistic_dice_loss(p, y, 0.5, None, True)
+    assert ld["loss"].item() == pytest.approx(float(g["m.loss"]), rel=1e-5)
+    ld["loss"].backward()
+    n = 0
+    for k, v in sd.items():
+        if f"m.grad.{k}" in g.keys():
+            close(v.grad, g.t(f"m.grad.{k}"), 1e-4, 1e-6)
+            n += 1
+    assert n >= 60
+    if "m.probs_eval" in g.keys():
+        with torch.no_grad():
+            pe = R.nested_res_unet_forward(dict(g.state_dict("m.sd_after.")), x, training=False)
+        np.testing.assert_allclose(pe.numpy(), g["m.probs_eval"], rtol=0, atol=2e-6)
+
+
 def test_split_and_flip_fixture(golden):
     g = golden("components.npz")
     x = g.t("split.x")
