@@ -230,6 +230,12 @@ def test_msseg2_full_size_residual_blur_bn_vs_cpu_oracle():
         checked += 1
     assert checked >= 60
     model.zero_grad(set_to_none=True)
+    # the same forward in the 16-bit operand modes (c8 activation flow under no_grad; BatchNorm on batch statistics):
+    # whole-network effect of the operand rounding against the fp32 oracle, BASELINE cfg3 / cfg5 tolerances
+    for mode, tol in (("bf16", 2e-2), ("fp16", 5e-3)):
+        with torch.no_grad(), sp.precision(mode):
+            err = (model(x.cuda()).cpu() - p_ref.detach()).abs().max().item()
+        assert 1e-7 < err <= tol, (mode, err)
     torch.cuda.empty_cache()
 
 
@@ -274,4 +280,8 @@ def test_dmri_hippo_full_size_nested_res_unet_vs_cpu_oracle():
         assert (bn.running_mean.cpu() - 0.1 * y1.mean(dim=(0, 2, 3, 4))).abs().max().item() <= 1e-5
         assert (bn.running_var.cpu() - (0.9 + 0.1 * y1.var(dim=(0, 2, 3, 4), unbiased=True))).abs().max().item() <= 1e-4
     model.zero_grad(set_to_none=True)
+    for mode, tol in (("bf16", 2e-2), ("fp16", 5e-3)):   # (as in the msseg2 test above)
+        with torch.no_grad(), sp.precision(mode):
+            err = (model(x.cuda()).cpu() - p_ref.detach()).abs().max().item()
+        assert 1e-7 < err <= tol, (mode, err)
     torch.cuda.empty_cache()
