@@ -484,3 +484,36 @@ def test_derived_filters_cached_outside_autograd():
     y4.sum().backward()
     assert m.weight.grad is not None and torch.equal(y4.detach(), y3)
     assert "kernel" in m.state_dict() and not any("DERIVED" in k or "wexp" in k for k in m.__dict__)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_forward_and_graphed_sliding_window_are_bit_identical(golden, precision):
+    """prediction.GraphedForward replays the no-grad forward from a hipGraph: the same bits as the eager forward, one
+    capture per input shape, a new capture after the parameters change; PatchPredict(graph=True) == graph=False."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.prediction import GraphedForward, PatchPredict
+    g = golden("unet_gn_convt.npz")
+    model = BUILDERS["unet_gn_convt.npz"][0]()
+    model.load_state_dict(g.state_dict("m.sd."))
+    model = model.cuda().eval()
+    with sp.precision(precision):
+        gf = GraphedForward(model)
+        xs = [torch.randn(2, 4, 16, 16, 16, device="cuda", generator=torch.Generator("cuda").manual_seed(s)) for s in (1, 2, 3)]
+        with torch.no_grad():
+            eager = [model(x) for x in xs]
+        for x, e in zip(xs, eager):
+            assert torch.equal(gf(x), e)
+        assert len(gf._graphs) == 1
+        y_other = gf(torch.randn(1, 4, 8, 16, 16, device="cuda"))          # another shape: its own capture
+        assert y_other.shape == (1, 3, 8, 16, 16) and len(gf._graphs) == 2
+        with torch.no_grad():
+            model.out_conv.bias.add_(0.5)                                   # parameters changed: captured again
+            e2 = model(xs[0])
+        assert torch.equal(gf(xs[0]), e2) and not torch.equal(e2, eager[0])
+        vol = torch.randn(4, 40, 40, 40, generator=torch.Generator().manual_seed(5))
+        outs = []
+        for graph in (False, True):
+            pp = PatchPredict(patch_batch_size=2, patch_size=16, patch_overlap=4, graph=graph)
+            outs.append(pp.predict(model, torch.device("cuda"), {"X": vol[None]})["y_pred"][0])
+        assert torch.equal(outs[0], outs[1])
+        assert (outs[1].sum(dim=0) - 1).abs().max().item() <= 1e-5
