@@ -189,3 +189,13 @@ def test_reference_format_checkpoint_roundtrip(golden, tmp_path):
     for k in ref:
         assert torch.equal(sd[k], ref[k]), k
     assert len(built["optimizer"].param_groups[0]["params"]) == len(list(built["model"].parameters()))
+
+
+def test_graphed_forward_is_transparent_off_the_gpu():
+    """prediction.GraphedForward only captures on the GPU: with a CPU tensor it is the plain call (the CPU double of the
+    distributed tests goes through PatchPredict(graph=True) unchanged)."""
+    from segmentation_pipeline_amd.prediction import GraphedForward
+    lin = torch.nn.Conv3d(2, 3, 1)
+    gf = GraphedForward(lin)
+    x = torch.randn(1, 2, 3, 4, 5)
+    assert torch.equal(gf(x), lin(x)) and not gf._graphs
