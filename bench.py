@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: BASELINE.json's metric on its cfg2 workload.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W          (any N: with N > 1 and no WORLD_SIZE in the
+                                                             environment it starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --workload cfg3               (cfg2 network, bf16 operands: BASELINE cfg3)
+    python bench.py --gpus N --workload cfg4               (sliding-window inference, tiles sharded over the ranks)
 
 A "step" is one iteration of the reference's training loop (segmentation_trainer.py:162-180:
 train() -> forward -> criterion -> zero_grad -> backward -> optimizer.step -> eval()) on one
@@ -174,15 +177,28 @@ def roofline_of(prof, precision, full_prof=None):
     return out
 
 
-def cpu_baseline(cfg, batch):
+def _timed(fn, warmup=1, reps=3):
+    """BASELINE.md section 3 / SURVEY section 8d protocol for the CPU leg: `warmup` untimed + `reps` timed iterations -> (mean s, last result)"""
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    t0 = time.time()
+    for _ in range(reps):
+        out = fn()
+    return (time.time() - t0) / reps, out
+
+
+def cpu_baseline(cfg, batch, train=True, n_out=None):
     """Stock torch-CPU restatement of the reference path (oracle/torch_ref.py, pinned to the real
-    reference by tests/golden) on a bounded sample: ONE no-grad forward + ONE train step of the
-    same workload on the host cores."""
+    reference by tests/golden) on a bounded sample of the same workload on the host cores: 1 warm-up + 3 timed
+    no-grad forwards and (train=True) 1 warm-up + 3 timed train steps."""
     from oracle import torch_ref as R
     cin, cout, filters, depth, patch = cfg
+    cout = cout if n_out is None else n_out
     torch.manual_seed(0)
-    model = build_model(cfg)
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    model = build_model((cin, cout, filters, depth, patch))
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
     spec = R.UNetSpec(cin, cout, filters, depth, norm="group", groups=8, up="convT")
     g = torch.Generator().manual_seed(1234)
     x = torch.randn((batch, cin) + patch, generator=g)
@@ -191,47 +207,111 @@ def cpu_baseline(cfg, batch):
     # the GPU box gives one GPU a share of 16 host cores (os.cpu_count() reports the whole host)
     cores = min(os.cpu_count() or 1, int(os.environ.get("M355_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    params = [v for v in sd.values() if v.requires_grad]
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.95)
+
+    def infer():
+        with torch.no_grad():
+            return R.unet_forward(sd, spec, x, training=False)
+    t_inf, p0 = _timed(infer)
+    # Dice of the seed-0 weights BEFORE any update (what the GPU's step-0 figures are compared with)
     with torch.no_grad():
-        t0 = time.time()
-        p = R.unet_forward(sd, spec, x, training=False)
-        t_inf = time.time() - t0
-    t0 = time.time()
-    p = R.unet_forward(sd, spec, x, training=True)
-    ld = R.hybrid_logistic_dice_loss(p, y)
-    opt.zero_grad()
-    ld["loss"].backward()
-    opt.step()
-    t_train = time.time() - t0
-    return {"value": batch / t_train, "unit": "patches/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
-            "kind": "port",
-            "sample": f"1 no-grad forward ({t_inf:.2f} s) + 1 train step ({t_train:.2f} s) of the same "
-                      f"{batch}x{cin}x{'x'.join(map(str, patch))} workload, torch-CPU restatement of the reference",
-            "infer_value": batch / t_inf, "dice_loss": float(ld["dice_loss"]), "loss": float(ld["loss"]),
-            "_probs": p.detach()}
+        ld0 = R.hybrid_logistic_dice_loss(p0, y)
+    out = {"unit": "patches/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
+           "infer_value": batch / t_inf, "dice_loss": float(ld0["dice_loss"]), "loss": float(ld0["loss"]), "_probs": p0.detach()}
+    shape = f"{batch}x{cin}x{'x'.join(map(str, patch))}"
+    if train:
+        params = [v for v in sd.values() if v.requires_grad]
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.95)
+
+        def step():
+            p = R.unet_forward(sd, spec, x, training=True)
+            ld = R.hybrid_logistic_dice_loss(p, y)
+            opt.zero_grad()
+            ld["loss"].backward()
+            opt.step()
+            return ld
+        t_train, _ = _timed(step)
+        out.update({"value": batch / t_train,
+                    "sample": f"1 warm-up + 3 timed no-grad forwards ({t_inf:.2f} s each) and 1 warm-up + 3 timed train steps "
+                              f"({t_train:.2f} s each) of the same {shape} workload, torch-CPU restatement of the reference"})
+    else:
+        out.update({"value": batch / t_inf,
+                    "sample": f"1 warm-up + 3 timed no-grad forwards ({t_inf:.2f} s each) of one {shape} tile of the same "
+                              f"sliding window, torch-CPU restatement of the reference"})
+    return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (one per GPU, torchrun's
+    own elastic agent) before this process has made any GPU call, forward their output (rank 0 prints the JSON line)
+    and return their exit code.  Nothing is re-exec'ed: this parent stays a plain CPU process."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS) + ["cfg3", "cfg4"],
+                    help="cfg2: the headline (fp32 train step + inference forward); cfg3 = cfg2 with --precision bf16; "
+                         "cfg4: sliding-window inference of a 4x256^3 volume (patch 160, overlap 20), tiles sharded over the ranks")
     ap.add_argument("--batch", type=int, default=1, help="patches per rank per step")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"],
                     help="arithmetic of the 3x3x3 convolutions (default: exact fp32, the BASELINE cfg2 mode; bf16 / fp16: "
                          "16-bit operands, fp32 accumulate -- BASELINE cfg3 / cfg5)")
+    ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="wire type of the gradient all-reduce buckets (bf16 halves the RCCL volume; fp32 master gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--launch-probe", default=None, help=argparse.SUPPRESS)   # tests: each rank writes its env here and exits
+    args = ap.parse_args(argv)
+    if args.workload == "cfg3":
+        args.workload, args.precision = "cfg2", args.precision or "bf16"
+    args.precision = args.precision or "fp32"
+    return args
 
+
+def rccl_info(world):
+    if not dist.is_initialized():
+        return {"ranks": 1, "backend": None, "version": None}
+    try:
+        ver = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception:   # noqa: BLE001 -- informational only
+        ver = None
+    return {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "version": ver}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one (before any GPU call in this process)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_probe:
+        with open(os.path.join(args.launch_probe, f"rank{rank}.json"), "w") as f:
+            json.dump({"rank": rank, "world": world, "local_rank": local_rank, "gpus": args.gpus,
+                       "master": os.environ.get("MASTER_ADDR")}, f)
+        return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; measuring {world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -241,30 +321,63 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    import segmentation_pipeline_amd as sp
+    sp.set_precision(args.precision)
+    if args.workload == "cfg4":
+        out = run_window(args, rank, world, device)
+    else:
+        out = run_train(args, rank, world, device, force_ddp)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    # The CPU leg runs on rank 0 after the process group is gone (the other ranks have left; no collective can time
+    # out behind ~30 s of host work) and for every N, so each line of a scaling run carries its own baseline.
+    if not args.no_cpu_baseline:
+        finish = out.pop("_cpu_leg")
+        finish(out)
+    out.pop("_cpu_leg", None)
+    print(json.dumps(out), flush=True)
+
+
+def barrier():
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, device):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dtype_label(precision):
+    return "f32" if precision == "fp32" else f"{precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere"
+
+
+def run_train(args, rank, world, device, force_ddp):
     from segmentation_pipeline_amd import distributed as D
     from segmentation_pipeline_amd import ops
     from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
     from segmentation_pipeline_amd.prediction import StandardPredict
     from segmentation_pipeline_amd.trainer import PhaseTimer, hard_dice_from_counts, train_step
 
-    import segmentation_pipeline_amd as sp
-    sp.set_precision(args.precision)
     cfg = WORKLOADS[args.workload]
     cin, cout, filters, depth, patch = cfg
     model = build_model(cfg).to(device)
     crit = HybridLogisticDiceLoss()
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)  # research/msseg2/msseg2.py:94
     ddp_kw = {"tail_bucket_bytes": int(os.environ["M355_DDP_TAIL"])} if "M355_DDP_TAIL" in os.environ else {}   # (A/B hook)
+    if args.bucket_dtype == "bf16":
+        ddp_kw["bucket_dtype"] = torch.bfloat16
     runner = D.PatchParallel(model, force_collectives=force_ddp, **ddp_kw) if (world > 1 or force_ddp) else model
     predictor = StandardPredict(image_names=["X", "y"])
     x, lab, y = synth((args.batch, cin) + patch, cout, 1234 + rank, device)
     batch = {"X": x, "y": y}
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # ---- Dice vs CPU reference: first forward from the seed-0 weights, before any update ----
     model.eval()
@@ -273,6 +386,7 @@ def main():
     am, counts = ops.argmax_confusion(p0, lab.to(torch.int32))
     gpu_dice0 = float(crit(p0, y)["dice_loss"])
     hard0 = hard_dice_from_counts(counts)[0].tolist()
+    p0_cpu, am_cpu_gpu, lab_cpu = (p0.cpu(), am.cpu().long(), lab.cpu()) if rank == 0 else (None, None, None)
 
     # The last warm-up step is event-timed launch by launch (per-op summary + which kernel dominates); inside the
     # timed region only the dominant kernel's launches carry timing events (the roofline measurement), so the
@@ -302,10 +416,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, device)
     value = world * args.batch * args.steps / elapsed
 
     # per-phase breakdown (TorchTimer semantics: a sync per stamp), outside the timed region
@@ -342,51 +453,123 @@ def main():
             torch.cuda.synchronize()
             prof_inf, ops.CONV_PROFILE = ops.CONV_PROFILE, None
             ops.CONV_PROFILE_KEYS = None
-        ti_t = torch.tensor([ti], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(ti_t, op=dist.ReduceOp.MAX)
-        ti = float(ti_t.item())
+        ti = max_over_ranks(ti, device)
         infer = {"value": world * args.batch * args.steps / ti, "unit": "patches/s", "ms_per_step": ti / args.steps * 1e3}
 
-    if rank == 0:
-        # ---- roofline of the dominant conv kernel of the timed train region (and of the inference region) ----
-        roofline = roofline_of(prof, args.precision, prof_w)
-        if infer is not None and prof_inf:
-            infer["roofline"] = roofline_of(prof_inf, args.precision)
-        # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
-        conv_summary = conv_summary_of(prof_w, 1) if prof_w else conv_summary_of(prof, args.steps)
+    if rank != 0:
+        return None
+    # ---- roofline of the dominant conv kernel of the timed train region (and of the inference region) ----
+    roofline = roofline_of(prof, args.precision, prof_w)
+    if infer is not None and prof_inf:
+        infer["roofline"] = roofline_of(prof_inf, args.precision)
+    # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
+    conv_summary = conv_summary_of(prof_w, 1) if prof_w else conv_summary_of(prof, args.steps)
+    wire = 2 if args.bucket_dtype == "bf16" else 4
+    n_params = sum(p.numel() for p in model.parameters())
+    out = {
+        "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(args.precision), "data": "synthetic",
+        "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet({cin},{cout},"
+                               f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
+                   "global_batch": world * args.batch, "params": n_params,
+                   "parallelism": f"patch-parallel dp{world}" if world > 1 else "single GPU",
+                   "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95)"},
+        "infer": infer, "phases_ms": phases, "conv_kernels": conv_summary, "roofline": roofline,
+        "rccl": dict(rccl_info(world), gradient_bytes_per_step=(n_params * wire if (world > 1 or force_ddp) else 0),
+                     bucket_dtype=args.bucket_dtype),
+        "final_loss": float(loss_dict["loss"].detach()),
+        "dice": {"gpu_soft_dice_loss_step0": gpu_dice0, "gpu_hard_dice_step0": hard0},
+    }
 
-        out = {
-            "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else f"{args.precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet({cin},{cout},"
-                                   f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
-                       "global_batch": world * args.batch, "params": sum(p.numel() for p in model.parameters()),
-                       "parallelism": f"patch-parallel dp{world}" if world > 1 else "single GPU",
-                       "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95)"},
-            "infer": infer, "phases_ms": phases, "conv_kernels": conv_summary, "roofline": roofline,
-            "final_loss": float(loss_dict["loss"].detach()),
-            "dice": {"gpu_soft_dice_loss_step0": gpu_dice0, "gpu_hard_dice_step0": hard0},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(cfg, args.batch)
-            p_cpu = cb.pop("_probs")
-            # Dice vs CPU ref on identical synthetic volume and identical seed-0 weights
-            am_cpu = p_cpu.argmax(dim=1)
-            from oracle import torch_ref as R
-            hard_cpu = [r[4] for r in R.hard_dice_table(am_cpu[0], lab[0].cpu(), cout)]
-            out["dice"].update({
-                "cpu_soft_dice_loss_step0": cb["dice_loss"], "cpu_hard_dice_step0": hard_cpu,
-                "max_abs_prob_diff_vs_cpu": float((p0.cpu() - p_cpu).abs().max()),
-                "argmax_mismatch_voxels": int((am.cpu().long() != am_cpu).sum()),
-            })
-            out["cpu_baseline"] = cb
-        print(json.dumps(out))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    def cpu_leg(out):
+        cb = cpu_baseline(cfg, args.batch)
+        p_cpu = cb.pop("_probs")
+        # Dice vs CPU ref on identical synthetic volume and identical seed-0 weights
+        am_cpu = p_cpu.argmax(dim=1)
+        from oracle import torch_ref as R
+        hard_cpu = [r[4] for r in R.hard_dice_table(am_cpu[0], lab_cpu[0], cout)]
+        out["dice"].update({
+            "cpu_soft_dice_loss_step0": cb["dice_loss"], "cpu_hard_dice_step0": hard_cpu,
+            "max_abs_prob_diff_vs_cpu": float((p0_cpu - p_cpu).abs().max()),
+            "argmax_mismatch_voxels": int((am_cpu_gpu != am_cpu).sum()),
+        })
+        out["cpu_baseline"] = cb
+    out["_cpu_leg"] = cpu_leg
+    return out
+
+
+# cfg4: cfg2 network with 2 outputs, volume 4x256^3, patch 160, overlap 20, 'average'
+CFG4 = {"volume": (4, 256, 256, 256), "patch": 160, "overlap": 20, "n_out": 2}
+
+
+def run_window(args, rank, world, device):
+    """One "step" = sliding-window inference of one resident 4x256^3 volume (research/msseg2/msseg2.py:139-146,
+    prediction.py:124-152): 8 tiles of 4x160^3 through the model, averaged.  With N ranks the tiles of a volume are
+    sharded (tile i -> rank i % N, one all_gather, every rank aggregates): total work is fixed -> "strong"."""
+    from segmentation_pipeline_amd import distributed as D
+    from segmentation_pipeline_amd import ops
+    from segmentation_pipeline_amd.prediction import PatchPredict, grid_locations
+
+    cin, _, filters, depth, _ = WORKLOADS["cfg2"]
+    cfg = (cin, CFG4["n_out"], filters, depth, (CFG4["patch"],) * 3)
+    model = build_model(cfg).to(device).eval()
+    vol = torch.randn(CFG4["volume"], generator=torch.Generator().manual_seed(1234)).to(device)   # the SAME volume on every rank
+    n_tiles = len(grid_locations(vol.shape[1:], (CFG4["patch"],) * 3, (CFG4["overlap"],) * 3))
+    pp = PatchPredict(patch_batch_size=1, patch_size=CFG4["patch"], patch_overlap=CFG4["overlap"])
+    with D.unit_sharding():
+        for i in range(max(1, args.warmup)):
+            if i == max(1, args.warmup) - 1 and rank == 0:
+                ops.CONV_PROFILE = []
+            out_vol = pp.predict_volume(model, vol)
+        if ops.CONV_PROFILE is not None:
+            torch.cuda.synchronize()
+            ops.CONV_PROFILE_KEYS, ops.CONV_PROFILE_EVERY = dominant_keys(ops.CONV_PROFILE, args.precision)
+            ops.CONV_PROFILE = None
+        gc.collect()
+        gc.freeze()
+        ops.CONV_PROFILE = [] if rank == 0 else None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_vol = pp.predict_volume(model, vol)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        ops.CONV_PROFILE_KEYS = None
+        elapsed = max_over_ranks(elapsed, device)
+        # phase table (a device synchronisation per stamp), outside the timed region
+        timings = {}
+        pt = PatchPredict(patch_batch_size=1, patch_size=CFG4["patch"], patch_overlap=CFG4["overlap"], timings=timings)
+        for _ in range(2):
+            pt.predict_volume(model, vol)
+    s = out_vol.sum(0)
+    sum_err = float((s - 1).abs().max())
+    digest = float(out_vol.double().sum())     # identical on every rank count (aggregation is in grid order)
+    if rank != 0:
+        return None
+    phases = {k: v / 2 * 1e3 for k, v in timings.items()}
+    serial = sum(v for k, v in phases.items() if k in ("exchange", "accumulate", "finalize"))
+    out = {
+        "metric": METRIC, "value": n_tiles * args.steps / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": dtype_label(args.precision), "data": "synthetic",
+        "config": {"workload": f"cfg4: sliding-window inference of one {'x'.join(map(str, CFG4['volume']))} volume per step, patch "
+                               f"{CFG4['patch']}, overlap {CFG4['overlap']}, average; {n_tiles} tiles of {cin}x{CFG4['patch']}^3 through "
+                               f"ModularUNet({cin},{CFG4['n_out']},{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2)",
+                   "tiles_per_volume": n_tiles, "parallelism": f"tiles sharded over {world} ranks, one all_gather" if world > 1 else "single GPU"},
+        "phases_ms": phases, "serial_ms_per_volume": serial,
+        "roofline": roofline_of(prof, args.precision) if prof else None,
+        "rccl": rccl_info(world),
+        "checks": {"max_abs_sum_p_minus_1": sum_err, "sum_of_probabilities": digest},
+    }
+
+    def cpu_leg(out):
+        cb = cpu_baseline(cfg, 1, train=False)
+        cb.pop("_probs")
+        out["cpu_baseline"] = cb
+    out["_cpu_leg"] = cpu_leg
+    return out
 
 
 if __name__ == "__main__":

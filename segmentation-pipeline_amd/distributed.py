@@ -85,10 +85,17 @@ class PatchParallel(nn.Module):
 
     def __init__(self, module: nn.Module, bucket_bytes: int = 25 << 20, process_group=None,
                  broadcast_parameters: bool = True, force_collectives: bool = False, sync_batch_norm: bool = False,
-                 tail_bucket_bytes: int = 4 << 20):
+                 tail_bucket_bytes: int = 4 << 20, bucket_dtype: torch.dtype = torch.float32):
         super().__init__()
+        if bucket_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"bucket_dtype must be float32, bfloat16 or float16, not {bucket_dtype}")
         self.module = module
         self.tail_bucket_bytes = tail_bucket_bytes
+        # bucket_dtype: the WIRE type of the gradient all-reduce.  float32 (default): the fp32 buckets themselves are
+        # reduced.  bfloat16 / float16 (the 16-bit precision modes, SURVEY section 5: 36.2 MB instead of 72.3 MB per cfg2
+        # step): each bucket is cast into a 16-bit wire buffer by the packing copy, reduced on the wire type and
+        # cast back into the fp32 bucket the optimizer reads -- master gradients and weights stay fp32.
+        self.bucket_dtype = bucket_dtype
         self.group = process_group
         self.sync_batch_norm = sync_batch_norm
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -105,8 +112,12 @@ class PatchParallel(nn.Module):
         self._backend_has_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         if self.active:
             if broadcast_parameters:
-                for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t.data, src=0, group=self.group)
+                # into `detach()` (shares storage AND the version counter with the parameter), not `.data`: the
+                # version-keyed caches (packed weights, derived filters, captured graphs) of a model that ran a
+                # forward before being wrapped must see that ranks != 0 now hold other values
+                with torch.no_grad():
+                    for t in list(module.parameters()) + list(module.buffers()):
+                        dist.broadcast(t.detach(), src=0, group=self.group)
             for idx, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
 
@@ -114,6 +125,7 @@ class PatchParallel(nn.Module):
     def _build_buckets(self, bucket_bytes):
         """Reverse parameter order ~ the order in which backward produces gradients."""
         self.buckets = []       # flat fp32 tensors
+        self.wire = []          # per bucket: the 16-bit wire buffer (bucket_dtype != float32), else None
         self.bucket_of = {}     # param index -> (bucket, offset)
         self.members = []       # per bucket: list of param indices
         cur, cur_bytes = [], 0
@@ -151,6 +163,8 @@ class PatchParallel(nn.Module):
                 self.bucket_of[i] = (b, off)
                 off += self.params[i].numel()
             self.buckets.append(flat)
+            wire_dtype = getattr(self, "bucket_dtype", torch.float32)
+            self.wire.append(None if wire_dtype == torch.float32 else torch.zeros(total, dtype=wire_dtype, device=dev))
             self.members.append(idxs)
 
     def _grad_view(self, idx):
@@ -174,15 +188,25 @@ class PatchParallel(nn.Module):
         """Pack the gradients of bucket b with ONE multi-tensor copy and start its all-reduce."""
         idxs = [i for i in self.members[b] if self.params[i].grad is not None]
         views = [self._grad_view(i) for i in idxs]
-        src = [(v, self.params[i].grad) for v, i in zip(views, idxs) if self.params[i].grad.data_ptr() != v.data_ptr()]
-        if src:
-            torch._foreach_copy_([v for v, _ in src], [g for _, g in src])
+        wire = self.wire[b]
+        if wire is not None:
+            # pack + cast in the same multi-tensor copy: gradient -> its slice of the 16-bit wire buffer
+            wviews = []
+            for i in idxs:
+                _, off = self.bucket_of[i]
+                wviews.append(wire[off:off + self.params[i].numel()].view_as(self.params[i]))
+            if idxs:
+                torch._foreach_copy_(wviews, [self.params[i].grad for i in idxs])
+        else:
+            src = [(v, self.params[i].grad) for v, i in zip(views, idxs) if self.params[i].grad.data_ptr() != v.data_ptr()]
+            if src:
+                torch._foreach_copy_([v for v, _ in src], [g for _, g in src])
         for v, i in zip(views, idxs):
-            self.params[i].grad = v  # the optimizer reads the reduced bucket
+            self.params[i].grad = v  # the optimizer reads the reduced (fp32) bucket
         # slices of parameters without a gradient are never written: they stay at their initial zero
         avg = self._backend_has_avg
-        work = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group,
-                               async_op=True)
+        work = dist.all_reduce(self.buckets[b] if wire is None else wire, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                               group=self.group, async_op=True)
         self._pending.append((b, work))
 
     # -- step protocol ---------------------------------------------------------
@@ -210,6 +234,8 @@ class PatchParallel(nn.Module):
                 self._launch(b)  # some members never produced a gradient this step
         for b, work in self._pending:
             work.wait()
+            if self.wire[b] is not None:
+                self.buckets[b].copy_(self.wire[b])      # 16-bit wire -> the fp32 master gradients (.grad views)
             if not self._backend_has_avg:
                 self.buckets[b].div_(self.world)
         self._pending.clear()
@@ -231,9 +257,10 @@ class PatchParallel(nn.Module):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat /= self.world
         off = 0
-        for b in bufs:
-            b.data.copy_(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
+        with torch.no_grad():
+            for b in bufs:
+                b.detach().copy_(flat[off:off + b.numel()].view_as(b))   # (bumps the buffer's version: see __init__)
+                off += b.numel()
 
     def state_dict(self, *args, **kwargs):
         return self.module.state_dict(*args, **kwargs)

@@ -146,7 +146,8 @@ def _run_ensemble(module, x, members, strategy):
                 back = torch.empty((pred.shape[0], pred.shape[1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
                 red = _Reducer('mean', back.shape, x.device)
                 red.acc = back                     # one accumulate with first=1 IS the inverse transform
-                red.add(pred, perm, fm)
+                # (a 'majority' member returns the reference's int64 one-hot mask: ms-inference.py:115-125 nests them)
+                red.add(pred if pred.dtype == torch.float32 else pred.float(), perm, fm)
                 return back
             return _torch_back(model(_torch_member(x, perm, fm)), perm, fm).contiguous()
         if not sharded:

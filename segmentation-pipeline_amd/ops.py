@@ -305,7 +305,11 @@ def _packed_weight(weight, d, which):
             weight._m355_packed = cache
         except (AttributeError, RuntimeError):
             return weight, 0
-    key = (which, d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.compute)
+    # The packed layout depends on the channel counts, the arithmetic and the kernel family only -- not on the spatial
+    # extent or the batch: ONE buffer per (direction, family) serves every input shape (variable-size validation
+    # volumes used to add a full copy of every weight per distinct shape, all re-packed after each optimizer.step).
+    small = 1 if (which == 0 and d.Cout <= 4 and conv_plan(d, 0)[0] == 2) else 0   # Cout <= 4 forward: its own layout
+    key = (which, d.Cin, d.Cout, d.compute, small)
     ent = cache[2].get(key)
     if ent is None:
         nbytes = L.m355_conv3d_packed_bytes(C.byref(d), which)

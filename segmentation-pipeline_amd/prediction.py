@@ -90,7 +90,11 @@ class GraphedForward:
         self._graphs = {}
 
     def _key(self, x):
-        version = sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.model.buffers())
+        # storage AND version of every parameter / buffer: a replaced Parameter, `module.to()` or an optimizer step
+        # all invalidate the capture (a sum of versions alone would replay a graph that reads freed storage).
+        # In-place writes through `.data` bump no version and are not supported on a captured model.
+        version = hash(tuple((t.data_ptr(), t._version) for t in
+                             itertools.chain(self.model.parameters(), self.model.buffers())))
         return (tuple(x.shape), x.dtype, x.device, ops.get_precision(), self.model.training, version)
 
     def __call__(self, x):
@@ -200,9 +204,9 @@ class PatchPredict:
                                                          self.pad_value)
                     t = self._stamp("tile_gather", t, dev)
                     # (the graph's output buffer is reused by the next replay: torch.cat below copies, but only after
-                    # the loop, so a graphed batch is cloned here; the ragged last batch runs eagerly)
-                    full = run is not model and len(idx) == self.patch_batch_size
-                    outs.append(run(tiles_in).clone() if full else model(tiles_in))
+                    # the loop, so a graphed batch is cloned here; the ragged last batch is a second capture, keyed by
+                    # its shape -- it recurs once per volume)
+                    outs.append(run(tiles_in).clone() if run is not model else model(tiles_in))
                     t = self._stamp("model", t, dev)
         local = torch.cat(outs, dim=0) if outs else None
         meta = torch.tensor([local.shape[1] if local is not None else 0], device=dev)

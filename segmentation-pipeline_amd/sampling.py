@@ -102,10 +102,16 @@ class VolumeFeeder:
 
     The reference's patch loader (`tio.Queue`, data_loader_factory.py:36-54) cuts patches on the CPU and ships
     every patch batch over PCIe.  Here a SUBJECT's volumes cross the link once: while the samplers above cut
-    patches from the resident volume(s) on the device, the next subject is staged into page-locked host memory and
-    copied to the device on a side HIP stream (`non_blocking`), so the H2D transfer (a 4 x 256^3 fp32 volume is
-    268 MB = ~4.5 ms at PCIe Gen5 x16) overlaps `patches_per_volume` training steps.  Two device slots and two
-    pinned staging buffers per tensor name are reused for the whole run (no allocation in the loop).
+    patches from the resident volume(s) on the device, a WORKER THREAD pulls the next subject from the iterable
+    (whatever loading / decoding that does), stages it into page-locked host memory and enqueues the copy to the
+    device on a side HIP stream, so neither the pageable -> pinned memcpy (a 4 x 256^3 fp32 volume is 268 MB: ~30 ms of
+    host memcpy) nor the H2D transfer (~4.5 ms at PCIe Gen5 x16) ever runs on the thread that launches the training
+    kernels.  Two device slots and two pinned staging buffers per tensor name are reused for the whole run.
+
+    Ordering (per slot): the worker overwrites a slot's pinned buffer only after the HOST has seen the previous
+    upload out of that buffer complete (`Event.synchronize`), and the upload into the slot's device tensors waits on
+    the stream for the event the consumer recorded when it was done reading them; the consumer's stream waits for
+    the upload event before the volumes are used.  The worker is at most one subject ahead.
 
         feeder = VolumeFeeder(subjects, device)             # subjects: iterable of {name: CPU tensor}
         for vols in feeder:                                  # vols: {name: device tensor}, valid until the next step
@@ -113,6 +119,8 @@ class VolumeFeeder:
                 (x, y), loc = sampler(vols["X"], vols["prob"], n, extra=[vols["y"]])
                 ...
     """
+
+    _STOP = object()
 
     def __init__(self, subjects: Iterable[dict], device, pin_memory: bool = True):
         self.subjects = subjects
@@ -123,14 +131,26 @@ class VolumeFeeder:
         self._slots = [{}, {}]       # device tensors per slot
         self._stage = [{}, {}]       # pinned host tensors per slot
         self._ready = [None, None]   # event: the slot's upload has finished
-        self._free = [None, None]    # event: the consumer is done with the slot
+        self.host_wait_s = 0.0       # time the CONSUMER thread spent waiting for the worker (0 when feeding keeps up)
 
-    def _upload(self, slot: int, subject: dict):
-        """stage `subject` into slot `slot` (asynchronously on the copy stream)"""
+    # -- event / stream primitives (overridden by the tests' doubles) ------------------------------------------
+    def _new_event(self):
+        return torch.cuda.Event() if self.cuda else None
+
+    def _stage_copy(self, dst, src):
+        dst.copy_(src)                                      # pageable -> pinned (host memcpy, worker thread)
+
+    def _upload(self, slot: int, subject: dict, free_event):
+        """stage `subject` into slot `slot` (worker thread; asynchronously on the copy stream)"""
         dev, st = self._slots[slot], self._stage[slot]
         if self.cuda:
-            if self._free[slot] is not None:
-                self.copy_stream.wait_event(self._free[slot])   # the trainer has finished reading this slot
+            torch.cuda.set_device(self.device)
+            if self._ready[slot] is not None:
+                # the previous H2D copy OUT of this slot's pinned buffers must have finished before the host
+                # overwrites them (a stream-side wait is not enough: the memcpy below runs now, on the host)
+                self._ready[slot].synchronize()
+            if free_event is not None:
+                self.copy_stream.wait_event(free_event)     # the trainer has finished reading this slot's tensors
             ctx = torch.cuda.stream(self.copy_stream)
         else:
             import contextlib
@@ -140,12 +160,12 @@ class VolumeFeeder:
                 if not torch.is_tensor(t):
                     dev[name] = t
                     continue
-                if name not in dev or dev[name].shape != t.shape or dev[name].dtype != t.dtype:
+                if name not in dev or not torch.is_tensor(dev[name]) or dev[name].shape != t.shape or dev[name].dtype != t.dtype:
                     dev[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
                     if self.pin:
                         st[name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                 if self.pin:
-                    st[name].copy_(t)                       # pageable -> pinned (host memcpy)
+                    self._stage_copy(st[name], t)
                     dev[name].copy_(st[name], non_blocking=True)
                 else:
                     dev[name].copy_(t)
@@ -153,33 +173,55 @@ class VolumeFeeder:
                 if name not in subject:
                     del dev[name]
             if self.cuda:
-                ev = torch.cuda.Event()
+                ev = self._new_event()
                 ev.record(self.copy_stream)
                 self._ready[slot] = ev
 
-    def __iter__(self) -> Iterator[dict]:
-        it = iter(self.subjects)
+    def _worker(self, ready_q, free_q, stop):
         try:
-            nxt = next(it)
-        except StopIteration:
-            return
-        slot = 0
-        self._upload(slot, nxt)
-        while True:
-            try:
-                nxt = next(it)
-                have_next = True
-            except StopIteration:
-                have_next = False
-            if have_next:
-                self._upload(slot ^ 1, nxt)                 # next subject in flight while this one is consumed
-            if self.cuda:
-                torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
-            yield dict(self._slots[slot])
-            if self.cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self._free[slot] = ev
-            if not have_next:
-                return
-            slot ^= 1
+            for k, subject in enumerate(self.subjects):
+                slot = k & 1
+                free_event = None
+                if k >= 2:                                   # slot reuse: wait (host) until the consumer left it
+                    free_event = free_q[slot].get()
+                    if free_event is self._STOP:
+                        return
+                if stop.is_set():
+                    return
+                self._upload(slot, subject, free_event)
+                ready_q.put((slot, self._ready[slot], None))
+            ready_q.put((None, None, None))
+        except BaseException as exc:   # noqa: BLE001 -- re-raised on the consumer thread
+            ready_q.put((None, None, exc))
+
+    def __iter__(self) -> Iterator[dict]:
+        import queue
+        import threading
+        import time
+        ready_q = queue.Queue()
+        free_q = [queue.Queue(), queue.Queue()]
+        stop = threading.Event()
+        worker = threading.Thread(target=self._worker, args=(ready_q, free_q, stop), daemon=True, name="m355-volume-feeder")
+        worker.start()
+        try:
+            while True:
+                t0 = time.perf_counter()
+                slot, ready, exc = ready_q.get()
+                self.host_wait_s += time.perf_counter() - t0
+                if exc is not None:
+                    raise exc
+                if slot is None:
+                    return
+                if self.cuda:
+                    torch.cuda.current_stream(self.device).wait_event(ready)
+                yield dict(self._slots[slot])
+                ev = None
+                if self.cuda:
+                    ev = self._new_event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                free_q[slot].put(ev)
+        finally:
+            stop.set()
+            for q in free_q:
+                q.put(self._STOP)
+            worker.join(timeout=60)

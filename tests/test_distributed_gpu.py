@@ -150,3 +150,118 @@ def test_sync_halves_bit_identical_at_world_one():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ the real RCCL path: two ranks on two devices
+def _nccl_worker(rank, world, port, ret):
+    """one rank of the 2-GPU test; everything it returns is a CPU tensor"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from segmentation_pipeline_amd import distributed as D, ops
+        from segmentation_pipeline_amd.models import EnsembleFlips
+        from segmentation_pipeline_amd.prediction import PatchPredict
+        ops.set_precision("fp32")
+        out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+        # (a) bucketed, backward-overlapped gradient all-reduce (ReduceOp.AVG on RCCL) == gradient of the batch of two
+        model = _build("unet_gn").to(dev)
+        ddp = D.PatchParallel(model, bucket_bytes=16 << 10)
+        x, w = _inputs()
+        per = SHAPE[0] // world
+        xs, ws = x[rank * per:(rank + 1) * per].to(dev), w[rank * per:(rank + 1) * per].to(dev)
+        out["ddp"] = _step(model, xs, ws, SHAPE[0], ddp)
+        out["n_buckets"] = len(ddp.buckets)
+        # the same with a bf16 wire
+        model2 = _build("unet_gn").to(dev)
+        ddp2 = D.PatchParallel(model2, bucket_bytes=16 << 10, bucket_dtype=torch.bfloat16)
+        out["ddp_bf16"] = _step(model2, xs, ws, SHAPE[0], ddp2)[2]
+        # (b) sharded sliding window and sharded ensemble == one rank, bit for bit (all_gather_into_tensor on device buffers)
+        model.eval()
+        vol = torch.randn((3, 24, 24, 40), generator=torch.Generator().manual_seed(5)).to(dev)
+        pp = PatchPredict(patch_batch_size=2, patch_size=16, patch_overlap=4)
+        ens = EnsembleFlips(model, "mean")
+        maj = EnsembleFlips(model, "majority")
+        xe = x[:1].to(dev)
+        with torch.no_grad():
+            single = (pp.predict_volume(model, vol), ens(xe), maj(xe))
+            with D.unit_sharding():
+                sharded = (pp.predict_volume(model, vol), ens(xe), maj(xe))
+        out["window"] = (single[0].cpu(), sharded[0].cpu())
+        out["ens"] = (single[1].cpu(), sharded[1].cpu())
+        out["maj"] = (single[2].cpu(), sharded[2].cpu())
+        torch.cuda.synchronize()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the real nccl == RCCL backend, one rank per device)")
+def test_rccl_two_ranks_two_devices():
+    """The multi-GPU paths on the backend they ship on: RCCL refuses two ranks on one device, so this
+    runs wherever two devices are visible (the driver's multi-GPU node) and is skipped on the one-GPU box."""
+    from segmentation_pipeline_amd import ops
+    ops.set_precision("fp32")
+    model = _build("unet_gn")
+    x, w = _inputs()
+    ref_out, ref_loss, ref_grads, _ = _step(model, x.cuda(), w.cuda(), SHAPE[0])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    per = SHAPE[0] // 2
+    for rank in range(2):
+        r = ret[rank]
+        assert r["backend"] == "nccl" and r["world"] == 2 and r["n_buckets"] > 1
+        out, loss, grads, _ = r["ddp"]
+        _close(out, ref_out[rank * per:(rank + 1) * per], 2e-5, f"rank {rank} output")
+        for k in ref_grads:
+            _close(grads[k], ref_grads[k], 2e-4, f"rank {rank} grad {k}")
+            _close(r["ddp_bf16"][k], ref_grads[k], 2 ** -7, f"rank {rank} grad {k} (bf16 wire)")
+            assert r["ddp_bf16"][k].dtype == torch.float32
+        for key in ("window", "ens", "maj"):
+            single, sharded = r[key]
+            assert torch.equal(single, sharded), f"rank {rank}: sharded {key} differs from the one-rank result"
+    for k in ref_grads:   # both ranks hold the same reduced gradients
+        assert torch.equal(ret[0]["ddp"][2][k], ret[1]["ddp"][2][k])
+
+
+def _nested_majority_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from functools import partial
+        from torch import nn
+        from segmentation_pipeline_amd import distributed as D, ops
+        from segmentation_pipeline_amd.models import EnsembleFlips, EnsembleModels, ModularUNet
+        torch.cuda.set_device(0)
+        ops.set_precision("fp32")
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round3.npz"), allow_pickle=False)
+        members = []
+        for i in (0, 1):
+            m = ModularUNet(2, 3, [8, 16], 2, block_params={'normalization_class': partial(nn.GroupNorm, 8)},
+                            upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
+            m.load_state_dict({k[len(f"ens.m{i}.sd."):]: torch.from_numpy(np.asarray(z[k])) for k in z.files
+                               if k.startswith(f"ens.m{i}.sd.")})
+            members.append(m.cuda().eval())
+        ens = EnsembleModels([EnsembleFlips(m, "majority") for m in members], "majority")
+        x = torch.from_numpy(z["ens.x"]).cuda()
+        with torch.no_grad(), D.unit_sharding():
+            got = ens(x)
+        ret[rank] = (got.cpu(), torch.from_numpy(z["ens.nested_flips.majority"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_majority_of_majority_ensemble_two_ranks_one_gpu():
+    """the reference's production ensemble -- EnsembleModels of 'majority' flip ensembles, 'majority'
+    (ms-inference.py:115-125) -- with its members sharded over two ranks: the int64 one-hot masks the members return
+    go through the sharded reduce path, and the result equals the reference's mask bit for bit."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nested_majority_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for rank in range(2):
+        got, ref = ret[rank]
+        assert got.dtype == torch.int64 and torch.equal(got, ref)

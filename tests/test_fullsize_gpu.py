@@ -185,6 +185,44 @@ def test_cfg4_sliding_window_full_size():
     torch.cuda.empty_cache()
 
 
+def test_msseg2_sliding_window_at_the_reference_parameters():
+    """The reference's validation window on its msseg2 network (research/msseg2/msseg2.py:84-93,139-146: patch 96, overlap
+    96 // 8 = 12, patch_batch_size 32) with the 'edge' padding of its inference script (competition/ms-inference.py:35), on
+    a 2x192^3 volume: 27 tiles of 2x96^3 in ONE batch of the BatchNorm (eval) network.  PatchPredict == a manual tile loop
+    over the edge-padded volume through the same model (numpy.pad + the oracle's tile list; torchio itself is absent:
+    parity unpinned, self-consistency only), eagerly and replayed from a hipGraph."""
+    from segmentation_pipeline_amd.models import BlurConv3d, BlurConvTranspose3d
+    from segmentation_pipeline_amd.prediction import PatchPredict
+    torch.manual_seed(0)
+    model = ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
+                        downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
+                        upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0}).cuda().eval()
+    vol = torch.randn((2, 192, 192, 192), generator=torch.Generator().manual_seed(11))
+    border = 12 // 2
+    padded = torch.from_numpy(np.pad(vol.numpy(), ((0, 0),) + ((border, border),) * 3, mode="edge"))
+    locs = R.grid_locations(tuple(padded.shape[1:]), (96,) * 3, (12,) * 3)
+    assert len(locs) == 27
+    acc = torch.zeros((2,) + tuple(padded.shape[1:]))
+    cnt = torch.zeros((1,) + tuple(padded.shape[1:]))
+    with torch.no_grad():
+        for (i, j, k) in locs:    # one tile at a time: eval-mode BatchNorm keeps samples independent
+            tile = model(padded[None, :, i:i + 96, j:j + 96, k:k + 96].contiguous().cuda())[0].cpu()
+            acc[:, i:i + 96, j:j + 96, k:k + 96] += tile
+            cnt[:, i:i + 96, j:j + 96, k:k + 96] += 1
+    ref = (acc / cnt)[:, border:-border, border:-border, border:-border]
+    for graph in (False, True):
+        pp = PatchPredict(patch_batch_size=32, patch_size=96, patch_overlap=12, padding_mode="edge", graph=graph)
+        out = pp.predict(model, torch.device("cuda"), {"X": vol[None]})["y_pred"][0]
+        assert out.shape == (2, 192, 192, 192)
+        assert (out.sum(dim=0) - 1).abs().max().item() <= 1e-5
+        assert (out.cpu() - ref).abs().max().item() <= 1e-5, f"graph={graph}"
+        if graph:
+            assert torch.equal(out, eager), "the replayed window differs from the eager one"
+        eager = out
+    del out, eager, acc, cnt, ref
+    torch.cuda.empty_cache()
+
+
 def test_msseg2_full_size_residual_blur_bn_vs_cpu_oracle():
     """The architecture the reference trained for MSSEG-2 (research/msseg2/msseg2.py:84-93,142: 6 levels of 40/40/80/80/
     120/120 filters, residual blocks, BatchNorm, BlurConv3d / BlurConvTranspose3d, class weights [1, 100]) at its full
