@@ -147,7 +147,7 @@ def conv_summary_of(prof, steps):
             for k, v in by_tag.items()}
 
 
-def roofline_of(prof, precision, full_prof=None):
+def roofline_of(prof, precision, full_prof=None, traffic=True):
     """Roofline object of the dominant conv kernel of a timed region.  prof: ops.CONV_PROFILE entries
     (tag, flops, e0, e1, plan, bytes).  Kernels are grouped by (kernel name, tile variant); the group with
     the most accumulated time is the dominant kernel.  bound = whichever of algorithmic-bytes / 8 TB/s and
@@ -170,7 +170,8 @@ def roofline_of(prof, precision, full_prof=None):
     else:
         ach = nbytes / (ms * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", ")), "kernel": kname, "launches": n,
+    # (the committed PMC passes are of the cfg2 command: quoted only for launches of that workload)
+    out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", ")) if traffic else None, "kernel": kname, "launches": n,
                 "avg_launch_ms": ms / n, "avg_gflop_per_launch": flops / n / 1e9,
                 "avg_algorithmic_mb_per_launch": nbytes / n / 1e6,
                 "time_share_of_conv": share})
@@ -559,7 +560,7 @@ def run_window(args, rank, world, device):
                                f"ModularUNet({cin},{CFG4['n_out']},{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2)",
                    "tiles_per_volume": n_tiles, "parallelism": f"tiles sharded over {world} ranks, one all_gather" if world > 1 else "single GPU"},
         "phases_ms": phases, "serial_ms_per_volume": serial,
-        "roofline": roofline_of(prof, args.precision) if prof else None,
+        "roofline": roofline_of(prof, args.precision, traffic=False) if prof else None,
         "rccl": rccl_info(world),
         "checks": {"max_abs_sum_p_minus_1": sum_err, "sum_of_probabilities": digest},
     }

@@ -331,6 +331,62 @@ int m355_act16_channel_partials(const void* x16, int64_t x16_batch_stride, int32
 int m355_avgpool3d_2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                               int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
 
+/* ---- the c8-only TRAINING flow of the 16-bit modes (round 3) ----
+ * With autograd on, activations and activation gradients of the conv -> norm/act -> conv -> pool / conv-transpose ->
+ * concat chain exist only as c8 tensors, as they already do under no_grad; these are the backward halves.  They replace
+ * the reference's autograd under `torch.cuda.amp.autocast` (segmentation_pipeline/segmentation_trainer.py:203-227) for
+ * Block3d (models/components.py:62-73), nn.AvgPool3d and nn.ConvTranspose3d(2, 2) (models/modular_unet.py:64,72-81,92,96).
+ *
+ * grad_scale / grad_unscale: the fp16 mode carries activation gradients multiplied by a power of two (at full size the
+ * gradient of a mean over ~2e6 voxels is ~1e-7, below the fp16 normal range).  The scale is applied where a gradient
+ * first becomes c8 (m355_act16_pack_scaled; values past the fp16 range saturate) and removed in the fp32 epilogue of
+ * every PARAMETER gradient (`grad_unscale` = 1 / scale); activation gradients keep it.  bf16: 1. */
+int m355_act16_pack_scaled(const float* x, void* x16, int32_t N, int32_t C, int64_t S, int64_t x_batch_stride,
+                           int64_t x16_batch_stride, int32_t compute, float scale, void* stream);
+int m355_act16_unpack_scaled(const void* x16, float* x, int32_t N, int32_t C, int64_t S, int64_t x16_batch_stride,
+                             int64_t x_batch_stride, int32_t compute, float scale, void* stream);
+/* data gradient of the 3x3x3 conv, c8 in -> c8 out (dx16 holds desc->Cin channels); workspace:
+ * m355_conv3d_h16_workspace(desc, 1).  Same arithmetic as m355_conv3d_bwd_data_h16 followed by one rounding. */
+int m355_conv3d_bwd_data_h16_c8(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride, const float* w,
+                                void* dx16, int64_t dx16_batch_stride, void* workspace, size_t workspace_bytes,
+                                void* stream);
+/* weight gradient from c8 operands as m355_conv3d_bwd_weight_h16, with the bias gradient (may be NULL) reduced from
+ * the c8 dy16 itself and both multiplied by grad_unscale in their fp32 epilogues. */
+size_t m355_conv3d_bwd_weight_c8_workspace(const m355_conv3d_desc* d);
+int m355_conv3d_bwd_weight_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                              int64_t dy16_batch_stride, float* dw, float* dbias, float grad_unscale, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* normalisation + activation backward on c8 operands: x16 = the saved PRE-NORM tensor, the incoming gradient is
+ * dy16 (may be NULL when dpool16 is given) + un-pooled dpool16 (may be NULL; then D, H, W are ignored): an encoder
+ * block's output continues into the skip connection AND, through nn.AvgPool3d(2, 2), into the next level, and the sum
+ * of the two gradients is formed inside this pass.  dx16: c8, same shape as x16.  dgamma / dbeta (may be NULL) fp32,
+ * multiplied by grad_unscale.  Workspace: m355_norm_workspace(desc).  Expressions as m355_norm_act_bwd. */
+int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                         int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride, int32_t D,
+                         int32_t H, int32_t W, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, void* dx16, int64_t dx16_batch_stride, float* dgamma, float* dbeta,
+                         int training, float grad_unscale, int32_t compute, void* workspace, size_t workspace_bytes,
+                         void* stream);
+/* nn.AvgPool3d(2, 2) backward c8 -> c8, optionally adding the gradient of the un-pooled tensor's other consumer
+ * (dskip16, may be NULL): dx16[v] = dskip16[v] + dpool16[v / 2] / 8.  D, H, W: the UN-pooled size (even). */
+int m355_avgpool3d_2x_bwd_h16(const void* dpool16, const void* dskip16, void* dx16, int32_t N, int32_t C, int32_t D,
+                              int32_t H, int32_t W, int64_t dpool16_batch_stride, int64_t dskip16_batch_stride,
+                              int64_t dx16_batch_stride, int32_t compute, void* stream);
+/* nn.ConvTranspose3d(kernel_size=2, stride=2) backward from c8 operands on the 16-bit matrix core (operands rounded to
+ * the 16-bit type, fp32 accumulate): dx16 (desc->Cin channels, c8) from dy16 (desc->Cout channels at twice the
+ * resolution); dw fp32 [Cin][Cout][2][2][2] and dbias (may be NULL), both multiplied by grad_unscale.
+ * m355_conv_transpose3d_h16_bwd_supported(desc) == 0: unpack / m355_conv_transpose3d_bwd_* / pack instead (other
+ * geometries, Cout > 128). */
+int32_t m355_conv_transpose3d_h16_bwd_supported(const m355_conv3d_desc* d);
+size_t m355_conv_transpose3d_h16_bwd_workspace(const m355_conv3d_desc* d);
+int m355_conv_transpose3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride,
+                                       const float* w, void* dx16, int64_t dx16_batch_stride, int32_t compute,
+                                       void* stream);
+int m355_conv_transpose3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                         const void* dy16, int64_t dy16_batch_stride, float* dw, float* dbias,
+                                         float grad_unscale, int32_t compute, void* workspace, size_t workspace_bytes,
+                                         void* stream);
+
 /* --------------------------------------------------------------- pooling
  * nn.AvgPool3d(kernel_size=2, stride=2, count_include_pad=False)
  * (models/modular_unet.py:22,41,64,92).  Input D,H,W must be even.

@@ -77,6 +77,18 @@ SIGNATURES = {
     "m355_act16_partials_slots": (_i64, [_i64]),
     "m355_act16_channel_partials": (C.c_int, [_P, _i64, _i32, _i32, _i64, _i32, _P, _P]),
     "m355_avgpool3d_2x_fwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
+    "m355_act16_pack_scaled": (C.c_int, [_P, _P, _i32, _i32, _i64, _i64, _i64, _i32, _f32, _P]),
+    "m355_act16_unpack_scaled": (C.c_int, [_P, _P, _i32, _i32, _i64, _i64, _i64, _i32, _f32, _P]),
+    "m355_conv3d_bwd_data_h16_c8": (C.c_int, [_CD, _P, _i64, _P, _P, _i64, _P, _sz, _P]),
+    "m355_conv3d_bwd_weight_c8_workspace": (_sz, [_CD]),
+    "m355_conv3d_bwd_weight_c8": (C.c_int, [_CD, _P, _i64, _P, _i64, _P, _P, _f32, _P, _sz, _P]),
+    "m355_norm_act_bwd_c8": (C.c_int, [_ND, _P, _i64, _P, _i64, _P, _i64, _i32, _i32, _i32, _P, _P, _P, _P, _P, _i64, _P, _P,
+                                       C.c_int, _f32, _i32, _P, _sz, _P]),
+    "m355_avgpool3d_2x_bwd_h16": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _P]),
+    "m355_conv_transpose3d_h16_bwd_supported": (_i32, [_CD]),
+    "m355_conv_transpose3d_h16_bwd_workspace": (_sz, [_CD]),
+    "m355_conv_transpose3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _i64, _i32, _P]),
+    "m355_conv_transpose3d_bwd_weight_h16": (C.c_int, [_CD, _P, _i64, _P, _i64, _P, _P, _f32, _i32, _P, _sz, _P]),
     "m355_conv3d_plan": (C.c_int, [_CD, _i32, C.POINTER(C.c_int32)]),
     "m355_conv3d_bwd_data_workspace": (_sz, [_CD]),
     "m355_conv3d_bwd_data": (C.c_int, [_CD, _P, _P, _P, _P, _sz, _P]),

@@ -35,6 +35,7 @@ static inline int check_launch(const char* what) {
   } while (0)
 
 constexpr int WAVE = 64;
+constexpr int NORM_CHUNK = 16384;   // elements (c8: voxels of one channel block) per block in the normalisation reduction passes
 constexpr int DBIAS_CHUNK = 8192;   // voxels per partial sum of the bias gradient (launch_dbias; workspace = Cout * chunks doubles)
 
 // wave-wide sum (64 lanes), result valid in every lane

@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2c_kernel(
 // dW[o][c][27] = sum over splits of slab[split][27][o][c] (fixed order): one block per (o, 32 input
 // channels); coalesced reads along c, transposed through LDS, one contiguous 864-float write.
 __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                            int Cin, int Cout, BwwClasses k) {
+                                                            int Cin, int Cout, BwwClasses k, float scale = 1.f) {
   __shared__ float tr[32 * 27 + 32];
   const int o = blockIdx.x, c0 = blockIdx.y * 32;
   const int nsplit = k.ns[(o >= k.of * 32 ? 2 : 0) + ((int)blockIdx.y >= k.cf ? 1 : 0)];  // splits of this pair's class
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
       }
       for (; s < nsplit; ++s) v += p[(int64_t)s * split_stride];
     }
-    tr[cl * 27 + tap] = v;
+    tr[cl * 27 + tap] = v * scale;   // (scale != 1 only in the fp16 training flow: the loss scale leaves here)
   }
   __syncthreads();
   float* dst = out + ((int64_t)o * Cin + c0) * 27;
@@ -2664,12 +2664,65 @@ extern "C" int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void*
   kred.cf = (int)ceil_div(d->Cin, 32);
   for (int c = 0; c < 4; ++c) kred.ns[c] = nsplit;
   hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)kred.cf), dim3(256), 0, st, slab, dw, d->Cin,
-                     d->Cout, kred);
+                     d->Cout, kred, 1.f);
   if (dbias) {
     const size_t slab_b = (size_t)round_up((int64_t)nsplit * d->Cout * d->Cin * 27 * 4, 256);
     launch_dbias(dy, dbias, d->N, d->Cout, S, dense_or(d->y_batch_stride, (int64_t)d->Cout * S), (char*)workspace + slab_b, st);
   }
   return check_launch("conv3d_bwd_weight_h16");
+}
+
+// ---- the c8-only training flow: data gradient written as c8, weight gradient with the bias gradient reduced from
+// the c8 dy and the loss scale of the fp16 mode removed in the fp32 epilogue ----
+extern "C" int m355_conv3d_bwd_data_h16_c8(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride,
+                                           const float* w, void* dx16, int64_t dx16_batch_stride, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (int rc = validate_h16(d, "conv3d_bwd_data_h16_c8")) return rc;
+  M355_REQUIRE(dy16 && w && dx16 && workspace, M355_EINVALID_ARG, "conv3d_bwd_data_h16_c8: null pointer");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const bool packed = (d->flags & M355_CONV_W_PACKED) != 0;
+  return run_mfma_conv(nullptr, packed ? nullptr : w, true, d->Cout, d->Cin, nullptr, nullptr, (float*)dx16, d->N, d->Cout,
+                       d->Cin, d->D, d->H, d->W, 0, dense_or(dx16_batch_stride, c8_blocks(d->Cin) * S * 8), workspace,
+                       workspace_bytes, (hipStream_t)stream, d->compute, nullptr, dy16,
+                       dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8), packed ? w : nullptr, true);
+}
+
+extern "C" size_t m355_conv3d_bwd_weight_c8_workspace(const m355_conv3d_desc* d) {
+  if (!d || !bww_c8_ok(d)) return 0;
+  return (size_t)round_up((int64_t)bww_c8_nsplit(d) * d->Cout * d->Cin * 27 * 4, 256) +
+         dbias_c8_ws_bytes(d->N, d->Cout, (int64_t)d->D * d->H * d->W);
+}
+
+extern "C" int m355_conv3d_bwd_weight_c8(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                         const void* dy16, int64_t dy16_batch_stride, float* dw, float* dbias,
+                                         float grad_unscale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_h16(d, "conv3d_bwd_weight_c8")) return rc;
+  M355_REQUIRE(x16 && dy16 && dw && workspace, M355_EINVALID_ARG, "conv3d_bwd_weight_c8: null pointer");
+  M355_REQUIRE(bww_c8_ok(d), M355_EUNSUPPORTED, "conv3d_bwd_weight_c8: volume too large for the c8 kernel (>= 2^25 voxels)");
+  M355_REQUIRE(workspace_bytes >= m355_conv3d_bwd_weight_c8_workspace(d), M355_EWORKSPACE,
+               "conv3d_bwd_weight_c8: workspace too small (%zu < %zu)", workspace_bytes, m355_conv3d_bwd_weight_c8_workspace(d));
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t xbs = dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8);
+  const int64_t ybs = dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "conv3d_bwd_weight_c8: c8 tensor not 16B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bww_c8_nsplit(d);
+  float* slab = (float*)workspace;
+  if (int rc = launch_bww_c8(d->compute, x16, dy16, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, nsplit, xbs, ybs, st))
+    return rc;
+  BwwClasses kred{};
+  kred.of = (int)ceil_div(d->Cout, 32);
+  kred.cf = (int)ceil_div(d->Cin, 32);
+  for (int c = 0; c < 4; ++c) kred.ns[c] = nsplit;
+  hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)kred.cf), dim3(256), 0, st, slab, dw, d->Cin,
+                     d->Cout, kred, grad_unscale);
+  if (dbias) {
+    const size_t slab_b = (size_t)round_up((int64_t)nsplit * d->Cout * d->Cin * 27 * 4, 256);
+    if (int rc = launch_dbias_c8(dy16, ybs, dbias, d->N, d->Cout, S, d->compute, grad_unscale, (char*)workspace + slab_b, st))
+      return rc;
+  }
+  return check_launch("conv3d_bwd_weight_c8");
 }
 
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
@@ -2835,7 +2888,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
       M355_BWW_LAUNCH(8)
     if (gen2) {
       hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)p.ctiles), dim3(256), 0, st, slab, dw,
-                         d->Cin, d->Cout, kred);
+                         d->Cin, d->Cout, kred, 1.f);
     } else {
       const int64_t total = (int64_t)d->Cout * d->Cin * 27;
       const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);

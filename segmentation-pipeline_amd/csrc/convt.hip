@@ -647,6 +647,235 @@ __global__ void convt_dx_reduce_kernel(const float* __restrict__ slab, float* __
   }
 }
 
+// =============================== k2s2 backward on c8 operands (16-bit training flow) ===============================
+// The activation gradient of the decoder travels as c8 only (train16.hip): dy16 is the c8 gradient of the up-sampled
+// slot of a concat buffer (written by the data gradient of the decoder block's first convolution), x16 the c8 input the
+// forward consumed.  Both kernels below are HBM-bound streams with the GEMM on v_mfma_f32_32x32x16_{bf16,f16}.
+//
+// ---- data gradient  dX[c, v] = sum_{t, o} W[c, o, t] * dY[o, 2v + t]:  M = Cin, K = 8 * Cout, N = voxels.
+// A k-step of 16 is (t, two channel blocks): the c8 item of output voxel 2v + t in block ob IS the B fragment of lane
+// (voxel v, k-half ob & 1) -- global -> register -> MFMA, dY is read exactly once per m-tile group.  The weights
+// (rounded to the 16-bit type) are staged once per workgroup in A-fragment order.  The rows of an m-tile are ordered
+// so that a lane ends up with whole channel blocks: row m = 8i + 4h + j holds channel 8 * (2 * (i >> 1) + h) +
+// 4 * (i & 1) + j of the tile, i.e. accumulators 0..7 / 8..15 of lane half h are the channel blocks h / 2 + h -- two
+// 16-byte stores per lane, 512 contiguous bytes per half-wave.
+template <typename HT, int MTW>
+__global__ __launch_bounds__(256) void convt_k2s2_bwd_data_h16_kernel(
+    const HT* __restrict__ dy16, const float* __restrict__ w, HT* __restrict__ dx16, int Cin, int Cout, int D, int H, int W,
+    int64_t ybs16, int64_t xbs16, int mt_per_wg) {
+  using hx8 = typename H16<HT>::x8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  hx8* afrag = reinterpret_cast<hx8*>(lds_raw);  // [m-tile of this workgroup][k-step][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int CBout = (Cout + 7) / 8, CBin = (Cin + 7) / 8;
+  const int npair = (CBout + 1) / 2, nks = 8 * npair;        // k-step s = pair * 8 + t
+  const int mtiles = (Cin + 31) / 32;
+  const int mt0 = blockIdx.y * mt_per_wg, nmt = min(mtiles, mt0 + mt_per_wg) - mt0;
+  for (int e = tid; e < nmt * nks * 64; e += 256) {
+    const int L = e & 63, s = (e >> 6) % nks, mt = mt0 + (e >> 6) / nks;
+    const int m = L & 31, i = m >> 3, hh = (m >> 2) & 1, j4 = m & 3;
+    const int c = mt * 32 + 8 * (2 * (i >> 1) + hh) + 4 * (i & 1) + j4;
+    const int t = s & 7, ob = 2 * (s >> 3) + (L >> 5);
+    hx8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = ob * 8 + j;
+      v[j] = (c < Cin && o < Cout) ? (HT)w[((int64_t)c * Cout + o) * 8 + t] : (HT)0.f;
+    }
+    afrag[e] = v;
+  }
+  __syncthreads();
+  const int n = blockIdx.z;
+  const hx8* yin = reinterpret_cast<const hx8*>(dy16 + (int64_t)n * ybs16);
+  hx8* xo = reinterpret_cast<hx8*>(dx16 + (int64_t)n * xbs16);
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t OS = (int64_t)S * 8;
+  const hx8 zero = {};
+  for (int vt = blockIdx.x; (int64_t)vt * 128 < S; vt += gridDim.x) {
+    const int v = vt * 128 + wave * 32 + l32;
+    const bool vok = v < S;
+    const int vc = min(v, S - 1);
+    const int ix = vc % W, iy = (vc / W) % H, iz = vc / (W * H);
+    const int64_t obase = ((int64_t)(2 * iz) * OH + 2 * iy) * OW + 2 * ix;
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int q = 0; q < MTW; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    hx8 bq[2][8];
+    auto fetch = [&](int pair, hx8 (&dst)[8]) {
+      const int ob = 2 * pair + half;
+      const bool ok = vok && ob < CBout;
+      const hx8* src = yin + (int64_t)(ok ? ob : 0) * OS + obase;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        dst[t] = ok ? src[((int64_t)(t >> 2) * OH + ((t >> 1) & 1)) * OW + (t & 1)] : zero;
+    };
+    fetch(0, bq[0]);
+    for (int pair = 0; pair < npair; ++pair) {
+      if (pair + 1 < npair) fetch(pair + 1, bq[(pair + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const hx8 b = bq[pair & 1][t];
+#pragma unroll
+        for (int q = 0; q < MTW; ++q)
+          if (q < nmt) acc[q] = H16<HT>::mfma(afrag[((int64_t)q * nks + pair * 8 + t) * 64 + lane], b, acc[q]);
+      }
+    }
+    if (vok) {
+#pragma unroll
+      for (int q = 0; q < MTW; ++q) {
+        if (q >= nmt) break;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int cb = (mt0 + q) * 4 + 2 * u + half;
+          if (cb < CBin) {
+            hx8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (HT)(cb * 8 + j < Cin ? acc[q][u * 8 + j] : 0.f);
+            xo[(int64_t)cb * S + v] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- weight gradient  dW[c, o, t] = sum_v X[c, v] * dY[o, 2v + t]:  M = Cin, N = Cout (per t), K = voxels.
+// Both operands need k = 16 x-adjacent voxels of ONE channel per lane while c8 keeps the 8 channels of a voxel
+// together: as in conv3_bww_c8_kernel the tiles sit in LDS voxel-major (64-byte rows of 32 channels) and the fragments
+// come out of `ds_read_b64_tr_b16`.  A workgroup = (32-channel o-tile, CT 32-channel c-tiles, voxel split); a tile is
+// 2 x 32 input voxels (x rows) and their 2 x 4 x 64 output voxels; wave w owns t = 2w, 2w + 1 (z-parity a = w >> 1,
+// y-parity b = w & 1, both x-parities).  dY is read once per c-tile group, X once per o-tile.
+template <typename HT>
+__device__ __forceinline__ typename H16<HT>::x8 tr_frag_rs(const unsigned char* p, int rowbytes4) {
+  typedef short s16x4_ __attribute__((ext_vector_type(4)));
+  typedef short s16x8_ __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4_ lds_s16x4_;
+  const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_*)(p));
+  const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_*)(p + rowbytes4));
+  const s16x8_ v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename H16<HT>::x8, v);
+}
+
+template <typename HT, int CT>
+__global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
+    const HT* __restrict__ x16, const HT* __restrict__ dy16, float* __restrict__ slab, int N, int Cin, int Cout, int D, int H,
+    int W, int64_t xbs16, int64_t ybs16, int nsplit, int cgroups) {
+  constexpr int TY = 2, TX = 32, NV = TY * TX;                 // 64 input voxels per tile (one z)
+  constexpr int XROW = CT * 64;                                // bytes per voxel row of the x tile
+  constexpr int XI = NV * CT * 4, DI = (2 * 2 * TY * 2 * TX) * 4;   // 16-byte items: x tile, dy tile (512 voxels)
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) uint4 xs[XI];
+  __shared__ __attribute__((aligned(16))) uint4 ds[DI];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int split = blockIdx.x, otile = blockIdx.y, cg = blockIdx.z;
+  const int CBin = (Cin + 7) / 8, CBout = (Cout + 7) / 8;
+  const int S = D * H * W, OH = 2 * H, OW = 2 * W, OS = S * 8;
+  const int ty_tiles = (H + TY - 1) / TY, tx_tiles = (W + TX - 1) / TX;
+  const int tiles_per_n = D * ty_tiles * tx_tiles, ntiles = N * tiles_per_n;
+  const int cb0 = cg * CT * 4;                                  // first input channel block of this workgroup
+  const int nbx = max(0, min(CT * 4, CBin - cb0)), nbd = max(0, min(4, CBout - 4 * otile));
+
+  // transposed-read lane bases (see conv3_bww_c8_kernel): lane 4q + p of a 16-lane group addresses voxel row q,
+  // channels 4p .. 4p+3 of the group's 16-channel half; groups 2, 3 take the voxels 8 .. 15 of the k-step
+  const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int xl = (8 * (grp >> 1) + tq) * XROW + (grp & 1) * 32 + tp * 8;
+  const int dl = (8 * (grp >> 1) + tq) * 128 + (grp & 1) * 32 + tp * 8;   // dy rows of one x-parity are 128 B apart
+  const int a = wave >> 1, b = wave & 1;
+
+  f32x16 acc[2][CT];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < CT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles, z0 = t / ty_tiles;
+    const int y0 = tyt * TY, x0 = txt * TX;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x16 + (int64_t)n * xbs16 + (int64_t)cb0 * S * 8), 0, nbx * S * 16, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dy16 + (int64_t)n * ybs16 + (int64_t)(4 * otile) * OS * 8), 0, nbd * OS * 16, 0x00020000);
+    __syncthreads();   // the previous tile's fragments have been read
+    for (int e = tid; e < XI; e += 256) {        // item e = (voxel e / (4 CT), channel block e % (4 CT))
+      const int vx = e / (CT * 4), cbl = e - vx * (CT * 4);
+      const int yy = vx / TX, xx = vx - yy * TX;
+      const bool ok = y0 + yy < H && x0 + xx < W && cbl < nbx;
+      xs[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+          rx, ok ? (unsigned)(cbl * S + (z0 * H + y0 + yy) * W + x0 + xx) * 16u : OOB, 0, 0));
+    }
+    for (int e = tid; e < DI; e += 256) {        // dy tile voxel-major: [az][oy][ox][4 blocks], oy < 2 TY, ox < 2 TX
+      const int vo = e >> 2, cbl = e & 3;
+      const int ox = vo % (2 * TX), oy = (vo / (2 * TX)) % (2 * TY), az = vo / (4 * TX * TY);
+      const int gy = 2 * y0 + oy, gx = 2 * x0 + ox;
+      const bool ok = gy < OH && gx < OW && cbl < nbd;
+      ds[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+          rd, ok ? (unsigned)(cbl * OS + ((2 * z0 + az) * OH + gy) * OW + gx) * 16u : OOB, 0, 0));
+    }
+    __syncthreads();
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xs) + xl;
+    const unsigned char* db = reinterpret_cast<const unsigned char*>(ds) + dl;
+#pragma unroll
+    for (int yy = 0; yy < TY; ++yy)
+#pragma unroll
+      for (int xk = 0; xk < 2; ++xk) {
+        typename H16<HT>::x8 af[CT];
+#pragma unroll
+        for (int q = 0; q < CT; ++q) af[q] = tr_frag_rs<HT>(xb + (yy * TX + 16 * xk) * XROW + q * 64, 4 * XROW);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          // output voxel (az = a, oy = 2 yy + b, ox = 2 (16 xk + k) + c), 64 bytes per voxel row
+          const typename H16<HT>::x8 bf =
+              tr_frag_rs<HT>(db + (((a * 2 * TY + 2 * yy + b) * 2 * TX) + 2 * 16 * xk + c) * 64, 4 * 128);
+#pragma unroll
+          for (int q = 0; q < CT; ++q) acc[c][q] = H16<HT>::mfma(af[q], bf, acc[c][q]);
+        }
+      }
+  }
+  // partial dW -> slab[split][t][c][o] (lane = output channel: 32 consecutive floats per store)
+  float* sl = slab + (int64_t)split * 8 * Cin * Cout;
+  const int o = otile * 32 + l32;
+  if (o < Cout) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int t = a * 4 + b * 2 + c;
+#pragma unroll
+      for (int q = 0; q < CT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (cg * CT + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (ci < Cin) sl[((int64_t)t * Cin + ci) * Cout + o] = acc[c][q][r];
+        }
+    }
+  }
+}
+
+// dW[c][o][t] = unscale * sum over splits of slab[split][t][c][o] (fixed order)
+__global__ __launch_bounds__(256) void convt_slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                  int Cin, int Cout, int nsplit, float unscale) {
+  const int64_t total = (int64_t)Cin * Cout * 8, plane = total;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int t = (int)(i & 7);
+    const int64_t co = i >> 3;                 // c * Cout + o
+    double v = 0.0;
+    for (int s = 0; s < nsplit; ++s) v += (double)slab[(int64_t)s * plane + (int64_t)t * Cin * Cout + co];
+    dw[i] = (float)(v * (double)unscale);
+  }
+}
+
 // ----------------------------------------------------- generic direct kernels
 // y[n,o,oz,oy,ox] = bias[o] + sum_{c, taps: (o + pad - d) % stride == 0} x[n,c,(o+pad-d)/stride] * w[c,o,d]
 __global__ void convt_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -1046,4 +1275,105 @@ extern "C" int m355_conv_transpose3d_bwd_weight(const m355_conv3d_desc* d, const
     launch_dbias(dy, dbias, d->N, d->Cout, (int64_t)OD * OH * OW, ybs, (char*)workspace + convt_slab_bytes(d), st);
   }
   return check_launch("conv_transpose3d_bwd_weight");
+}
+
+// ---------------------------------------------------------------- c8 backward entry points (16-bit training flow)
+static bool convt_c8_bwd_ok(const m355_conv3d_desc* d) {
+  // the MFMA kernels: k2 s2, all weights of an m-tile group within 64 KB of A fragments, 32-bit buffer offsets
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  return is_k2s2(d) && 8 * ceil_div(c8_blocks(d->Cout), 2) <= 64 && S * 8 * 16 * 4 < (1ll << 31) &&
+         S * 16 * std::min<int64_t>(16, c8_blocks(d->Cin)) < (1ll << 31);
+}
+static int convt_c8_ct(const m355_conv3d_desc* d) { const int ct = (int)ceil_div(d->Cin, 32); return ct >= 4 ? 4 : (ct >= 2 ? 2 : 1); }
+static int convt_c8_nsplit(const m355_conv3d_desc* d) {
+  const int64_t ntiles = (int64_t)d->N * d->D * ceil_div(d->H, 2) * ceil_div(d->W, 32);
+  const int64_t groups = ceil_div(d->Cout, 32) * ceil_div(ceil_div(d->Cin, 32), convt_c8_ct(d));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 2 * (int64_t)num_cus() / groups));
+}
+
+extern "C" int32_t m355_conv_transpose3d_h16_bwd_supported(const m355_conv3d_desc* d) {
+  return d && d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->D > 0 && d->H > 0 && d->W > 0 && convt_c8_bwd_ok(d) ? 1 : 0;
+}
+
+extern "C" size_t m355_conv_transpose3d_h16_bwd_workspace(const m355_conv3d_desc* d) {
+  if (!d || !m355_conv_transpose3d_h16_bwd_supported(d)) return 0;
+  const int64_t OS = (int64_t)d->D * d->H * d->W * 8;
+  return (size_t)round_up((int64_t)convt_c8_nsplit(d) * 8 * d->Cin * d->Cout * 4, 256) + dbias_c8_ws_bytes(d->N, d->Cout, OS);
+}
+
+extern "C" int m355_conv_transpose3d_bwd_data_h16(const m355_conv3d_desc* d, const void* dy16, int64_t dy16_batch_stride,
+                                                  const float* w, void* dx16, int64_t dx16_batch_stride, int32_t compute,
+                                                  void* stream) {
+  if (int rc = validate_convt(d, "conv_transpose3d_bwd_data_h16")) return rc;
+  M355_REQUIRE(dy16 && w && dx16, M355_EINVALID_ARG, "conv_transpose3d_bwd_data_h16: null pointer");
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "conv_transpose3d_bwd_data_h16: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  M355_REQUIRE(convt_c8_bwd_ok(d), M355_EUNSUPPORTED,
+               "conv_transpose3d_bwd_data_h16: only kernel_size 2 / stride 2 / padding 0 with Cout <= 128 has a c8 kernel "
+               "(m355_conv_transpose3d_h16_bwd_supported)");
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t ybs = dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8 * 8);
+  const int64_t xbs = dense_or(dx16_batch_stride, c8_blocks(d->Cin) * S * 8);
+  M355_REQUIRE((((uintptr_t)dy16 | (uintptr_t)dx16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "conv_transpose3d_bwd_data_h16: c8 tensor not 16B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nks = 8 * (int)ceil_div(c8_blocks(d->Cout), 2);
+  const int mtiles = (int)ceil_div(d->Cin, 32);
+  int mt_per_wg = std::max(1, std::min(std::min(mtiles, 64 / nks), 4));
+  if (mt_per_wg == 3) mt_per_wg = 2;
+  const int groups = (int)ceil_div(mtiles, mt_per_wg);
+  const int64_t vox_tiles = ceil_div(S, 128);
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(vox_tiles, ceil_div(4 * (int64_t)num_cus(), (int64_t)groups * d->N)));
+  dim3 grid((unsigned)gx, (unsigned)groups, (unsigned)d->N);
+  const size_t lds = (size_t)mt_per_wg * nks * 1024;
+#define M355_CTBD(HT, MTW)                                                                                            \
+  hipLaunchKernelGGL((convt_k2s2_bwd_data_h16_kernel<HT, MTW>), grid, dim3(256), lds, st, (const HT*)dy16, w, (HT*)dx16, \
+                     d->Cin, d->Cout, d->D, d->H, d->W, ybs, xbs, mt_per_wg)
+#define M355_CTBD_T(HT)                                                  \
+  if (mt_per_wg == 1) M355_CTBD(HT, 1); else if (mt_per_wg == 2) M355_CTBD(HT, 2); else M355_CTBD(HT, 4);
+  if (compute == M355_COMPUTE_BF16) { M355_CTBD_T(__bf16) } else { M355_CTBD_T(_Float16) }
+#undef M355_CTBD_T
+#undef M355_CTBD
+  return check_launch("convt_k2s2_bwd_data_h16");
+}
+
+extern "C" int m355_conv_transpose3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64_t x16_batch_stride,
+                                                    const void* dy16, int64_t dy16_batch_stride, float* dw, float* dbias,
+                                                    float grad_unscale, int32_t compute, void* workspace,
+                                                    size_t workspace_bytes, void* stream) {
+  if (int rc = validate_convt(d, "conv_transpose3d_bwd_weight_h16")) return rc;
+  M355_REQUIRE(x16 && dy16 && dw && workspace, M355_EINVALID_ARG, "conv_transpose3d_bwd_weight_h16: null pointer");
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "conv_transpose3d_bwd_weight_h16: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16");
+  M355_REQUIRE(convt_c8_bwd_ok(d), M355_EUNSUPPORTED,
+               "conv_transpose3d_bwd_weight_h16: unsupported geometry (m355_conv_transpose3d_h16_bwd_supported)");
+  M355_REQUIRE(workspace_bytes >= m355_conv_transpose3d_h16_bwd_workspace(d), M355_EWORKSPACE,
+               "conv_transpose3d_bwd_weight_h16: workspace too small (%zu < %zu)", workspace_bytes,
+               m355_conv_transpose3d_h16_bwd_workspace(d));
+  const int64_t S = (int64_t)d->D * d->H * d->W;
+  const int64_t xbs = dense_or(x16_batch_stride, c8_blocks(d->Cin) * S * 8);
+  const int64_t ybs = dense_or(dy16_batch_stride, c8_blocks(d->Cout) * S * 8 * 8);
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16) & 15) == 0 && xbs % 8 == 0 && ybs % 8 == 0, M355_EINVALID_ARG,
+               "conv_transpose3d_bwd_weight_h16: c8 tensor not 16B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int ct = convt_c8_ct(d), nsplit = convt_c8_nsplit(d);
+  const int cgroups = (int)ceil_div(ceil_div(d->Cin, 32), ct);
+  float* slab = (float*)workspace;
+  dim3 grid((unsigned)nsplit, (unsigned)ceil_div(d->Cout, 32), (unsigned)cgroups);
+#define M355_CTBW(HT, CT)                                                                                               \
+  hipLaunchKernelGGL((convt_k2s2_bww_c8_kernel<HT, CT>), grid, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16, slab,  \
+                     d->N, d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, nsplit, cgroups)
+#define M355_CTBW_T(HT) if (ct == 1) M355_CTBW(HT, 1); else if (ct == 2) M355_CTBW(HT, 2); else M355_CTBW(HT, 4);
+  if (compute == M355_COMPUTE_BF16) { M355_CTBW_T(__bf16) } else { M355_CTBW_T(_Float16) }
+#undef M355_CTBW_T
+#undef M355_CTBW
+  const int64_t total = (int64_t)d->Cin * d->Cout * 8;
+  hipLaunchKernelGGL(convt_slab_reduce_t_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1024)), dim3(256), 0,
+                     st, slab, dw, d->Cin, d->Cout, nsplit, grad_unscale);
+  if (dbias) {
+    const size_t slab_b = (size_t)round_up((int64_t)nsplit * 8 * d->Cin * d->Cout * 4, 256);
+    if (int rc = launch_dbias_c8(dy16, ybs, dbias, d->N, d->Cout, S * 8, compute, grad_unscale, (char*)workspace + slab_b, st))
+      return rc;
+  }
+  return check_launch("conv_transpose3d_bwd_weight_h16");
 }

@@ -16,8 +16,6 @@
 
 namespace m355 {
 
-constexpr int NORM_CHUNK = 16384;  // elements per block in the reduction passes
-
 struct NormGeom {
   int64_t nstats;  // number of statistics
   int64_t runs;    // runs per statistic
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __res
                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ stat_m, int N,
                                                               int C, int groups, int nblk, int64_t count, int training,
-                                                              const double* __restrict__ count_ptr) {
+                                                              const double* __restrict__ count_ptr, float grad_unscale) {
   // synchronised batch norm: divide by the element count over all ranks; the SUM all-reduce of stat_m is then the mean
   if (count_ptr) count = (int64_t)count_ptr[0];
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
@@ -409,8 +407,10 @@ __global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __res
     a = wave_sum(a);
     bb = wave_sum(bb);
     if (lane == 0) {
-      if (dbeta) dbeta[c] = (float)a;
-      if (dgamma) dgamma[c] = (float)bb;
+      // grad_unscale: 1 except in the fp16 training flow, whose activation gradients travel multiplied by a power of
+      // two (loss scaling); the parameter gradients leave in true units
+      if (dbeta) dbeta[c] = (float)(a * (double)grad_unscale);
+      if (dgamma) dgamma[c] = (float)(bb * (double)grad_unscale);
     }
   }
 }
@@ -610,8 +610,19 @@ static int norm_act_bwd_reduce_impl(const m355_norm_desc* d, const float* x, con
                        d->act_slope, xbs, ybs, nblk_c);
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)nthreads), dim3(64), 0, st, partial, gamma, dgamma, dbeta,
-                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training, count_ptr);
+                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training, count_ptr, 1.f);
   return check_launch(who);
+}
+
+// the finalize stage for the c8 backward (train16.hip), whose first pass writes the same partial layout
+int m355::launch_norm_bwd_reduce(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* stat_m, int N,
+                           int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st) {
+  const int nblk_c = (int)ceil_div(S, NORM_CHUNK);
+  const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
+  const int64_t count = groups == 0 ? (int64_t)N * S : (int64_t)(C / groups) * S;
+  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)std::max<int64_t>(nstats, C)), dim3(64), 0, st, partial, gamma,
+                     dgamma, dbeta, stat_m, N, C, groups, nblk_c, count, training, nullptr, grad_unscale);
+  return check_launch("norm_bwd_reduce");
 }
 
 // second half: dx (and its c8 twin) from x, dy and the per-statistic means

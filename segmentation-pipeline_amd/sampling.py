@@ -126,6 +126,8 @@ class VolumeFeeder:
         self.subjects = subjects
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:      # the worker thread needs the concrete device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.pin = pin_memory and self.cuda
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._slots = [{}, {}]       # device tensors per slot

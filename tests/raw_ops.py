@@ -252,6 +252,94 @@ class RawOps:
                                                       self._stream()), "conv_transpose3d_fwd_h16")
         return y16
 
+    # ---- c8-only training flow (round 3) ----
+    def act16_pack_scaled(self, x, compute, scale):
+        x = self.to(x)
+        N, Cc = x.shape[:2]
+        S = x[0, 0].numel()
+        dt = torch.bfloat16 if compute == 1 else torch.float16
+        x16 = torch.full((N, (Cc + 7) // 8, S, 8), 7.0, dtype=dt, device=self.device)
+        self._chk(self.fn("act16_pack_scaled")(_p(x), _p(x16), N, Cc, S, 0, 0, compute, float(scale), self._stream()),
+                  "act16_pack_scaled")
+        return x16
+
+    def act16_unpack_scaled(self, x16, Cc, spatial, compute, scale):
+        N, CBp, S, _ = x16.shape
+        x = self.empty(N, Cc, *spatial)
+        self._chk(self.fn("act16_unpack_scaled")(_p(x16), _p(x), N, Cc, S, CBp * S * 8, 0, compute, float(scale),
+                                                 self._stream()), "act16_unpack_scaled")
+        return x
+
+    def conv3d_bwd_data_h16_c8(self, dy16, Cout, w, x_shape, compute=1):
+        w = self.to(w)
+        N, CBp, S, _ = dy16.shape
+        d = self.conv_desc(x_shape, Cout, 3, 1, 1, compute=compute)
+        dx16 = torch.full((N, (x_shape[1] + 7) // 8, S, 8), 7.0, dtype=dy16.dtype, device=self.device)
+        n = self.lib.m355_conv3d_h16_workspace(C.byref(d), 1)
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("conv3d_bwd_data_h16_c8")(C.byref(d), _p(dy16), CBp * S * 8, _p(w), _p(dx16), 0, _p(ws), ws.numel(),
+                                                    self._stream()), "conv3d_bwd_data_h16_c8")
+        return dx16
+
+    def conv3d_bwd_weight_c8(self, x16, dy16, Cin, Cout, spatial, compute=1, with_bias=True, unscale=1.0):
+        N = x16.shape[0]
+        d = self.conv_desc((N, Cin) + tuple(spatial), Cout, 3, 1, 1, compute=compute)
+        dw, db = self.empty(Cout, Cin, 3, 3, 3), (self.empty(Cout) if with_bias else None)
+        n = self.lib.m355_conv3d_bwd_weight_c8_workspace(C.byref(d))
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("conv3d_bwd_weight_c8")(C.byref(d), _p(x16), 0, _p(dy16), 0, _p(dw), _p(db), float(unscale), _p(ws),
+                                                  ws.numel(), self._stream()), "conv3d_bwd_weight_c8")
+        return dw, db
+
+    def norm_act_bwd_c8(self, x16, dy16, dpool16, Cc, spatial, mean, rstd, gamma, beta, groups, act, compute, training=1,
+                        unscale=1.0, eps=1e-5, slope=0.01):
+        """-> (dx16, dgamma, dbeta); dy16 / dpool16: c8 gradients (either may be None, not both)"""
+        mean, rstd, gamma, beta = map(self.to, (mean, rstd, gamma, beta))
+        N, S = x16.shape[0], x16.shape[2]
+        D, H, W = spatial
+        d = NormDesc(N, Cc, S, groups, act, eps, slope, 0, 0, 0)
+        dx16 = torch.full_like(x16, 7.0)
+        dg = self.empty(Cc) if gamma is not None else None
+        db = self.empty(Cc) if gamma is not None else None
+        ws = self._ws("norm_workspace", d)
+        self._chk(self.fn("norm_act_bwd_c8")(C.byref(d), _p(x16), 0, _p(dy16), 0, _p(dpool16), 0, D, H, W, _p(mean), _p(rstd),
+                                             _p(gamma), _p(beta), _p(dx16), 0, _p(dg), _p(db), training, float(unscale),
+                                             compute, _p(ws), ws.numel(), self._stream()), "norm_act_bwd_c8")
+        return dx16, dg, db
+
+    def avgpool_bwd_h16(self, dpool16, dskip16, Cc, spatial, compute):
+        D, H, W = spatial
+        N = dpool16.shape[0]
+        dx16 = torch.full((N, (Cc + 7) // 8, D * H * W, 8), 7.0, dtype=dpool16.dtype, device=self.device)
+        self._chk(self.fn("avgpool3d_2x_bwd_h16")(_p(dpool16), _p(dskip16), _p(dx16), N, Cc, D, H, W, 0, 0, 0, compute,
+                                                  self._stream()), "avgpool3d_2x_bwd_h16")
+        return dx16
+
+    def convt_h16_bwd_supported(self, x_shape, Cout):
+        d = self.conv_desc(x_shape, Cout, 2, 2, 0)
+        return bool(self.lib.m355_conv_transpose3d_h16_bwd_supported(C.byref(d)))
+
+    def convt_bwd_data_h16(self, dy16, w, x_shape, compute):
+        w = self.to(w)
+        N, Cin = x_shape[:2]
+        S = x_shape[2] * x_shape[3] * x_shape[4]
+        d = self.conv_desc(x_shape, w.shape[1], 2, 2, 0)
+        dx16 = torch.full((N, (Cin + 7) // 8, S, 8), 7.0, dtype=dy16.dtype, device=self.device)
+        self._chk(self.fn("conv_transpose3d_bwd_data_h16")(C.byref(d), _p(dy16), 0, _p(w), _p(dx16), 0, compute,
+                                                           self._stream()), "conv_transpose3d_bwd_data_h16")
+        return dx16
+
+    def convt_bwd_weight_h16(self, x16, dy16, x_shape, Cout, compute, with_bias=True, unscale=1.0):
+        d = self.conv_desc(x_shape, Cout, 2, 2, 0)
+        dw = self.empty(x_shape[1], Cout, 2, 2, 2)
+        db = self.empty(Cout) if with_bias else None
+        n = self.lib.m355_conv_transpose3d_h16_bwd_workspace(C.byref(d))
+        ws = torch.empty(max(int(n), 16), dtype=torch.uint8, device=self.device)
+        self._chk(self.fn("conv_transpose3d_bwd_weight_h16")(C.byref(d), _p(x16), 0, _p(dy16), 0, _p(dw), _p(db), float(unscale),
+                                                             compute, _p(ws), ws.numel(), self._stream()),
+                  "conv_transpose3d_bwd_weight_h16")
+        return dw, db
+
     def conv3d_fwd_stats(self, x, w, bias=None, groups=0, eps=1e-5):
         """fused conv + statistics: returns (y, mean, rstd) of the normalisation that follows the conv, or
         None when this backend has no fused statistics for the shape"""

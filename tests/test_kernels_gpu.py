@@ -982,3 +982,145 @@ def test_conv3d_bwd_weight_bf16_mode_falls_back_to_exact_fp32(hip, oracle):
         dw_h, _ = hip.conv3d_bwd_weight(x, dy, 3, compute=1)
         dw_o, _ = oracle.conv3d_bwd_weight(x, dy, 3, compute=0)
         close(dw_h, dw_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, "fallback")
+
+
+# ----------------------------------------------------------------- c8-only training flow (round 3)
+def _ulp(compute):
+    return 2.0 ** -8 if compute == 1 else 2.0 ** -11
+
+
+def _dt(compute):
+    return torch.bfloat16 if compute == 1 else torch.float16
+
+
+def _rounded_close(got, ref, compute, atol, what):
+    """`got` = one rounding to the 16-bit type of (a value within atol of) `ref`"""
+    bad = (got - ref).abs() > _ulp(compute) * ref.abs() * 1.01 + atol
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, worst {(got - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_act16_pack_unpack_scaled(hip, compute):
+    """the loss scale enters where a gradient becomes c8: pack == round(x * scale), saturating at the fp16 range
+    (an inf would poison every downstream sum); unpack removes it"""
+    dt = _dt(compute)
+    x = rnd(2, 13, 3, 5, 7, seed=1) * 1e-3
+    x[0, 0, 0, 0, 0], x[1, 2, 1, 1, 1] = 3.0, -5.0
+    scale = 2.0 ** 15
+    x16 = hip.act16_pack_scaled(x, compute, scale)
+    want = (x * scale)
+    if compute == 2:
+        want = want.clamp(-65504.0, 65504.0)
+    assert torch.equal(_c8_to_ncdhw(x16, 13, (3, 5, 7)), want.to(dt).float())
+    assert (x16[:, -1, :, 13 % 8:].float() == 0).all()
+    back = hip.act16_unpack_scaled(x16, 13, (3, 5, 7), compute, 1.0 / scale)
+    assert torch.equal(back.cpu(), want.to(dt).float() / scale)
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("env", [{}, {"M355_CONV_KSPLIT": "2"}])
+def test_conv3d_bwd_data_c8_output_and_weight_gradient_c8(hip, oracle, compute, env, tuning):
+    """m355_conv3d_bwd_data_h16_c8 == m355_conv3d_bwd_data_h16 rounded once; m355_conv3d_bwd_weight_c8: dw bit-identical to
+    m355_conv3d_bwd_weight_h16 (same kernel, unscale 1), the bias gradient reduced from the c8 gradient itself, and
+    grad_unscale applied to both in the fp32 epilogue"""
+    tuning(**env)
+    dt = _dt(compute)
+    for (N, ci, co, D, H, W) in [(2, 16, 40, 5, 6, 36), (1, 24, 13, 6, 9, 16), (1, 4, 32, 8, 8, 32), (1, 32, 3, 4, 8, 32)]:
+        x, dy = rnd(N, ci, D, H, W, seed=1), rnd(N, co, D, H, W, seed=2)
+        w = rnd(co, ci, 3, 3, 3, seed=3) * (1.0 / (27 * co) ** 0.5)
+        x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
+        dx32 = hip.conv3d_bwd_data_h16(dy16, co, w, (N, ci, D, H, W), compute).cpu()
+        dx16 = hip.conv3d_bwd_data_h16_c8(dy16, co, w, (N, ci, D, H, W), compute)
+        assert torch.equal(_c8_to_ncdhw(dx16, ci, (D, H, W)), dx32.to(dt).float())
+        if ci % 8:
+            assert (dx16[:, -1, :, ci % 8:].float() == 0).all()
+        dw0, _ = hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (D, H, W), compute)
+        dw, db = hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (D, H, W), compute)
+        assert torch.equal(dw, dw0)
+        dyr = dy.to(dt).float()
+        close(db, dyr.double().sum(dim=(0, 2, 3, 4)).float(), 1e-5, 1e-4, "dbias from c8")
+        dws, dbs = hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (D, H, W), compute, unscale=2.0 ** -7)
+        assert torch.equal(dws, dw * 2.0 ** -7)
+        close(dbs, db * 2.0 ** -7, 1e-6, 1e-7, "dbias unscale")
+        # and against the oracle on the rounded operands
+        ref_dw, _ = oracle.conv3d_bwd_weight(x.to(dt).float(), dyr, 3)
+        close(dw, ref_dw, 3e-5, 3e-5 * ref_dw.abs().max().item(), "dw vs oracle")
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_norm_act_bwd_c8(hip, oracle, compute):
+    """m355_norm_act_bwd_c8 == the oracle's backward on the 16-bit values (x16 = pre-norm tensor; incoming gradient =
+    dy16 + un-pooled dpool16, either alone or both), dx rounded once; dgamma / dbeta fp32 with grad_unscale.
+    GroupNorm / BatchNorm geometry, ReLU / LeakyReLU / none, N = 2, ragged channel counts, eval mode."""
+    dt = _dt(compute)
+    cases = [(2, 16, 4, 6, 8, 4, 1, 1, "both"), (1, 12, 2, 4, 6, 0, 2, 1, "dy"), (1, 40, 4, 4, 32, 8, 1, 1, "pool"),
+             (2, 13, 2, 6, 8, 0, 1, 0, "both"), (1, 8, 34, 32, 32, 2, 0, 1, "dy")]
+    for (N, Cc, D, H, W, groups, act, training, src) in cases:
+        x, dy = rnd(N, Cc, D, H, W, seed=1), rnd(N, Cc, D, H, W, seed=6)
+        dp = rnd(N, Cc, D // 2, H // 2, W // 2, seed=7)
+        gamma, beta = rnd(Cc, seed=2) * 0.5 + 1.0, rnd(Cc, seed=3) * 0.1
+        x16 = hip.act16_pack(x, compute)
+        dy16 = hip.act16_pack(dy, compute) if src in ("dy", "both") else None
+        dp16 = hip.act16_pack(dp, compute) if src in ("pool", "both") else None
+        xr = x.to(dt).float()
+        g = torch.zeros_like(x)
+        if dy16 is not None:
+            g = g + dy.to(dt).float()
+        if dp16 is not None:
+            g = g + 0.125 * dp.to(dt).float().repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+        mean, rstd = oracle.norm_stats(xr, groups)[:2]
+        ref_dx, ref_dg, ref_db = oracle.norm_act_bwd(xr, g, mean, rstd, gamma, beta, groups, act, training=training)
+        dx16, dg, db = hip.norm_act_bwd_c8(x16, dy16, dp16, Cc, (D, H, W), mean, rstd, gamma, beta, groups, act, compute,
+                                           training=training)
+        scale = ref_dx.abs().max().item()
+        _rounded_close(_c8_to_ncdhw(dx16, Cc, (D, H, W)), ref_dx, compute, 2e-5 * scale, f"dx {(N, Cc, groups, act, src)}")
+        close(dg, ref_dg, 1e-4, 1e-4 * ref_dg.abs().max().item(), "dgamma")
+        close(db, ref_db, 1e-4, 1e-4 * ref_db.abs().max().item(), "dbeta")
+        if Cc % 8:
+            assert (dx16[:, -1, :, Cc % 8:].float() == 0).all()
+        _, dg2, db2 = hip.norm_act_bwd_c8(x16, dy16, dp16, Cc, (D, H, W), mean, rstd, gamma, beta, groups, act, compute,
+                                          training=training, unscale=0.25)
+        close(dg2, dg * 0.25, 1e-6, 1e-7, "dgamma unscale")
+        close(db2, db * 0.25, 1e-6, 1e-7, "dbeta unscale")
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_avgpool_bwd_c8(hip, compute):
+    dt = _dt(compute)
+    for (N, Cc, D, H, W) in [(2, 16, 4, 6, 8), (1, 13, 2, 4, 34)]:
+        dp, sk = rnd(N, Cc, D // 2, H // 2, W // 2, seed=1), rnd(N, Cc, D, H, W, seed=2)
+        dp16, sk16 = hip.act16_pack(dp, compute), hip.act16_pack(sk, compute)
+        up = 0.125 * dp.to(dt).float().repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+        got = _c8_to_ncdhw(hip.avgpool_bwd_h16(dp16, None, Cc, (D, H, W), compute), Cc, (D, H, W))
+        assert torch.equal(got, up.to(dt).float())
+        got = _c8_to_ncdhw(hip.avgpool_bwd_h16(dp16, sk16, Cc, (D, H, W), compute), Cc, (D, H, W))
+        _rounded_close(got, up + sk.to(dt).float(), compute, 1e-7, "pool bwd + skip")
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_conv_transpose3d_c8_backward(hip, oracle, compute):
+    """m355_conv_transpose3d_bwd_data_h16 / _bwd_weight_h16 (k2 s2, c8 operands, 16-bit MFMA) == the oracle on the
+    16-bit operand values (weights rounded too in the data gradient), dx rounded once; ragged channel counts, voxel
+    tiles that overhang, N = 2, grad_unscale; unsupported geometries are reported by the query."""
+    dt = _dt(compute)
+    assert not hip.convt_h16_bwd_supported((1, 320, 8, 8, 8), 256)
+    for (N, ci, co, D, H, W) in [(1, 64, 32, 4, 4, 32), (2, 24, 40, 3, 5, 6), (1, 128, 64, 2, 2, 34), (1, 8, 13, 4, 4, 4),
+                                 (1, 160, 16, 2, 3, 33)]:
+        assert hip.convt_h16_bwd_supported((N, ci, D, H, W), co)
+        x, dy = rnd(N, ci, D, H, W, seed=1), rnd(N, co, 2 * D, 2 * H, 2 * W, seed=2)
+        w = rnd(ci, co, 2, 2, 2, seed=3) * 0.2
+        x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
+        xr, dyr, wr = x.to(dt).float(), dy.to(dt).float(), w.to(dt).float()
+        ref_dx = oracle.convt_bwd_data(dyr, wr, (N, ci, D, H, W), 2, 0, 0)
+        dx16 = hip.convt_bwd_data_h16(dy16, w, (N, ci, D, H, W), compute)
+        _rounded_close(_c8_to_ncdhw(dx16, ci, (D, H, W)), ref_dx, compute, 3e-5 * ref_dx.abs().max().item(),
+                       f"convT dx {(N, ci, co, D, H, W)}")
+        if ci % 8:
+            assert (dx16[:, -1, :, ci % 8:].float() == 0).all()
+        ref_dw, ref_db = oracle.convt_bwd_weight(xr, dyr, 2, 2, 0, 0)
+        dw, db = hip.convt_bwd_weight_h16(x16, dy16, (N, ci, D, H, W), co, compute)
+        close(dw, ref_dw, 3e-5, 3e-5 * ref_dw.abs().max().item(), f"convT dw {(N, ci, co, D, H, W)}")
+        close(db, ref_db, 1e-5, 1e-4, "convT dbias")
+        dw2, db2 = hip.convt_bwd_weight_h16(x16, dy16, (N, ci, D, H, W), co, compute, unscale=0.5)
+        close(dw2, dw * 0.5, 1e-6, 1e-8, "convT dw unscale")
+        close(db2, db * 0.5, 1e-6, 1e-8, "convT dbias unscale")
