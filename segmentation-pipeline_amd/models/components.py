@@ -224,8 +224,11 @@ def run_norm_act(norm, act, x, add=None, out=None, stats=None, c8=0, pool=False)
     return nn.AvgPool3d(2, 2) of the result, computed in the same pass -> (y, pooled)."""
     code, slope = _act_code(act)
     fn = ops.norm_act
-    if pool:
-        assert add is None and not c8
+    if pool and c8:      # c8 training flow: the pooled tensor is a second output of the c8 -> c8 pass
+        assert add is None
+        fn = lambda x_, g_, b_, cfg_, add=None: ops.norm_act(x_, g_, b_, cfg_, pool=True)
+    elif pool:
+        assert add is None
         fn = lambda x_, g_, b_, cfg_, add=None: ops.norm_act_pool(x_, g_, b_, cfg_)
     if norm is None:
         # activation only: identity statistics
@@ -345,6 +348,11 @@ class Block3d(nn.Module):
                 if (pool and ops.FUSE_POOL and last and add is None and not drop and not c8 and ops.get_precision() == "fp32"
                         and isinstance(h, torch.Tensor) and all(v % 2 == 0 for v in h.shape[2:])):
                     return run_norm_act(norm, act, h, out=slot, stats=stats, pool=True)   # -> (result, pooled)
+                if (pool and last and add is None and not drop and c8 and torch.is_grad_enabled() and norm is not None
+                        and isinstance(h, ops.Act16) and all(v % 2 == 0 for v in h.shape[2:])):
+                    # c8 training flow: (result, pooled) from one autograd node, whose backward sums the skip-path and
+                    # the un-pooled gradient inside the normalisation backward
+                    return run_norm_act(norm, act, h, out=slot, stats=stats, c8=c8, pool=True)
                 h = run_norm_act(norm, act, h, add=add, out=slot, stats=stats, c8=c8)
         if self._num_convs == 0 and res is not None:
             h = ops.add(res, h)

@@ -168,11 +168,14 @@ class ModularUNet(nn.Module):
                 else:
                     buf = torch.empty((N, c_up + f[i]) + spatial, dtype=torch.float32, device=x.device)
                     slot = ops.OutSlot(buf, c_up, c_up + f[i])
-                fuse_pool = (not flow and _is_avgpool2(self.downsampling[i]) and isinstance(self.down_blocks[i], Block3d))
+                # the block's last pass also emits the pooled tensor: fp32 flow, and the c8 TRAINING flow (one autograd
+                # node for both uses of the block output); the c8 no-grad flow pools in its own small pass
+                fuse_pool = ((not flow or torch.is_grad_enabled()) and _is_avgpool2(self.downsampling[i])
+                             and isinstance(self.down_blocks[i], Block3d))
                 x = self.down_blocks[i](x, out=slot, pool=True) if fuse_pool else self.down_blocks[i](x, out=slot)
                 if isinstance(x, tuple):
                     x_skip, x = x      # AvgPool3d(2, 2) came out of the block's last norm + activation pass
-                elif (isinstance(self.downsampling[i], nn.AvgPool3d) and isinstance(x, torch.Tensor)
+                elif (isinstance(self.downsampling[i], nn.AvgPool3d) and isinstance(x, (torch.Tensor, ops.Act16))
                         and x.requires_grad and torch.is_grad_enabled()):
                     _run_downsample(self.downsampling[i], None)          # validates the module's geometry
                     x_skip, x = ops.avgpool3d_2x_with_skip(x)            # one fused gradient for both uses

@@ -182,18 +182,41 @@ def _alloc_out(out: Optional[OutSlot], shape, like):
 
 # ----------------------------------------------------- c8 activations (16-bit modes)
 def h16_flow() -> int:
-    """The 16-bit compute code when activations should flow in the c8 layout (a 16-bit precision mode and
-    no autograd recording), else 0."""
+    """The 16-bit compute code when activations should flow in the c8 layout (a 16-bit precision mode; with autograd
+    recording the c8-only training flow, H16_TRAIN_C8ONLY), else 0."""
     c = _COMPUTE[_compute_mode]
-    return c if (c != _lib.COMPUTE_F32 and not torch.is_grad_enabled()) else 0
+    if c == _lib.COMPUTE_F32:
+        return 0
+    if not torch.is_grad_enabled():
+        return c
+    # with autograd: the c8-only training flow (`_*C8Fn` below), except under synchronised batch norm, whose backward is
+    # split around an all-reduce (fp32 halves only)
+    return c if (H16_TRAIN_C8ONLY and _bn_sync_group is None) else 0
 
 
 class Act16:
     """An activation in the c8 layout: `data` is [N, CB_total, S, 8] (bf16 / fp16); this activation
     occupies the channel blocks [cb0, cb0 + ceil(C / 8)) of it (a slot of a concat buffer, or all of it)."""
 
-    def __init__(self, data: torch.Tensor, C: int, spatial, compute: int, cb0: int = 0):
+    def __init__(self, data: torch.Tensor, C: int, spatial, compute: int, cb0: int = 0, t: Optional[torch.Tensor] = None):
         self.data, self.C, self.spatial, self.compute, self.cb0 = data, int(C), tuple(spatial), compute, cb0
+        # c8-only TRAINING flow: the autograd handle of this activation -- a [N, CB, S, 8] tensor aliasing exactly its
+        # channel blocks of `data` (produced by one of the `_*C8Fn` functions below); None outside autograd
+        self.t = t
+
+    @property
+    def requires_grad(self):
+        return self.t is not None and self.t.requires_grad
+
+    @property
+    def CB(self):
+        return (self.C + 7) // 8
+
+    def alias(self):
+        """a fresh [N, CB, S, 8] tensor over exactly this activation's blocks (no autograd history)"""
+        d = self.data
+        N, CBt, S = d.shape[0], d.shape[1], d.shape[2]
+        return torch.as_strided(d.detach(), (N, self.CB, S, 8), (CBt * S * 8, S * 8, 8, 1), d.storage_offset() + self.cb0 * S * 8)
 
     @staticmethod
     def empty(N, C, spatial, compute, device):
@@ -224,6 +247,8 @@ class Act16:
         return Act16(self.data, c1 - c0, self.spatial, self.compute, self.cb0 + c0 // 8)
 
     def to_f32(self):
+        if torch.is_grad_enabled() and self.requires_grad:      # c8 training flow: differentiable (fallback ops)
+            return _UnpackFn.apply(self.t, self)
         N = self.data.shape[0]
         x = torch.empty((N, self.C) + self.spatial, dtype=torch.float32, device=self.device)
         check(_lib.lib().m355_act16_unpack(self.ptr(), _p(x), N, self.C, self.S, self.batch_stride(), 0, self.compute,
@@ -233,6 +258,14 @@ class Act16:
 
 def pack_act16(x: torch.Tensor, compute: int, out: Optional[Act16] = None) -> Act16:
     """fp32 NCDHW tensor -> c8 (into `out`, a slot of matching shape, or a fresh buffer)."""
+    if torch.is_grad_enabled() and x.requires_grad and h16_flow():   # c8 training flow: differentiable (fallback ops)
+        N, Cc = x.shape[:2]
+        if out is None:
+            out = Act16.empty(N, Cc, x.shape[2:], compute, x.device)
+        elif out.shape != tuple(x.shape):
+            raise _lib.M355Error(f"c8 slot shape {out.shape} != tensor shape {tuple(x.shape)}")
+        t = _PackFn.apply(x, out)
+        return Act16(out.data, out.C, out.spatial, out.compute, out.cb0, t)
     _require(x)
     x, xbs = _dense_channels(x)
     N, Cc = x.shape[:2]
@@ -257,6 +290,29 @@ PACK_CACHE = True
 # 16-bit precision modes, training: pack the conv input / output gradient to c8 once in the autograd function and run
 # forward, data gradient and weight gradient on the c8 entry points (False: fp32 operands, staged inside the library)
 H16_TRAIN_C8 = True
+# ... and keep activations AND activation gradients of ModularUNet / Block3d only in c8 while training (round 3: the
+# fp32 tensors the twin flow keeps beside the c8 ones bound the 16-bit step); False: the round-2 twin flow
+H16_TRAIN_C8ONLY = os.environ.get("M355_TRAIN_C8ONLY", "1") != "0"
+_bn_sync_group = None      # (defined properly with batch_norm_sync below)
+
+# fp16 carries activation gradients multiplied by a power of two (include/m355seg.h, "grad_scale"): "auto" derives it
+# from the size of the prediction at the output convolution -- the gradient of a mean-type loss is ~1/(N * voxels) --
+# as 2^(floor(log2(N * voxels)) + 6); a number fixes it.  bf16 has fp32's exponent range: always 1.
+FP16_GRAD_SCALE = "auto"
+_fp16_scale = 2.0 ** 16
+
+
+def grad_scale(compute) -> float:
+    return _fp16_scale if compute == _lib.COMPUTE_F16 else 1.0
+
+
+def _set_auto_grad_scale(n_elements):
+    global _fp16_scale
+    if FP16_GRAD_SCALE == "auto":
+        import math
+        _fp16_scale = 2.0 ** min(24, max(0, int(math.floor(math.log2(max(1, n_elements)))) + 6))
+    else:
+        _fp16_scale = float(FP16_GRAD_SCALE)
 # an encoder block's last norm + activation pass also emits the AvgPool3d(2, 2) the next level consumes
 FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"
 
@@ -400,6 +456,422 @@ def _conv3d_act16(x16: Act16, weight, bias, add, stats, c8_out=False, softmax=Fa
     if softmax and not fuse_sm:
         y = softmax_channels(as_f32(y))
     return y
+
+
+# ------------------------------------------------- c8-only TRAINING flow (16-bit modes, autograd on)
+# Activations and their gradients are [N, CB, S, 8] 16-bit tensors (the c8 layout) on BOTH sides of every function:
+# forward kernels as in the no-grad flow, backward kernels from csrc/train16.hip / convt.hip (include/m355seg.h,
+# "c8-only TRAINING flow").  An `Act16` carries the autograd handle `t` of its tensor; the functions read their
+# operands through the `Act16` objects in `meta` (pointers, batch strides) and take the handles only as graph edges.
+def _c8t(t):
+    """(tensor, batch stride) of a [N, CB, S, 8] c8 tensor whose samples are dense -- a slot alias or a slice of a
+    gradient buffer along the block axis; anything else is compacted first"""
+    N, CB, S, _ = t.shape
+    st = t.stride()
+    if st[3] != 1 or st[2] != 8 or (CB > 1 and st[1] != S * 8) or (N > 1 and st[0] % 8):
+        t = t.contiguous()
+        return t, CB * S * 8
+    return t, (st[0] if N > 1 else CB * S * 8)
+
+
+def _pack_scaled(x, compute, scale):
+    """fp32 NCDHW gradient -> dense c8 tensor, multiplied by the loss scale of the mode"""
+    x, xbs = _dense_channels(x)
+    N, Cc = x.shape[:2]
+    S = x.shape[2] * x.shape[3] * x.shape[4]
+    out = torch.empty((N, (Cc + 7) // 8, S, 8), dtype=_DT16[compute], device=x.device)
+    check(_lib.lib().m355_act16_pack_scaled(_p(x), _p(out), N, Cc, S, xbs, 0, compute, float(scale), _stream()),
+          "act16_pack_scaled")
+    return out
+
+
+def _unpack_scaled(t, Cc, spatial, compute, scale):
+    t, bs = _c8t(t)
+    N, S = t.shape[0], t.shape[2]
+    x = torch.empty((N, Cc) + tuple(spatial), dtype=torch.float32, device=t.device)
+    check(_lib.lib().m355_act16_unpack_scaled(_p(t), _p(x), N, Cc, S, bs, 0, compute, float(scale), _stream()),
+          "act16_unpack_scaled")
+    return x
+
+
+class _PackFn(torch.autograd.Function):
+    """fp32 NCDHW -> c8 (the generic entry of a tensor into the c8 training flow); backward: the c8 gradient back to
+    fp32, loss scale removed"""
+
+    @staticmethod
+    def forward(ctx, x, out: Act16):
+        _require(x)
+        xd, xbs = _dense_channels(x)
+        N, Cc = xd.shape[:2]
+        check(_lib.lib().m355_act16_pack(_p(xd), out.ptr(), N, Cc, out.S, xbs, out.batch_stride(), out.compute, _stream()),
+              "act16_pack")
+        ctx.info = (Cc, out.spatial, out.compute)
+        return out.alias()
+
+    @staticmethod
+    def backward(ctx, dy16):
+        Cc, spatial, compute = ctx.info
+        return _unpack_scaled(dy16, Cc, spatial, compute, 1.0 / grad_scale(compute)), None
+
+
+class _UnpackFn(torch.autograd.Function):
+    """c8 -> fp32 NCDHW (ops without a c8 kernel: trilinear upsampling, dropout, space-to-depth ...); backward: the fp32
+    gradient enters the c8 flow (loss scale applied)"""
+
+    @staticmethod
+    def forward(ctx, t, a: Act16):
+        N = a.data.shape[0]
+        x = torch.empty((N, a.C) + a.spatial, dtype=torch.float32, device=a.device)
+        check(_lib.lib().m355_act16_unpack(a.ptr(), _p(x), N, a.C, a.S, a.batch_stride(), 0, a.compute, _stream()),
+              "act16_unpack")
+        ctx.compute = a.compute
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _pack_scaled(dy, ctx.compute, grad_scale(ctx.compute)), None
+
+
+@dataclass
+class _C8ConvMeta:
+    x16: "Act16"                      # the whole (possibly concatenated) conv input
+    part_blocks: Sequence[int]        # channel blocks of each autograd part of it
+    out16: Optional["Act16"] = None   # c8 destination (None with f32_out)
+    f32_out: bool = False             # fp32 NCDHW result (the out conv), optionally with the fused softmax
+    softmax: bool = False
+    stats: Optional[dict] = None
+    has_add: bool = False
+
+
+class _Conv3dC8Fn(torch.autograd.Function):
+    """3x3x3 / s1 / p1 convolution of the c8 training flow: c8 in -> c8 out (pre-norm tensor, statistics fused), or
+    -> fp32 (+ softmax) for the output convolution.  Backward: weight / bias gradient from the two c8 operands
+    (m355_conv3d_bwd_weight_c8), data gradient c8 -> c8 (m355_conv3d_bwd_data_h16_c8) sliced per concat part."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, add, meta: _C8ConvMeta, *part_ts):
+        L = _lib.lib()
+        x16 = meta.x16
+        _require(weight, bias, add)
+        weight = weight.contiguous()
+        N, Cin, D, H, W = x16.shape
+        Cout = weight.shape[0]
+        d = _conv_desc(N, Cin, Cout, D, H, W, 3, 1, 1, 0, 0, compute=x16.compute)
+        wbuf, flags = _packed_weight(weight, d, 0)
+        fuse_sm = meta.softmax and add is None and L.m355_conv3d_fuses_softmax(C.byref(d)) != 0
+        dk = _with_flags(d, flags | (_lib.CONV_SOFTMAX if fuse_sm else 0))
+        ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(d), 0), x16.device)
+        prof, plan = _prof_gate("conv3d_fwd", d, 0)
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        part = None
+        slots = 0
+        if meta.stats is not None:
+            slots = L.m355_conv3d_stats_slots(C.byref(d)) if meta.f32_out else L.m355_conv3d_stats_slots_c8(C.byref(d))
+        if slots > 0:
+            part = torch.empty((N, slots, Cout, 2), dtype=torch.float32, device=x16.device)
+            meta.stats["partials"], meta.stats["slots"] = part, slots
+        if meta.f32_out:
+            if add is not None:
+                add = add.contiguous()
+            y = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x16.device)
+            check(L.m355_conv3d_fwd_h16(C.byref(dk), x16.ptr(), x16.batch_stride(), _p(wbuf), _p(bias), _p(add), _p(y),
+                                        _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16")
+            if meta.softmax and not fuse_sm:
+                logits, y = y, torch.empty_like(y)
+                check(L.m355_softmax_fwd(_p(logits), _p(y), N, Cout, 1, D * H * W, 0.0, _stream()), "softmax_fwd")
+            if meta.softmax:
+                _set_auto_grad_scale(N * D * H * W)
+            out = y
+        else:
+            y16 = meta.out16
+            check(L.m355_conv3d_fwd_h16_c8(C.byref(dk), x16.ptr(), x16.batch_stride(), _p(wbuf), _p(bias), y16.ptr(),
+                                           y16.batch_stride(), _p(part), _p(ws), ws.numel(), _stream()), "conv3d_fwd_h16_c8")
+            out = y16.alias()
+        if prof is not None:
+            e1.record()
+            prof.append(("conv3d_fwd", 2.0 * 27 * Cin * Cout * N * D * H * W, e0, e1, plan,
+                         _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 4 if meta.f32_out else 2)))
+        ctx.meta, ctx.desc = meta, d
+        ctx.has_bias = bias is not None
+        ctx.x_info = (x16.C, x16.spatial, x16.compute)
+        xa = x16.alias()
+        if meta.softmax:
+            ctx.save_for_backward(xa, weight, out)
+        else:
+            ctx.save_for_backward(xa, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        meta, d = ctx.meta, ctx.desc
+        compute = d.compute
+        scale = grad_scale(compute)
+        if meta.softmax:
+            xa, weight, y = ctx.saved_tensors
+            dy = dy.contiguous()
+            dl = torch.empty_like(y)
+            check(L.m355_softmax_bwd(_p(y), _p(dy), _p(dl), d.N, d.Cout, 1, y.numel() // (d.N * d.Cout), _stream()),
+                  "softmax_bwd")
+            dy = dl
+        else:
+            xa, weight = ctx.saved_tensors
+        dadd = dy if (meta.has_add and ctx.needs_input_grad[2]) else None
+        if meta.f32_out:        # the gradient enters the c8 flow here
+            dy16 = _pack_scaled(dy, compute, scale)
+        else:
+            dy16 = dy
+        dy16, dybs = _c8t(dy16)
+        xa, xbs = _c8t(xa)
+        need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_bias
+        need_x = any(ctx.needs_input_grad[4:])
+        dw = db = None
+        if need_w or need_b:
+            dw = torch.empty_like(weight)
+            db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+            prof, _ = _prof_gate("conv3d_bwd_weight")
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ws = _workspace(L.m355_conv3d_bwd_weight_c8_workspace(C.byref(d)), weight.device)
+            check(L.m355_conv3d_bwd_weight_c8(C.byref(d), _p(xa), xbs, _p(dy16), dybs, _p(dw), _p(db), 1.0 / scale, _p(ws),
+                                              ws.numel(), _stream()), "conv3d_bwd_weight_c8")
+            if prof is not None:
+                e1.record()
+                vox = d.D * d.H * d.W
+                prof.append(("conv3d_bwd_weight", 2.0 * 27 * d.Cin * d.Cout * d.N * vox, e0, e1, None,
+                             _conv_bytes(d.N, d.Cin, d.Cout, vox, 27, 2, 2)))
+        dparts: List[Optional[torch.Tensor]] = [None] * len(meta.part_blocks)
+        if need_x:
+            S = d.D * d.H * d.W
+            dx16 = torch.empty((d.N, (d.Cin + 7) // 8, S, 8), dtype=_DT16[compute], device=weight.device)
+            dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, 3, 1, 1, 0, 0, compute=compute)
+            wbuf, flags = _packed_weight(weight, dd, 1)
+            ws = _workspace(L.m355_conv3d_h16_workspace(C.byref(dd), 1), weight.device)
+            prof, plan = _prof_gate("conv3d_bwd_data", dd, 1)
+            dd = _with_flags(dd, flags)
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(L.m355_conv3d_bwd_data_h16_c8(C.byref(dd), _p(dy16), dybs, _p(wbuf), _p(dx16), 0, _p(ws), ws.numel(),
+                                                _stream()), "conv3d_bwd_data_h16_c8")
+            if prof is not None:
+                e1.record()
+                prof.append(("conv3d_bwd_data", 2.0 * 27 * d.Cin * d.Cout * d.N * S, e0, e1, plan,
+                             _conv_bytes(d.N, d.Cin, d.Cout, S, 27, 2, 2)))
+            b0 = 0
+            for i, nb in enumerate(meta.part_blocks):
+                if ctx.needs_input_grad[4 + i]:
+                    dparts[i] = dx16 if len(meta.part_blocks) == 1 else dx16[:, b0:b0 + nb]
+                b0 += nb
+        return (dw if need_w else None, db if need_b else None, dadd, None, *dparts)
+
+
+def _conv3d_c8_train(x16: Act16, parts, weight, bias, add, stats, c8_out, softmax, out16=None):
+    """dispatch of `_conv3d_act16` while autograd records (c8 training flow)"""
+    if parts is None:
+        parts = [x16]
+    if any(p.C % 8 for p in parts[:-1]):
+        raise _lib.M355Error("c8 training flow: concat parts must be whole channel blocks")
+    if c8_out and out16 is None:
+        N, _, D, H, W = x16.shape
+        out16 = Act16.empty(N, weight.shape[0], (D, H, W), x16.compute, x16.device)
+    meta = _C8ConvMeta(x16, [p.CB for p in parts], out16=out16, f32_out=not c8_out, softmax=softmax, stats=stats,
+                       has_add=add is not None)
+    out = _Conv3dC8Fn.apply(weight, bias, add, meta, *[p.t for p in parts])
+    if not c8_out:
+        return out
+    y16 = meta.out16
+    if stats is not None and "partials" not in stats:
+        _c8_channel_partials(y16, stats)
+    return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, out)
+
+
+@dataclass
+class _C8NormMeta:
+    x16: "Act16"
+    add16: Optional["Act16"]
+    out16: Optional["Act16"]
+    cfg: "NormCfg"
+    pool: bool = False
+    pooled16: Optional["Act16"] = None
+
+
+class _NormActC8Fn(torch.autograd.Function):
+    """normalisation + activation (+ residual add) of the c8 training flow, c8 -> c8; optionally nn.AvgPool3d(2, 2) of
+    the result as a second output (an encoder block's output feeds the skip connection and the next level).  Backward:
+    ONE call of m355_norm_act_bwd_c8, which also sums the skip-path and the un-pooled gradient."""
+
+    @staticmethod
+    def forward(ctx, x_t, gamma, beta, add_t, meta: _C8NormMeta):
+        L = _lib.lib()
+        x, cfg = meta.x16, meta.cfg
+        _require(gamma, beta)
+        N, Cc, spatial, S = x.shape[0], x.C, x.spatial, x.S
+        out16 = meta.out16
+        d = NormDesc(N, Cc, S, cfg.groups, cfg.act, cfg.eps, cfg.slope, 0, 0, 0)
+        use_batch = cfg.groups > 0 or cfg.training or cfg.running_mean is None
+        if use_batch and not (cfg.stats and cfg.stats.get("partials") is not None):
+            cfg.stats = {} if cfg.stats is None else cfg.stats
+            _c8_channel_partials(x, cfg.stats)
+        mean, rstd, use_batch = _norm_statistics(L, d, None, cfg, N, Cc, device=x.device)
+        a16 = meta.add16
+        check(L.m355_norm_act_fwd_c8(C.byref(d), x.ptr(), x.batch_stride(), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                     a16.ptr() if a16 is not None else None, a16.batch_stride() if a16 is not None else 0,
+                                     out16.ptr(), out16.batch_stride(), x.compute, _stream()), "norm_act_fwd_c8")
+        ctx.desc, ctx.batch_stats, ctx.has_add, ctx.has_affine = d, use_batch, a16 is not None, gamma is not None
+        ctx.compute, ctx.spatial = x.compute, spatial
+        ctx.save_for_backward(x.alias(), mean, rstd, gamma, beta)
+        if not meta.pool:
+            return out16.alias()
+        D, H, W = spatial
+        p16 = meta.pooled16
+        check(L.m355_avgpool3d_2x_fwd_h16(out16.ptr(), p16.ptr(), N, Cc, D, H, W, out16.batch_stride(), p16.batch_stride(),
+                                          x.compute, _stream()), "avgpool3d_2x_fwd_h16")
+        return out16.alias(), p16.alias()
+
+    @staticmethod
+    def backward(ctx, dy16, dpool16=None):
+        L = _lib.lib()
+        xa, mean, rstd, gamma, beta = ctx.saved_tensors
+        d = ctx.desc
+        compute = ctx.compute
+        xa, xbs = _c8t(xa)
+        dyb = dpb = 0
+        if dy16 is not None:
+            dy16, dyb = _c8t(dy16)
+        if dpool16 is not None:
+            dpool16, dpb = _c8t(dpool16)
+        dx16 = torch.empty((d.N, (d.C + 7) // 8, d.S, 8), dtype=_DT16[compute], device=xa.device)
+        dgamma = torch.empty(d.C, dtype=torch.float32, device=xa.device) if ctx.has_affine else None
+        dbeta = torch.empty(d.C, dtype=torch.float32, device=xa.device) if ctx.has_affine else None
+        ws = _workspace(L.m355_norm_workspace(C.byref(d)), xa.device)
+        D, H, W = ctx.spatial
+        check(L.m355_norm_act_bwd_c8(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean), _p(rstd),
+                                     _p(gamma), _p(beta), _p(dx16), 0, _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0,
+                                     1.0 / grad_scale(compute), compute, _p(ws), ws.numel(), _stream()), "norm_act_bwd_c8")
+        dadd = dy16 if (ctx.has_add and ctx.needs_input_grad[3]) else None
+        return dx16, dgamma, dbeta, dadd, None
+
+
+def _norm_act_c8_train(x: Act16, gamma, beta, add, cfg: "NormCfg", pool=False):
+    out16 = cfg.out.act16() if cfg.out is not None else None
+    if out16 is not None and out16.shape != x.shape:
+        raise _lib.M355Error(f"c8 slot shape {out16.shape} != op output shape {x.shape}")
+    add16 = None
+    if add is not None:
+        add16 = add if isinstance(add, Act16) else pack_act16(add, x.compute)
+    if out16 is None:
+        out16 = Act16.empty(x.shape[0], x.C, x.spatial, x.compute, x.device)
+    pooled16 = None
+    if pool:
+        D, H, W = x.spatial
+        pooled16 = Act16.empty(x.shape[0], x.C, (D // 2, H // 2, W // 2), x.compute, x.device)
+    meta = _C8NormMeta(x, add16, out16, cfg, pool, pooled16)
+    res = _NormActC8Fn.apply(x.t, gamma, beta, add16.t if add16 is not None else None, meta)
+    o = meta.out16
+    if pool:
+        y = Act16(o.data, o.C, o.spatial, o.compute, o.cb0, res[0])
+        p = meta.pooled16
+        return y, Act16(p.data, p.C, p.spatial, p.compute, p.cb0, res[1])
+    return Act16(o.data, o.C, o.spatial, o.compute, o.cb0, res)
+
+
+class _PoolC8Fn(torch.autograd.Function):
+    """nn.AvgPool3d(2, 2) c8 -> c8; skip=True: also returns the input as it continues into the skip connection, so that
+    the backward receives both gradients and sums them in the pool-backward pass"""
+
+    @staticmethod
+    def forward(ctx, x_t, x: Act16, out16: Optional[Act16], skip: bool):
+        N, Cc, D, H, W = x.shape
+        y16 = out16 if out16 is not None else Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        check(_lib.lib().m355_avgpool3d_2x_fwd_h16(x.ptr(), y16.ptr(), N, Cc, D, H, W, x.batch_stride(), y16.batch_stride(),
+                                                   x.compute, _stream()), "avgpool3d_2x_fwd_h16")
+        ctx.info = (N, Cc, D, H, W, x.compute)
+        return (x_t.view_as(x_t), y16.alias()) if skip else y16.alias()
+
+    @staticmethod
+    def backward(ctx, *grads):
+        N, Cc, D, H, W, compute = ctx.info
+        g_skip, g_pool = (grads if len(grads) == 2 else (None, grads[0]))
+        if g_pool is None:
+            return g_skip, None, None, None
+        g_pool, pbs = _c8t(g_pool)
+        sbs = 0
+        if g_skip is not None:
+            g_skip, sbs = _c8t(g_skip)
+        dx16 = torch.empty((N, (Cc + 7) // 8, D * H * W, 8), dtype=_DT16[compute], device=g_pool.device)
+        check(_lib.lib().m355_avgpool3d_2x_bwd_h16(_p(g_pool), _p(g_skip), _p(dx16), N, Cc, D, H, W, pbs, sbs, 0, compute,
+                                                   _stream()), "avgpool3d_2x_bwd_h16")
+        return dx16, None, None, None
+
+
+class _ConvTC8Fn(torch.autograd.Function):
+    """nn.ConvTranspose3d(kernel_size=2, stride=2) of the c8 training flow: c8 -> c8 straight into its concat slot;
+    backward on the 16-bit MFMA from c8 operands where the library has the kernels (Cout <= 128), else through the
+    fp32 kernels (the deepest levels: a few MB)."""
+
+    @staticmethod
+    def forward(ctx, x_t, weight, bias, x: Act16, y16: Act16):
+        L = _lib.lib()
+        _require(weight, bias)
+        weight = weight.contiguous()
+        N, Cin, D, H, W = x.shape
+        Cout = weight.shape[1]
+        if y16.shape != (N, Cout, 2 * D, 2 * H, 2 * W):
+            raise _lib.M355Error(f"c8 slot shape {y16.shape} != op output shape {(N, Cout, 2 * D, 2 * H, 2 * W)}")
+        d = _conv_desc(N, Cin, Cout, D, H, W, 2, 2, 0, 0, 0)
+        check(L.m355_conv_transpose3d_fwd_h16(C.byref(d), x.ptr(), x.batch_stride(), _p(weight), _p(bias), y16.ptr(),
+                                              y16.batch_stride(), x.compute, _stream()), "conv_transpose3d_fwd_h16")
+        ctx.desc, ctx.compute, ctx.has_bias = d, x.compute, bias is not None
+        ctx.save_for_backward(x.alias(), weight)
+        return y16.alias()
+
+    @staticmethod
+    def backward(ctx, dy16):
+        L = _lib.lib()
+        xa, weight = ctx.saved_tensors
+        d, compute = ctx.desc, ctx.compute
+        scale = grad_scale(compute)
+        dy16, dybs = _c8t(dy16)
+        xa, xbs = _c8t(xa)
+        S = d.D * d.H * d.W
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx16 = dw = db = None
+        if L.m355_conv_transpose3d_h16_bwd_supported(C.byref(d)):
+            if need_x:
+                dx16 = torch.empty((d.N, (d.Cin + 7) // 8, S, 8), dtype=_DT16[compute], device=weight.device)
+                check(L.m355_conv_transpose3d_bwd_data_h16(C.byref(d), _p(dy16), dybs, _p(weight), _p(dx16), 0, compute,
+                                                           _stream()), "conv_transpose3d_bwd_data_h16")
+            if need_w:
+                dw = torch.empty_like(weight)
+                db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+                ws = _workspace(L.m355_conv_transpose3d_h16_bwd_workspace(C.byref(d)), weight.device)
+                check(L.m355_conv_transpose3d_bwd_weight_h16(C.byref(d), _p(xa), xbs, _p(dy16), dybs, _p(dw), _p(db),
+                                                             1.0 / scale, compute, _p(ws), ws.numel(), _stream()),
+                      "conv_transpose3d_bwd_weight_h16")
+        else:
+            dy = _unpack_scaled(dy16, d.Cout, (2 * d.D, 2 * d.H, 2 * d.W), compute, 1.0 / scale)
+            ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(d)), weight.device)
+            if need_x:
+                dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=torch.float32, device=weight.device)
+                check(L.m355_conv_transpose3d_bwd_data(C.byref(d), _p(dy), _p(weight), _p(dx), _p(ws), ws.numel(), _stream()),
+                      "conv_transpose3d_bwd_data")
+                dx16 = _pack_scaled(dx, compute, scale)
+            if need_w:
+                x = _unpack_scaled(xa, d.Cin, (d.D, d.H, d.W), compute, 1.0)
+                dw = torch.empty_like(weight)
+                db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
+                check(L.m355_conv_transpose3d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(),
+                                                         _stream()), "conv_transpose3d_bwd_weight")
+        return dx16, dw, db, None, None
+
+
+def _act16_tracks(*xs):
+    """autograd is recording and one of these c8 activations carries a gradient"""
+    return torch.is_grad_enabled() and any(isinstance(x, Act16) and x.requires_grad for x in xs)
 
 
 # ------------------------------------------------------------------ conv3d
@@ -604,14 +1076,21 @@ def conv3d(x, weight, bias=None, add=None, stride=1, padding=1, out: Optional[Ou
     k = weight.shape[2]
     if not (weight.shape[2] == weight.shape[3] == weight.shape[4]):
         raise NotImplementedError("only cubic kernels are supported")
+    c8_parts = None
     if isinstance(x, Concat) and isinstance(x.buf, Act16):
-        x = x.buf
+        c8_parts, x = x.parts, x.buf
     if out is not None and out.buf16 is not None:   # c8 flow: the destination slot only exists in c8
         return pack_act16(conv3d(x, weight, bias, add, stride, padding, None, stats), out.buf16.compute, out.act16())
     if isinstance(x, Act16):
         if k == 3 and stride == 1 and padding == 1:
+            if torch.is_grad_enabled() and (weight.requires_grad or _act16_tracks(x, *(c8_parts or ()))):
+                # c8 training flow (a conv with a fused fp32 `add` keeps its result in fp32)
+                return _conv3d_c8_train(x, c8_parts, weight, bias, as_f32(add) if add is not None else None, stats,
+                                        c8_out and not softmax and add is None, softmax)
             return _conv3d_act16(x, weight, bias, as_f32(add) if add is not None else None, stats, c8_out and not softmax,
                                  softmax)
+        if c8_parts is not None and _act16_tracks(*c8_parts):
+            raise NotImplementedError("c8 training flow: only 3x3x3 / stride 1 / padding 1 convolutions read a concat buffer")
         x = x.to_f32()
     if isinstance(x, Concat):
         meta = _ConvMeta(k, stride, padding, catbuf=x.buf, out=out, stats=stats, softmax=softmax)
@@ -678,6 +1157,13 @@ def conv_transpose3d(x, weight, bias=None, stride=2, padding=0, output_padding=0
     k = weight.shape[2]
     if isinstance(x, Act16):
         if k == 2 and stride == 2 and padding == 0 and output_padding == 0:   # c8 -> c8 kernel
+            if torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
+                y16 = out.act16() if (out is not None and out.buf16 is not None) else None
+                if y16 is None:
+                    N, Cin, D, H, W = x.shape
+                    y16 = Act16.empty(N, weight.shape[1], (2 * D, 2 * H, 2 * W), x.compute, x.device)
+                t = _ConvTC8Fn.apply(x.t, weight, bias, x, y16)
+                return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, t)
             _require(weight, bias)
             N, Cin, D, H, W = x.shape
             Cout = weight.shape[1]
@@ -718,9 +1204,6 @@ class NormCfg:
 # around the forward), BatchNorm layers in training mode take their statistics over the batch of ALL ranks -- the
 # reference is one process normalising the whole batch (segmentation_trainer.py:189-262).  Two small all-reduces per
 # layer and step: the per-channel sums forward, the per-channel gradient means backward.
-_bn_sync_group = None
-
-
 class batch_norm_sync:
     """Context manager: BatchNorm training statistics over all ranks of `group` (None = off)."""
 
@@ -963,10 +1446,14 @@ def norm_act_pool(x, gamma, beta, cfg: NormCfg):
     return _NormActPoolFn.apply(x, gamma, beta, cfg)
 
 
-def norm_act(x, gamma, beta, cfg: NormCfg, add=None):
+def norm_act(x, gamma, beta, cfg: NormCfg, add=None, pool=False):
     """normalization_class + activation_class of Block3d (components.py:52-55), optionally
     fused with the residual sum (components.py:67-68): act(norm(x)) + add.  With `cfg.c8` set (16-bit
     precision mode under no_grad) the result is an `Act16` and nothing is written in fp32."""
+    if cfg.c8 and isinstance(x, Act16) and torch.is_grad_enabled():
+        return _norm_act_c8_train(x, gamma, beta, add, cfg, pool=pool)      # c8 training flow
+    if pool:
+        raise _lib.M355Error("norm_act(pool=True) is the c8 training flow's fused pool; use norm_act_pool for fp32 tensors")
     if cfg.c8 and not torch.is_grad_enabled():
         return _norm_act_c8(x, gamma, beta, add, cfg)
     x = as_f32(x)
@@ -1038,6 +1525,12 @@ class _PoolSkipFn(torch.autograd.Function):
 
 def avgpool3d_2x_with_skip(x):
     """-> (x as it continues into the skip connection, AvgPool3d(2, 2)(x)); see _PoolSkipFn."""
+    if isinstance(x, Act16):
+        N, Cc, D, H, W = x.shape
+        y16 = Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        skip_t, pooled_t = _PoolC8Fn.apply(x.t, x, y16, True)
+        return (Act16(x.data, x.C, x.spatial, x.compute, x.cb0, skip_t),
+                Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, pooled_t))
     return _PoolSkipFn.apply(x)
 
 
@@ -1048,6 +1541,8 @@ def avgpool3d_2x(x, out: Optional[OutSlot] = None):
         y16 = out.act16() if out is not None else None
         if y16 is None:
             y16 = Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        if _act16_tracks(x):
+            return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, _PoolC8Fn.apply(x.t, x, y16, False))
         check(_lib.lib().m355_avgpool3d_2x_fwd_h16(x.ptr(), y16.ptr(), N, Cc, D, H, W, x.batch_stride(),
                                                    y16.batch_stride(), x.compute, _stream()), "avgpool3d_2x_fwd_h16")
         return y16

@@ -845,16 +845,50 @@ def test_c8_inference_flow_matches_fp32_golden_and_autograd_path(golden, mode, n
         with torch.no_grad():
             assert ops.h16_flow() != 0
             p_flow = model(x)
-        assert ops.h16_flow() == 0
+        assert ops.h16_flow() != 0           # autograd on: the c8-only TRAINING flow (round 3), same forward kernels
         p_grad = model(x).detach()
+        try:                                 # ... and the round-2 twin flow (fp32 tensors beside the c8 operands)
+            ops.H16_TRAIN_C8ONLY = False
+            assert ops.h16_flow() == 0
+            p_twin = model(x).detach()
+        finally:
+            ops.H16_TRAIN_C8ONLY = True
     with torch.no_grad():
         p32 = model(x)                       # exact fp32 mode (itself pinned to the golden by test_model_gpu.py)
     if name == "unet_gn_convt.npz":          # BatchNorm goldens were taken after a training step moved the statistics
         assert (p32.cpu() - g.t("m.probs_eval")).abs().max().item() <= 1e-4
+        assert torch.equal(p_flow, p_grad), "the c8 training flow's forward is the no-grad c8 flow, bit for bit"
     assert (p_flow - p32).abs().max().item() <= 2 * tol
     assert (p_flow - p_grad).abs().max().item() <= tol
+    assert (p_flow - p_twin).abs().max().item() <= tol
     assert (p_flow.sum(dim=1) - 1).abs().max().item() <= 1e-5
-    assert (p_flow - p_grad).abs().max().item() > 0 or name != "unet_gn_convt.npz"   # really a different data path
+    assert (p_flow - p_twin).abs().max().item() > 0 or name != "unet_gn_convt.npz"   # really a different data path
+
+
+def _grads_as_accurate_as_the_rounded_oracle(g, model, mode, x, y, all_cos_min, cos_min):
+    """The composed c8 training flow on the small north-star golden: its parameter gradients against the REFERENCE's
+    fp32 gradients (the golden) must be as accurate as those of the rounding-matched oracle (oracle.torch_ref with
+    `rounding=mode`: same operand / activation / gradient roundings, fp32 everything else): per parameter the relative L2
+    distance to the golden at most 3x the oracle's (+ 0.03), plus bounds on direction and size.  (See
+    tests/test_fullsize_gpu.py::_composed_16bit_training_check for why a deep network cannot match the rounded oracle
+    element by element.)"""
+    from oracle import torch_ref as R
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g.state_dict("m.sd.").items()}
+    spec = R.UNetSpec(4, 3, [8, 16, 32], 3, norm="group", groups=8, up="convT", rounding=mode)
+    ld = R.hybrid_logistic_dice_loss(R.unet_forward(sd, spec, x, training=True), y)
+    ld["loss"].backward()
+    dot = na = nb = 0.0
+    for k, v in model.named_parameters():
+        ref = g.t(f"m.grad.{k}").double().flatten()
+        got, orc = v.grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        assert torch.isfinite(got).all()
+        cos = float(got @ ref / (got.norm() * ref.norm() + 1e-30))
+        rel, rel_o = float((got - ref).norm() / ref.norm()), float((orc - ref).norm() / ref.norm())
+        assert cos >= cos_min, (k, cos)
+        assert abs(float(got.norm() / ref.norm()) - 1.0) <= 0.12, (k, float(got.norm() / ref.norm()))
+        assert rel <= 3.0 * rel_o + 0.03, (k, rel, rel_o)
+        dot, na, nb = dot + float(got @ ref), na + float(got @ got), nb + float(ref @ ref)
+    assert dot / (na * nb) ** 0.5 >= all_cos_min, dot / (na * nb) ** 0.5
 
 
 def test_fp16_precision_mode_end_to_end(golden):
@@ -879,12 +913,7 @@ def test_fp16_precision_mode_end_to_end(golden):
     err = (p.detach().cpu() - g.t("m.probs_train")).abs().max().item()
     assert 1e-7 < err <= 5e-3, err
     assert abs(ld["dice_loss"].item() - float(g["m.dice_loss"])) <= 2e-4
-    for k, v in model.named_parameters():
-        ref = g.t(f"m.grad.{k}").double().flatten()
-        got = v.grad.cpu().double().flatten()
-        assert torch.isfinite(got).all()
-        cos = torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30)
-        assert cos > 0.98, (k, cos.item())   # bf16 mode: 0.95
+    _grads_as_accurate_as_the_rounded_oracle(g, model, "fp16", x.cpu(), y.cpu(), all_cos_min=0.99999, cos_min=0.99)
 
 
 def test_c8_twin_of_the_training_flow_is_voided_by_in_place_modification():
@@ -930,12 +959,7 @@ def test_bf16_precision_mode_end_to_end(golden):
     err = (p.detach().cpu() - g.t("m.probs_train")).abs().max().item()
     assert 1e-6 < err <= 2e-2, err                     # really a different arithmetic, within the stated tolerance
     assert abs(ld["dice_loss"].item() - float(g["m.dice_loss"])) <= 1e-3
-    for k, v in model.named_parameters():
-        ref = g.t(f"m.grad.{k}").double().flatten()
-        got = v.grad.cpu().double().flatten()
-        assert torch.isfinite(got).all()
-        cos = torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30)
-        assert cos > 0.95, (k, cos.item())                # bf16 operand noise, same direction
+    _grads_as_accurate_as_the_rounded_oracle(g, model, "bf16", x.cpu(), y.cpu(), all_cos_min=0.9995, cos_min=0.95)
     with pytest.raises(ValueError):
         sp.set_precision("fp8")
 
