@@ -35,6 +35,7 @@ static Tuning read_tuning() {
   t.conv_cube = env_int("M355_CONV_CUBE", 3);
   t.h16_order = env_int("M355_H16_ORDER", 3);
   t.fuse_softmax = env_int("M355_FUSE_SOFTMAX", 1);
+  t.convt_wgs = env_int("M355_CONVT_WGS", 0);
   t.h16_stagger = env_int("M355_H16_STAGGER", 2);
   return t;
 }

@@ -36,6 +36,7 @@ static inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 constexpr int NORM_CHUNK = 16384;   // elements (c8: voxels of one channel block) per block in the normalisation reduction passes
+constexpr int NORM_CHUNK_C8 = 4096; // voxels per block of the c8 backward's first pass (8 channels per thread: smaller chunks fill the chip)
 constexpr int DBIAS_CHUNK = 8192;   // voxels per partial sum of the bias gradient (launch_dbias; workspace = Cout * chunks doubles)
 
 // wave-wide sum (64 lanes), result valid in every lane
@@ -71,6 +72,7 @@ struct Tuning {
   int no_small = 0, smallcout_valu = 1, bww_nsplit = 0, bww_gen = 2, bww_queue = 1, h16_persistent = 1, tile16 = 1, convt_h16 = 1, h16_w8 = 1, h16_oneshot = 1, h16_xcd = 1;
   int conv_cube = 3, h16_order = 3;   // item order of the conv kernels: bit 0 = (y, z) tiles in 4x4 cubes, bit 1 = channel tile fastest
   int fuse_softmax = 1;
+  int convt_wgs = 0;     // c8 conv-transpose kernels: workgroups per CU of the persistent grids (0 = built-in)
   int h16_stagger = 2;   // 16-bit conv kernel: start offset of the odd workgroup of a CU, in units of 1024 cycles
 };
 const Tuning& tuning();

@@ -291,17 +291,36 @@ __global__ __launch_bounds__(256) void convt_k2s2_fwd_h16_kernel(
   const int ks_n = (Cin + 15) / 16, CBin = (Cin + 7) / 8;
   const int mtiles = 2 * ((Cout + 7) / 8);
   const int mt0 = blockIdx.y * mt_per_wg, nmt = min(mtiles, mt0 + mt_per_wg) - mt0;
-  for (int e = tid; e < nmt * ks_n * 64; e += 256) {
-    const int L = e & 63, s = (e >> 6) % ks_n, mt = mt0 + (e >> 6) / ks_n;
-    const int cb = mt >> 1, a = mt & 1, m = L & 31;
-    const int o = cb * 8 + (m & 3) + 4 * ((m >> 3) & 1), c = (m >> 2) & 1, b = m >> 4;
-    hx8 v;
+  {
+    // staging in the MEMORY order of w ([Cin][Cout][a][b][c]: (o, b, c) runs of one (k, a) are 16-byte pieces 32 bytes
+    // apart) with 2-byte scatter writes into fragment order -- every element of the fragment space is written exactly
+    // once, zeros past Cin / Cout.  (Gathering each fragment with 8 loads Cout * 32 bytes apart made this staging,
+    // repeated by every workgroup, longer than the voxel tiles it serves.)
+    HT* af16 = reinterpret_cast<HT*>(lds_raw);
+    const int kpad = ks_n * 16;
+    const int total4 = nmt * kpad * 8;                     // float4 pieces: the (b, c) quad of one (k, o, a)
+    for (int e0 = tid; e0 < total4; e0 += 256 * 8) {       // 8 x 16-byte loads in flight per thread
+      float4 v[8];
+      int dst[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = s * 16 + (L >> 5) * 8 + j;
-      v[j] = (k < Cin && o < Cout) ? (HT)w[(((int64_t)k * Cout + o) * 2 + a) * 4 + b * 2 + c] : (HT)0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        const int o_in = e & 7, k = (e >> 3) % kpad, tl = (e >> 3) / kpad;
+        const int mt = mt0 + tl, cb = mt >> 1, a = mt & 1, o = cb * 8 + o_in;
+        const bool ok = e < total4 && k < Cin && o < Cout;
+        v[u] = ok ? *reinterpret_cast<const float4*>(w + (((int64_t)k * Cout + o) * 2 + a) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // row m = (o_in & 3) + 4 c + 8 (o_in >> 2) + 16 b of the m-tile, element k & 7 of lane half (k >> 3) & 1
+        dst[u] = e < total4 ? ((tl * ks_n + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (o_in & 3) + 8 * (o_in >> 2)) * 8 + (k & 7) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) {
+          af16[dst[u]] = (HT)v[u].x;               // (b, c) = (0, 0)
+          af16[dst[u] + 4 * 8] = (HT)v[u].y;       // c = 1: row + 4
+          af16[dst[u] + 16 * 8] = (HT)v[u].z;      // b = 1: row + 16
+          af16[dst[u] + 20 * 8] = (HT)v[u].w;
+        }
     }
-    afrag[e] = v;
   }
   __syncthreads();
   const int n = blockIdx.z;
@@ -674,18 +693,35 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_h16_kernel(
   const int npair = (CBout + 1) / 2, nks = 8 * npair;        // k-step s = pair * 8 + t
   const int mtiles = (Cin + 31) / 32;
   const int mt0 = blockIdx.y * mt_per_wg, nmt = min(mtiles, mt0 + mt_per_wg) - mt0;
-  for (int e = tid; e < nmt * nks * 64; e += 256) {
-    const int L = e & 63, s = (e >> 6) % nks, mt = mt0 + (e >> 6) / nks;
-    const int m = L & 31, i = m >> 3, hh = (m >> 2) & 1, j4 = m & 3;
-    const int c = mt * 32 + 8 * (2 * (i >> 1) + hh) + 4 * (i & 1) + j4;
-    const int t = s & 7, ob = 2 * (s >> 3) + (L >> 5);
-    hx8 v;
+  {
+    // staging in the memory order of w ([Cin][Cout][t]: the (o, t) plane of one input channel is contiguous) with
+    // 2-byte scatter writes into fragment order; every element written once, zeros past Cin / Cout
+    HT* af16 = reinterpret_cast<HT*>(lds_raw);
+    const int opad = npair * 16;
+    const int total4 = nmt * 32 * opad * 2;                // float4 pieces: t = 0..3 / 4..7 of one (c, o)
+    for (int e0 = tid; e0 < total4; e0 += 256 * 8) {       // 8 x 16-byte loads in flight per thread
+      float4 v[8];
+      int dst[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int o = ob * 8 + j;
-      v[j] = (c < Cin && o < Cout) ? (HT)w[((int64_t)c * Cout + o) * 8 + t] : (HT)0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        const int th = e & 1, o = (e >> 1) % opad;
+        const int m = ((e >> 1) / opad) & 31, q = ((e >> 1) / opad) >> 5;
+        const int i = m >> 3, hh = (m >> 2) & 1, j4 = m & 3;
+        const int c = (mt0 + q) * 32 + 8 * (2 * (i >> 1) + hh) + 4 * (i & 1) + j4;
+        const bool ok = e < total4 && c < Cin && o < Cout;
+        v[u] = ok ? *reinterpret_cast<const float4*>(w + ((int64_t)c * Cout + o) * 8 + 4 * th) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[u] = e < total4 ? ((q * nks + (o >> 4) * 8 + 4 * th) * 64 + ((o >> 3) & 1) * 32 + m) * 8 + (o & 7) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) {                       // k-step = pair * 8 + t: consecutive t are 64 fragments apart
+          af16[dst[u]] = (HT)v[u].x;
+          af16[dst[u] + 64 * 8] = (HT)v[u].y;
+          af16[dst[u] + 2 * 64 * 8] = (HT)v[u].z;
+          af16[dst[u] + 3 * 64 * 8] = (HT)v[u].w;
+        }
     }
-    afrag[e] = v;
   }
   __syncthreads();
   const int n = blockIdx.z;
@@ -705,7 +741,8 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_h16_kernel(
     for (int q = 0; q < MTW; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    hx8 bq[2][8];
+    // two statically named register sets in ping-pong (an array indexed by `pair & 1` lives in scratch memory)
+    hx8 b0[8], b1[8];
     auto fetch = [&](int pair, hx8 (&dst)[8]) {
       const int ob = 2 * pair + half;
       const bool ok = vok && ob < CBout;
@@ -714,15 +751,21 @@ __global__ __launch_bounds__(256) void convt_k2s2_bwd_data_h16_kernel(
       for (int t = 0; t < 8; ++t)
         dst[t] = ok ? src[((int64_t)(t >> 2) * OH + ((t >> 1) & 1)) * OW + (t & 1)] : zero;
     };
-    fetch(0, bq[0]);
-    for (int pair = 0; pair < npair; ++pair) {
-      if (pair + 1 < npair) fetch(pair + 1, bq[(pair + 1) & 1]);
+    auto multiply = [&](int pair, const hx8 (&b)[8]) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const hx8 b = bq[pair & 1][t];
 #pragma unroll
         for (int q = 0; q < MTW; ++q)
-          if (q < nmt) acc[q] = H16<HT>::mfma(afrag[((int64_t)q * nks + pair * 8 + t) * 64 + lane], b, acc[q]);
+          if (q < nmt) acc[q] = H16<HT>::mfma(afrag[((int64_t)q * nks + pair * 8 + t) * 64 + lane], b[t], acc[q]);
+      }
+    };
+    fetch(0, b0);
+    for (int pair = 0; pair < npair; pair += 2) {
+      if (pair + 1 < npair) fetch(pair + 1, b1);
+      multiply(pair, b0);
+      if (pair + 1 < npair) {
+        if (pair + 2 < npair) fetch(pair + 2, b0);
+        multiply(pair + 1, b1);
       }
     }
     if (vok) {
@@ -797,7 +840,10 @@ __global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
 
-  for (int tile = split; tile < ntiles; tile += nsplit) {
+  // the next tile travels global -> registers while the current one is multiplied out of LDS
+  constexpr int XPER = XI / 256, DPER = DI / 256;   // CT and 8 items per thread
+  uint4 xr[XPER], dr[DPER];
+  auto fetch = [&](int tile, bool live) {
     int t = tile;
     const int n = t / tiles_per_n;
     t -= n * tiles_per_n;
@@ -806,28 +852,45 @@ __global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
     const int tyt = t % ty_tiles, z0 = t / ty_tiles;
     const int y0 = tyt * TY, x0 = txt * TX;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(x16 + (int64_t)n * xbs16 + (int64_t)cb0 * S * 8), 0, nbx * S * 16, 0x00020000);
+        (void*)(x16 + (int64_t)n * xbs16 + (int64_t)cb0 * S * 8), 0, live ? nbx * S * 16 : 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(dy16 + (int64_t)n * ybs16 + (int64_t)(4 * otile) * OS * 8), 0, nbd * OS * 16, 0x00020000);
-    __syncthreads();   // the previous tile's fragments have been read
-    for (int e = tid; e < XI; e += 256) {        // item e = (voxel e / (4 CT), channel block e % (4 CT))
+        (void*)(dy16 + (int64_t)n * ybs16 + (int64_t)(4 * otile) * OS * 8), 0, live ? nbd * OS * 16 : 0, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {           // item e = (voxel e / (4 CT), channel block e % (4 CT))
+      const int e = tid + 256 * k;
       const int vx = e / (CT * 4), cbl = e - vx * (CT * 4);
       const int yy = vx / TX, xx = vx - yy * TX;
       const bool ok = y0 + yy < H && x0 + xx < W && cbl < nbx;
-      xs[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+      xr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
           rx, ok ? (unsigned)(cbl * S + (z0 * H + y0 + yy) * W + x0 + xx) * 16u : OOB, 0, 0));
     }
-    for (int e = tid; e < DI; e += 256) {        // dy tile voxel-major: [az][oy][ox][4 blocks], oy < 2 TY, ox < 2 TX
+#pragma unroll
+    for (int k = 0; k < DPER; ++k) {           // dy tile voxel-major: [az][oy][ox][4 blocks], oy < 2 TY, ox < 2 TX
+      const int e = tid + 256 * k;
       const int vo = e >> 2, cbl = e & 3;
       const int ox = vo % (2 * TX), oy = (vo / (2 * TX)) % (2 * TY), az = vo / (4 * TX * TY);
       const int gy = 2 * y0 + oy, gx = 2 * x0 + ox;
       const bool ok = gy < OH && gx < OW && cbl < nbd;
-      ds[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+      dr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
           rd, ok ? (unsigned)(cbl * OS + ((2 * z0 + az) * OH + gy) * OW + gx) * 16u : OOB, 0, 0));
     }
-    __syncthreads();
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xs) + xl;
-    const unsigned char* db = reinterpret_cast<const unsigned char*>(ds) + dl;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) xs[tid + 256 * k] = xr[k];
+#pragma unroll
+    for (int k = 0; k < DPER; ++k) ds[tid + 256 * k] = dr[k];
+  };
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(xs) + xl;
+  const unsigned char* db = reinterpret_cast<const unsigned char*>(ds) + dl;
+  if (split < ntiles) {
+    fetch(split, true);
+    commit();
+  }
+  __syncthreads();
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    fetch(more ? tile + nsplit : tile, more);   // (zero-sized descriptors after the last tile)
 #pragma unroll
     for (int yy = 0; yy < TY; ++yy)
 #pragma unroll
@@ -844,6 +907,9 @@ __global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
           for (int q = 0; q < CT; ++q) acc[c][q] = H16<HT>::mfma(af[q], bf, acc[c][q]);
         }
       }
+    __syncthreads();   // every wave is done reading this tile
+    if (more) commit();
+    __syncthreads();
   }
   // partial dW -> slab[split][t][c][o] (lane = output channel: 32 consecutive floats per store)
   float* sl = slab + (int64_t)split * 8 * Cin * Cout;
@@ -863,16 +929,31 @@ __global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
   }
 }
 
-// dW[c][o][t] = unscale * sum over splits of slab[split][t][c][o] (fixed order)
+// dW[c][o][t] = unscale * sum over splits of slab[split][t][c][o], in a fixed order: a block owns 64 consecutive slab
+// positions; its 4 waves take the splits s = wave, wave + 4, ... (coalesced 256-byte reads), then the four partial
+// sums are added in wave order
 __global__ __launch_bounds__(256) void convt_slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                   int Cin, int Cout, int nsplit, float unscale) {
-  const int64_t total = (int64_t)Cin * Cout * 8, plane = total;
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
-    const int t = (int)(i & 7);
-    const int64_t co = i >> 3;                 // c * Cout + o
-    double v = 0.0;
-    for (int s = 0; s < nsplit; ++s) v += (double)slab[(int64_t)s * plane + (int64_t)t * Cin * Cout + co];
-    dw[i] = (float)(v * (double)unscale);
+  __shared__ double part[4][64];
+  const int64_t plane = (int64_t)Cin * Cout * 8, cc = (int64_t)Cin * Cout;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t j = blockIdx.x * 64ll + lane;              // slab position t * Cin * Cout + (c * Cout + o)
+  double v = 0.0;
+  if (j < plane) {
+    int s = wv;
+    for (; s + 12 < nsplit; s += 16) {                     // four loads in flight
+      const float a0 = slab[(int64_t)s * plane + j], a1 = slab[(int64_t)(s + 4) * plane + j];
+      const float a2 = slab[(int64_t)(s + 8) * plane + j], a3 = slab[(int64_t)(s + 12) * plane + j];
+      v += (double)a0; v += (double)a1; v += (double)a2; v += (double)a3;
+    }
+    for (; s < nsplit; s += 4) v += (double)slab[(int64_t)s * plane + j];
+  }
+  part[wv][lane] = v;
+  __syncthreads();
+  if (wv == 0 && j < plane) {
+    const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    const int t = (int)(j / cc);
+    dw[(j - (int64_t)t * cc) * 8 + t] = (float)(tot * (double)unscale);
   }
 }
 
@@ -1288,7 +1369,9 @@ static int convt_c8_ct(const m355_conv3d_desc* d) { const int ct = (int)ceil_div
 static int convt_c8_nsplit(const m355_conv3d_desc* d) {
   const int64_t ntiles = (int64_t)d->N * d->D * ceil_div(d->H, 2) * ceil_div(d->W, 32);
   const int64_t groups = ceil_div(d->Cout, 32) * ceil_div(ceil_div(d->Cin, 32), convt_c8_ct(d));
-  return (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 2 * (int64_t)num_cus() / groups));
+  // (every split writes a slab of 8 * Cin * Cout floats that the reduction reads again: one workgroup per CU)
+  const int64_t wgs = (int64_t)(tuning().convt_wgs ? tuning().convt_wgs : 1) * num_cus();
+  return (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, wgs / groups));
 }
 
 extern "C" int32_t m355_conv_transpose3d_h16_bwd_supported(const m355_conv3d_desc* d) {
@@ -1323,7 +1406,10 @@ extern "C" int m355_conv_transpose3d_bwd_data_h16(const m355_conv3d_desc* d, con
   if (mt_per_wg == 3) mt_per_wg = 2;
   const int groups = (int)ceil_div(mtiles, mt_per_wg);
   const int64_t vox_tiles = ceil_div(S, 128);
-  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(vox_tiles, ceil_div(4 * (int64_t)num_cus(), (int64_t)groups * d->N)));
+  // one residency of workgroups (2 per CU), each walking its share of the voxel tiles: the weights are staged once
+  const int64_t wgs = (int64_t)(tuning().convt_wgs ? tuning().convt_wgs : 2) * num_cus();
+  // (weights are staged per workgroup: at least four voxel tiles each on the small levels)
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(vox_tiles, 4), ceil_div(wgs, (int64_t)groups * d->N)));
   dim3 grid((unsigned)gx, (unsigned)groups, (unsigned)d->N);
   const size_t lds = (size_t)mt_per_wg * nks * 1024;
 #define M355_CTBD(HT, MTW)                                                                                            \
@@ -1368,8 +1454,8 @@ extern "C" int m355_conv_transpose3d_bwd_weight_h16(const m355_conv3d_desc* d, c
 #undef M355_CTBW_T
 #undef M355_CTBW
   const int64_t total = (int64_t)d->Cin * d->Cout * 8;
-  hipLaunchKernelGGL(convt_slab_reduce_t_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1024)), dim3(256), 0,
-                     st, slab, dw, d->Cin, d->Cout, nsplit, grad_unscale);
+  hipLaunchKernelGGL(convt_slab_reduce_t_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, st, slab, dw, d->Cin,
+                     d->Cout, nsplit, grad_unscale);
   if (dbias) {
     const size_t slab_b = (size_t)round_up((int64_t)nsplit * 8 * d->Cin * d->Cout * 4, 256);
     if (int rc = launch_dbias_c8(dy16, ybs, dbias, d->N, d->Cout, S * 8, compute, grad_unscale, (char*)workspace + slab_b, st))

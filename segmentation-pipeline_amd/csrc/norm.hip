@@ -484,7 +484,7 @@ extern "C" size_t m355_norm_workspace(const m355_norm_desc* d) {
   if (!d || d->N <= 0 || d->C <= 0 || d->S <= 0) return 0;
   const NormGeom g = geom(d);
   const size_t fwd = (size_t)g.nstats * g.nblk * 2 * sizeof(double);
-  const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK);
+  const int nblk_c = (int)ceil_div(d->S, NORM_CHUNK_C8);   // (the c8 backward's chunks: the larger of the two layouts)
   const size_t bwd = (size_t)round_up((int64_t)d->N * d->C * nblk_c * 2 * sizeof(double), 256) +
                      (size_t)round_up((int64_t)d->N * d->C * 2 * sizeof(double), 256) +
                      (size_t)g.nstats * 2 * sizeof(float) + 256;
@@ -617,7 +617,7 @@ static int norm_act_bwd_reduce_impl(const m355_norm_desc* d, const float* x, con
 // the finalize stage for the c8 backward (train16.hip), whose first pass writes the same partial layout
 int m355::launch_norm_bwd_reduce(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* stat_m, int N,
                            int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st) {
-  const int nblk_c = (int)ceil_div(S, NORM_CHUNK);
+  const int nblk_c = (int)ceil_div(S, NORM_CHUNK_C8);
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
   const int64_t count = groups == 0 ? (int64_t)N * S : (int64_t)(C / groups) * S;
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)std::max<int64_t>(nstats, C)), dim3(64), 0, st, partial, gamma,

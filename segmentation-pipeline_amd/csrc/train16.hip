@@ -74,18 +74,37 @@ __global__ __launch_bounds__(256) void unpack_act16_scaled_kernel(const HT* __re
 }
 
 // ---------------------------------------------------------------- incoming gradient of a (skip, pooled) pair
-// g[v] = dy16[v] (when present) + 0.125 * dpool16[v / 2 per axis]: autograd of y -> (y, AvgPool3d(2, 2)(y))
+// g[v] = dy16[v] (when present) + 0.125 * dpool16[v / 2 per axis]: autograd of y -> (y, AvgPool3d(2, 2)(y)).
+// A thread walks voxels v0, v0 + step, v0 + 2 step, ...: the (z, y, x) of the pooled source advance incrementally
+// (one division pair at the start instead of two per item -- the pass is HBM-bound only if the ALU keeps up).
 template <typename HT, bool POOL>
 struct GradSrc {
   using hx8 = typename H16<HT>::x8;
   const hx8* dy;   // may be null when POOL
   const hx8* dp;   // pooled gradient (POOL only)
   int H, W, OH, OW;
+  int x, y, z, dx, dyq;   // position of the current voxel; step = dyq rows + dx columns
+  __device__ __forceinline__ void start(int64_t v, int64_t step) {
+    if constexpr (POOL) {
+      x = (int)(v % W);
+      const int64_t r = v / W;
+      y = (int)(r % H);
+      z = (int)(r / H);
+      dx = (int)(step % W);
+      dyq = (int)(step / W);
+    }
+  }
+  __device__ __forceinline__ void advance() {
+    if constexpr (POOL) {
+      x += dx;
+      y += dyq;
+      if (x >= W) { x -= W; ++y; }
+      while (y >= H) { y -= H; ++z; }
+    }
+  }
+  // the gradient at voxel v == the current position (clamped loads past the end are the caller's business)
   __device__ __forceinline__ void load(int64_t v, float (&g)[8]) const {
     if constexpr (POOL) {
-      const int x = (int)(v % W);
-      const int64_t r = v / W;
-      const int y = (int)(r % H), z = (int)(r / H);
       const hx8 p = dp[((int64_t)(z >> 1) * OH + (y >> 1)) * OW + (x >> 1)];
       if (dy) {
         const hx8 d = dy[v];
@@ -132,23 +151,39 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_c8_kernel(
   src.dy = dy16 ? reinterpret_cast<const hx8*>(dy16 + (int64_t)n * ybs16) + (int64_t)cb * S : nullptr;
   src.H = H; src.W = W; src.OH = H >> 1; src.OW = W >> 1;
   src.dp = POOL ? reinterpret_cast<const hx8*>(dp16 + (int64_t)n * pbs16) + (int64_t)cb * (S >> 3) : nullptr;
-  const int64_t begin = (int64_t)b * NORM_CHUNK, end = min(S, begin + NORM_CHUNK);
+  const int64_t begin = (int64_t)b * NORM_CHUNK_C8, end = min(S, begin + NORM_CHUNK_C8);
   float a1[8], a2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
-  for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
-    const hx8 xv = xp[i];
-    float g[8];
-    src.load(i, g);
+  constexpr int U = 4;     // items in flight per thread (2 U 16-byte loads): the chunk is 16 items per thread
+  src.start(min(begin + threadIdx.x, S - 1), 256);
+  for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 256 * U) {
+    hx8 xv[U];
+    float g[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xf = (float)xv[j];
-      const float xh = (xf - m[j]) * r[j];
-      const float pre = fmaf(xf, sc[j], sh[j]);
-      const float gg = g[j] * act16_grad_t(pre, act, slope);
-      a1[j] += gg;
-      a2[j] = fmaf(gg, xh, a2[j]);
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + 256 * u;
+      const bool ok = i < end;
+      if (ok) {
+        xv[u] = xp[i];
+        src.load(i, g[u]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[u][j] = (HT)0.f; g[u][j] = 0.f; }
+      }
+      src.advance();
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xf = (float)xv[u][j];
+        const float xh = (xf - m[j]) * r[j];
+        const float pre = fmaf(xf, sc[j], sh[j]);
+        const float gg = g[u][j] * act16_grad_t(pre, act, slope);
+        a1[j] += gg;
+        a2[j] = fmaf(gg, xh, a2[j]);
+      }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -206,14 +241,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_c8c8_kernel(
   src.dp = POOL ? reinterpret_cast<const hx8*>(dp16 + (int64_t)n * pbs16) + (int64_t)cb * (S >> 3) : nullptr;
   hx8* dst = reinterpret_cast<hx8*>(dx16 + (int64_t)n * dxbs16) + (int64_t)cb * S;
   const int64_t stride = gridDim.x * 256ll;
+  src.start(min<int64_t>(blockIdx.x * 256ll + threadIdx.x, S - 1), stride);
   for (int64_t i0 = blockIdx.x * 256ll + threadIdx.x; i0 < S; i0 += stride * U) {
     hx8 xv[U];
     float g[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = min(i0 + u * stride, S - 1);
-      xv[u] = xp[i];
-      src.load(i, g[u]);
+      const int64_t i = i0 + u * stride;
+      if (i < S) {
+        xv[u] = xp[i];
+        src.load(i, g[u]);
+      }
+      src.advance();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -250,6 +289,7 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_c8_kernel(const HT* __restri
     src.dy = dskip16 ? reinterpret_cast<const hx8*>(dskip16 + (int64_t)n * sbs16) + (int64_t)cb * S : nullptr;
     src.dp = reinterpret_cast<const hx8*>(dp16 + (int64_t)n * pbs16) + (int64_t)cb * (S >> 3);
     src.H = H; src.W = W; src.OH = H >> 1; src.OW = W >> 1;
+    src.start(v, 0);
     float g[8];
     src.load(v, g);
     hx8 o;
@@ -351,7 +391,7 @@ extern "C" int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, in
   M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)dpool16 | (uintptr_t)dx16) & 15) == 0 && xbs % 8 == 0 &&
                    ybs % 8 == 0 && dxbs % 8 == 0 && pbs % 8 == 0, M355_EINVALID_ARG, "norm_act_bwd_c8: c8 tensor not 16B aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)ceil_div(d->S, NORM_CHUNK);
+  const int nblk = (int)ceil_div(d->S, NORM_CHUNK_C8);
   double* partial = (double*)workspace;
   float* stat_m = (float*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk * 2 * sizeof(double), 256));
   const dim3 g1((unsigned)nblk, (unsigned)c8_blocks(d->C), (unsigned)d->N);

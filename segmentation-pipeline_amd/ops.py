@@ -297,7 +297,9 @@ _bn_sync_group = None      # (defined properly with batch_norm_sync below)
 
 # fp16 carries activation gradients multiplied by a power of two (include/m355seg.h, "grad_scale"): "auto" derives it
 # from the size of the prediction at the output convolution -- the gradient of a mean-type loss is ~1/(N * voxels) --
-# as 2^(floor(log2(N * voxels)) + 6); a number fixes it.  bf16 has fp32's exponent range: always 1.
+# as 2^(floor(log2(N * voxels)) + 3): the gradient of the logits is then O(1..10) x class weight, three decimal orders
+# below the fp16 maximum (normalisation backward multiplies by rstd, which can be large for a nearly constant group)
+# and four above its normal minimum; a number fixes it.  bf16 has fp32's exponent range: always 1.
 FP16_GRAD_SCALE = "auto"
 _fp16_scale = 2.0 ** 16
 
@@ -310,7 +312,7 @@ def _set_auto_grad_scale(n_elements):
     global _fp16_scale
     if FP16_GRAD_SCALE == "auto":
         import math
-        _fp16_scale = 2.0 ** min(24, max(0, int(math.floor(math.log2(max(1, n_elements)))) + 6))
+        _fp16_scale = 2.0 ** min(24, max(0, int(math.floor(math.log2(max(1, n_elements)))) + 3))
     else:
         _fp16_scale = float(FP16_GRAD_SCALE)
 # an encoder block's last norm + activation pass also emits the AvgPool3d(2, 2) the next level consumes

@@ -145,7 +145,7 @@ def _rounded_oracle(case, mode, loss_scale=1.0):
     conv-transpose operand and every stored activation where the c8 flow of the GPU path rounds -- and, through autograd
     of the casts, the activation gradients at the same points.  loss_scale: the backward pass starts from loss * scale
     and the parameter gradients are divided by it (what the fp16 mode's loss scaling does on the GPU)."""
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in case.model.state_dict().items()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in case.model.state_dict().items()}
     spec = R.UNetSpec(case.cin, case.cout, FILTERS, 5, norm="group", groups=8, up="convT", rounding=mode)
     torch.set_num_threads(16)
     p = R.unet_forward(sd, spec, case.x, training=True)
@@ -162,12 +162,12 @@ def _fp32_oracle_grads(case):
     return case.grads
 
 
-def _grad_stats(got, ref):
+def _grad_stats(got, ref, who="gpu"):
     """per-parameter (cosine, norm ratio, relative L2 error) and the cosine over all parameters"""
     rows, dot, na, nb = {}, 0.0, 0.0, 0.0
     for k, b in ref.items():
         a, b = got[k].double().flatten(), b.double().flatten()
-        assert torch.isfinite(a).all(), k
+        assert torch.isfinite(a).all(), f"{who}: non-finite gradient of {k}"
         rows[k] = (float(a @ b / (a.norm() * b.norm() + 1e-300)), float(a.norm() / (b.norm() + 1e-300)),
                    float((a - b).norm() / (b.norm() + 1e-300)))
         dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
@@ -200,7 +200,7 @@ def _composed_16bit_training_check(case, mode, prob_tol_fp32, prob_tol_rounded, 
     assert err_r <= prob_tol_rounded, err_r
     assert abs(ld["loss"].item() - ld_r["loss"]) <= 2e-5 and abs(ld["loss"].item() - case.loss_ref["loss"]) <= 1e-4
     rows, all_cos = _grad_stats(got, ref32)
-    rows_r, all_cos_r = _grad_stats(g_r, ref32)
+    rows_r, all_cos_r = _grad_stats(g_r, ref32, who="rounded oracle")
     assert all_cos >= all_cos_min, all_cos
     for k, (cos, ratio, rel) in rows.items():
         assert cos >= cos_min, (k, cos)
@@ -218,7 +218,7 @@ def test_cfg3_full_size_bf16_composed_training_flow_vs_rounding_matched_oracle(c
 def test_cfg5_full_size_fp16_composed_training_flow_with_loss_scaling(cfg5):
     """BASELINE cfg5 (fp16, 1x3x32x256x256) train mode.  At this size the gradient of the mean loss is ~1e-7 per voxel --
     below the fp16 normal range: without a loss scale the activation gradients underflow (round 2: parameter cosine
-    0.09 vs the fp32 oracle).  The c8 training flow carries them multiplied by 2^(floor(log2(N * voxels)) + 6) and
+    0.09 vs the fp32 oracle).  The c8 training flow carries them multiplied by 2^(floor(log2(N * voxels)) + 3) and
     removes the factor in the fp32 epilogues of the parameter gradients.  Measured: worst parameter cosine 0.997,
     norm ratio within 2.2 %, relative L2 error <= 0.08."""
     rows, _ = _composed_16bit_training_check(cfg5, "fp16", 5e-3, 2e-3, 0.99, 0.04, 0.99999)
