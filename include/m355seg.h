@@ -94,8 +94,9 @@ enum {
   /* the `w` argument of m355_conv3d_fwd(_stats|_h16) / m355_conv3d_bwd_data(_h16) points at weights packed by
    * m355_conv3d_pack for THIS descriptor (same shapes, compute mode and direction) instead of the torch-layout
    * filter: the per-launch repacking kernel is skipped.  Weights only change at optimizer.step, so a caller
-   * packs once per parameter version.  The buffer also holds the work-queue state of the persistent kernels
-   * (reset by the kernel itself when it drains): it must not be shared by two launches that run concurrently. */
+   * packs once per parameter version.  The buffer is read-only for the conv kernels: any number of launches, on any
+   * streams, may share it concurrently (the work-queue state of the queue-driven kernels lives in a per-stream slot
+   * of a small pool the library owns -- the one allocation it makes, 256 KB per device on first use). */
   M355_CONV_W_PACKED = 1,
   /* forward only: nn.Softmax(dim=1) over the Cout output channels applied in the conv epilogue (the out conv +
    * hypothesis of ModularUNet, models/modular_unet.py:99-100); allowed when m355_conv3d_fuses_softmax(desc) != 0
@@ -492,6 +493,21 @@ int m355_blur_weight_bwd(const float* dwexp, const float* w, const float* scale,
 int m355_weight_standardize_fwd(const float* w, float* wn, float* mean_std, int32_t A, int32_t n, void* stream);
 int m355_weight_standardize_bwd(const float* dwn, const float* w, const float* mean_std, float* dw, int32_t A,
                                 int32_t n, void* stream);
+
+/* Device-side weighted patch sampling.  Replaces tio.WeightedSampler(patch_size,
+ * probability_map='patch_probability') of the reference's patch loader (data_loader_factory.py:36-54,
+ * research/msseg2/msseg2.py:148-149; the map comes from ImageFromLabels, transforms/image_from_labels.py:11-57): the
+ * patch CENTRE is drawn with probability proportional to the map (negative entries count as 0) restricted to centres
+ * whose patch lies inside the volume; the returned location is the patch CORNER.  m355_sampler_build: a two-level
+ * cumulative table of the map ((ceil(V / 1024) + 1) doubles, once per map); table[last] is the total weight (the caller
+ * checks it is positive).  m355_sampler_draw: locations[p] = corner of the patch whose centre is the first voxel with
+ * cumulative weight > u[p] * total, u in [0, 1) -- one wave per patch, one launch per batch; feed the locations to
+ * m355_patch_gather.  fp64 sums in a fixed order: a draw is a pure function of (map, u). */
+size_t m355_sampler_table_bytes(int32_t V0, int32_t V1, int32_t V2);
+int m355_sampler_build(const float* prob, int32_t V0, int32_t V1, int32_t V2, int32_t p0, int32_t p1, int32_t p2,
+                       double* table, void* stream);
+int m355_sampler_draw(const float* prob, const double* table, int32_t V0, int32_t V1, int32_t V2, int32_t p0, int32_t p1,
+                      int32_t p2, const double* u, int32_t P, int32_t* locations, void* stream);
 
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio

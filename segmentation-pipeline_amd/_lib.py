@@ -131,6 +131,9 @@ SIGNATURES = {
     "m355_blur_weight_bwd": (C.c_int, [_P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "m355_weight_standardize_fwd": (C.c_int, [_P, _P, _P, _i32, _i32, _P]),
     "m355_weight_standardize_bwd": (C.c_int, [_P, _P, _P, _P, _i32, _i32, _P]),
+    "m355_sampler_table_bytes": (_sz, [_i32, _i32, _i32]),
+    "m355_sampler_build": (C.c_int, [_P] + [_i32] * 6 + [_P, _P]),
+    "m355_sampler_draw": (C.c_int, [_P, _P] + [_i32] * 6 + [_P, _i32, _P, _P]),
     "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_gather_padded": (C.c_int, [_P, _P, _P] + [_i32] * 12 + [_f32, _P]),

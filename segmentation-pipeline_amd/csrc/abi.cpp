@@ -1,5 +1,8 @@
 // Version / error reporting for libm355seg.
 #include "common.hpp"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace m355 {
 static thread_local char g_err[512] = "";
@@ -58,6 +61,39 @@ int num_cus() {
     cache[dev] = n;
   }
   return cache[dev];
+}
+// ---- work-queue state of the queue-driven conv kernels ----
+// One 64-byte slot (eight per-XCD ticket counters + an exit counter, all zero between launches: the last workgroup of
+// a launch resets them) per (device, stream), in a small pool the library owns.  Launches on one stream are ordered,
+// so they can share a slot; launches on DIFFERENT streams -- validation overlapping training on the same model, two
+// replicas of a predictor -- get different slots and may run concurrently.  (Round 2 kept this state in the tail of
+// the packed-weight buffer: two concurrent launches over one model corrupted each other's queues.)
+// The pool is allocated on first use (hipMalloc + hipMemset, outside any stream capture: torch's capture warm-up runs
+// every kernel eagerly first); kernels captured into a hipGraph keep the slot of their capture stream.
+int* queue_state(hipStream_t st) {
+  constexpr int SLOTS = 4096;
+  static std::mutex mu;
+  static int* pool[64] = {nullptr};
+  static std::map<std::pair<int, hipStream_t>, int> slot_of;
+  static int next_slot[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)SLOTS * 64) != hipSuccess || hipMemset(p, 0, (size_t)SLOTS * 64) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    pool[dev] = (int*)p;
+  }
+  auto key = std::make_pair(dev, st);
+  auto it = slot_of.find(key);
+  if (it == slot_of.end()) it = slot_of.emplace(key, next_slot[dev]++ % SLOTS).first;   // (> 4096 live streams share slots)
+  return pool[dev] + (size_t)it->second * 16;
 }
 }  // namespace m355
 

@@ -83,4 +83,7 @@ static inline int64_t dense_or(int64_t stride, int64_t dense) { return stride ? 
 // over the CUs.  Falls back to 256 when no device is visible (workspace queries on a build host).
 int num_cus();
 
+// zero-initialised, self-resetting work-queue state (16 ints) of this (device, stream): abi.cpp
+int* queue_state(hipStream_t st);
+
 }  // namespace m355

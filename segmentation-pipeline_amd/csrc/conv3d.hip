@@ -1562,6 +1562,51 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
   for (int e = threadIdx.x; e < cw * 27; e += 256) dst[e] = tr[e];
 }
 
+// The same reduction for FEW (o, c-tile) pairs with MANY splits (32 -> 32 at 128^3: 32 blocks each walking 256 slabs,
+// 22 us on 32 of 256 CUs): one block per (o, c-tile, tap); its 256 threads are 32 channels x 8 split lanes, lane j sums
+// the splits s = j, j + 8, ... and the eight partial sums are added in lane order -- fixed order, bit-reproducible.
+__global__ __launch_bounds__(256) void slab_reduce_tap_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                              int Cin, int Cout, BwwClasses k, float scale) {
+  __shared__ float part[8][32];
+  const int o = blockIdx.x, ct = blockIdx.y, tap = blockIdx.z;
+  const int nsplit = k.ns[(o >= k.of * 32 ? 2 : 0) + (ct >= k.cf ? 1 : 0)];
+  const int64_t plane = (int64_t)Cout * Cin, split_stride = 27 * plane;
+  const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int c = ct * 32 + cl;
+  float v = 0.f;
+  if (c < Cin) {
+    const float* p = slab + (int64_t)tap * plane + (int64_t)o * Cin + c;
+    int s = j;
+    for (; s + 24 < nsplit; s += 32) {   // four loads in flight
+      const float t0 = p[(int64_t)s * split_stride], t1 = p[(int64_t)(s + 8) * split_stride],
+                  t2 = p[(int64_t)(s + 16) * split_stride], t3 = p[(int64_t)(s + 24) * split_stride];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; s < nsplit; s += 8) v += p[(int64_t)s * split_stride];
+  }
+  part[j][cl] = v;
+  __syncthreads();
+  if (j == 0 && c < Cin) {
+    float t = part[0][cl];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += part[q][cl];
+    out[((int64_t)o * Cin + c) * 27 + tap] = t * scale;
+  }
+}
+
+// picks the reduction by shape: per-tap blocks where the (o, c-tile) grid alone cannot fill the chip
+static void launch_slab_reduce_t(const float* slab, float* dw, int Cin, int Cout, int ctiles, const BwwClasses& k,
+                                 float scale, hipStream_t st) {
+  int max_ns = 1;
+  for (int c = 0; c < 4; ++c) max_ns = std::max(max_ns, k.ns[c]);
+  if ((int64_t)Cout * ctiles < 2 * (int64_t)num_cus() && max_ns >= 16)
+    hipLaunchKernelGGL(slab_reduce_tap_kernel, dim3((unsigned)Cout, (unsigned)ctiles, 27u), dim3(256), 0, st, slab, dw, Cin,
+                       Cout, k, scale);
+  else
+    hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)Cout, (unsigned)ctiles), dim3(256), 0, st, slab, dw, Cin, Cout,
+                       k, scale);
+}
+
 // ------------------------------------------- bwd-weight, tiny channel count on one side
 // dW[o,c,tap] when Cin <= 4 (first conv) or Cout <= 4 (out conv).  The generic kernel would
 // pad the narrow side to 32 MFMA rows/cols (8-10x waste).  Here the narrow channel AND the
@@ -2163,7 +2208,8 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
   M355_REQUIRE(((uintptr_t)ws & 15) == 0, M355_EINVALID_ARG, "conv3d: workspace not 16B aligned");
   float* wp = prepacked ? (float*)prepacked : (float*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
-  int* work_counter = (int*)((char*)wp + p.wp_bytes - 256);  // last 256 B of the packed-weight region
+  int* work_counter = queue_state(st);   // per (device, stream): concurrent launches over one model never share it
+  M355_REQUIRE(work_counter, M355_ELAUNCH, "conv3d: could not allocate the work-queue state");
   if (!prepacked) launch_pack_w3(p, w, wp, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
@@ -2663,8 +2709,7 @@ extern "C" int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void*
   kred.of = (int)ceil_div(d->Cout, 32);
   kred.cf = (int)ceil_div(d->Cin, 32);
   for (int c = 0; c < 4; ++c) kred.ns[c] = nsplit;
-  hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)kred.cf), dim3(256), 0, st, slab, dw, d->Cin,
-                     d->Cout, kred, 1.f);
+  launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, kred.cf, kred, 1.f, st);
   if (dbias) {
     const size_t slab_b = (size_t)round_up((int64_t)nsplit * d->Cout * d->Cin * 27 * 4, 256);
     launch_dbias(dy, dbias, d->N, d->Cout, S, dense_or(d->y_batch_stride, (int64_t)d->Cout * S), (char*)workspace + slab_b, st);
@@ -2715,8 +2760,7 @@ extern "C" int m355_conv3d_bwd_weight_c8(const m355_conv3d_desc* d, const void* 
   kred.of = (int)ceil_div(d->Cout, 32);
   kred.cf = (int)ceil_div(d->Cin, 32);
   for (int c = 0; c < 4; ++c) kred.ns[c] = nsplit;
-  hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)kred.cf), dim3(256), 0, st, slab, dw, d->Cin,
-                     d->Cout, kred, grad_unscale);
+  launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, kred.cf, kred, grad_unscale, st);
   if (dbias) {
     const size_t slab_b = (size_t)round_up((int64_t)nsplit * d->Cout * d->Cin * 27 * 4, 256);
     if (int rc = launch_dbias_c8(dy16, ybs, dbias, d->N, d->Cout, S, d->compute, grad_unscale, (char*)workspace + slab_b, st))
@@ -2887,8 +2931,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     else
       M355_BWW_LAUNCH(8)
     if (gen2) {
-      hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)d->Cout, (unsigned)p.ctiles), dim3(256), 0, st, slab, dw,
-                         d->Cin, d->Cout, kred, 1.f);
+      launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, p.ctiles, kred, 1.f, st);
     } else {
       const int64_t total = (int64_t)d->Cout * d->Cin * 27;
       const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);

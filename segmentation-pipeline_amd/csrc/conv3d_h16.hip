@@ -907,7 +907,8 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
                "conv3d(16-bit operands): the softmax epilogue needs Cout <= 4, an unsplit plan, fp32 output, no add / statistics");
   HT* wpb = prepacked ? (HT*)prepacked : (HT*)ws;
   float* slab = (float*)((char*)ws + p.wp_bytes);
-  int* work_counter = (int*)((char*)wpb + p.wp_bytes - 256);  // last 256 B of the packed-weight region
+  int* work_counter = queue_state(st);   // per (device, stream): concurrent launches over one model never share it
+  M355_REQUIRE(work_counter, M355_ELAUNCH, "conv3d(16-bit operands): could not allocate the work-queue state");
   if (!prepacked) pack_w3_h16_t<HT>(p, w, wpb, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;

@@ -289,6 +289,133 @@ __global__ void confusion_tn_kernel(unsigned long long* __restrict__ counts, int
     counts[i * 4 + 3] = (unsigned long long)S - counts[i * 4] - counts[i * 4 + 1] - counts[i * 4 + 2];
 }
 
+
+// ------------------------------------------------------------------ device-side weighted patch sampling (N2)
+// tio.WeightedSampler(patch_size, probability_map) (data_loader_factory.py:36-54, research/msseg2/msseg2.py:148-149;
+// the map is ImageFromLabels' "brain 1, lesion 100", transforms/image_from_labels.py:11-57): a patch CENTRE is drawn with
+// probability proportional to the map, restricted to centres whose patch fits in the volume.  Round 2 built a float64
+// cumulative sum of the whole volume per CALL (134 MB for 256^3).  Here a two-level table is built once per map --
+// table[b] = sum of the (clamped, border-masked) weights of all voxels before block b of 1024 voxels, table[nb] = the
+// total -- and a draw is a binary search over the table plus a scan of ONE block: one wave per patch, one launch per
+// batch.  All sums are fp64 in a fixed order, so a draw is a pure function of (map, u).
+constexpr int SAMPLER_BLOCK = 1024;
+
+struct SamplerGeom {
+  int V0, V1, V2, lo0, lo1, lo2, hi0, hi1, hi2;   // a centre i is valid iff lo <= i < V - hi (per axis)
+};
+__device__ __forceinline__ double sampler_weight(const float* __restrict__ prob, int64_t idx, int64_t total,
+                                                 const SamplerGeom& g) {
+  if (idx >= total) return 0.0;
+  const int k = (int)(idx % g.V2);
+  const int64_t r = idx / g.V2;
+  const int j = (int)(r % g.V1), i = (int)(r / g.V1);
+  if (i < g.lo0 || i >= g.V0 - g.hi0 || j < g.lo1 || j >= g.V1 - g.hi1 || k < g.lo2 || k >= g.V2 - g.hi2) return 0.0;
+  const float w = prob[idx];
+  return w > 0.f ? (double)w : 0.0;      // negative weights count as 0, NaN as 0
+}
+
+// table[b + 1] = weight of block b (thread t: voxels 4t .. 4t+3 in order; then the fixed tree of block_sum)
+__global__ __launch_bounds__(256) void sampler_block_sums_kernel(const float* __restrict__ prob, double* __restrict__ table,
+                                                                 SamplerGeom g) {
+  __shared__ double scratch[4];
+  const int64_t total = (int64_t)g.V0 * g.V1 * g.V2;
+  const int64_t base = (int64_t)blockIdx.x * SAMPLER_BLOCK + threadIdx.x * 4;
+  double v = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v += sampler_weight(prob, base + q, total, g);
+  const double t = block_sum<double, 256>(v, scratch);
+  if (threadIdx.x == 0) table[blockIdx.x + 1] = t;
+}
+
+// in place: table[1..nb] block weights -> table[b] = sum of the blocks before b (table[0] = 0, table[nb] = total)
+__global__ __launch_bounds__(256) void sampler_prefix_kernel(double* __restrict__ table, int nb) {
+  __shared__ double part[256];
+  const int t = threadIdx.x;
+  const int per = (nb + 255) / 256;
+  const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+  double s = 0.0;
+  for (int b = b0; b < b1; ++b) s += table[b + 1];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    double run = 0.0;
+    for (int q = 0; q < 256; ++q) {
+      const double x = part[q];
+      part[q] = run;
+      run += x;
+    }
+    table[0] = 0.0;
+  }
+  __syncthreads();
+  double run = part[t];
+  for (int b = b0; b < b1; ++b) {      // table[b + 1] <- inclusive prefix; read before write, each entry owned by one thread
+    run += table[b + 1];
+    table[b + 1] = run;
+  }
+}
+
+// one wave per patch: corner location of the patch whose centre is the first voxel with cumulative weight > u * total
+__global__ __launch_bounds__(64) void sampler_draw_kernel(const float* __restrict__ prob, const double* __restrict__ table,
+                                                          int nb, SamplerGeom g, int p0, int p1, int p2,
+                                                          const double* __restrict__ u, int P, int32_t* __restrict__ loc) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int64_t total = (int64_t)g.V0 * g.V1 * g.V2;
+  const double sum = table[nb];
+  double target = u[p] * sum;
+  if (!(target < sum)) target = sum * (1.0 - 1.1102230246251565e-16);   // u == 1 (rounding): the last weighted voxel
+  if (!(target >= 0.0)) target = 0.0;
+  int lo = 0, hi = nb;                       // largest b with table[b] <= target (wave-uniform)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (table[mid] <= target) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const double r = target - table[b];
+  const int64_t base = (int64_t)b * SAMPLER_BLOCK + lane * 16;
+  double w[16], s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    w[q] = sampler_weight(prob, base + q, total, g);
+    s += w[q];
+  }
+  double incl = s;                            // inclusive scan over the lanes, fixed order
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const double excl = incl - s;
+  // the lane whose range holds the target; rounding can leave no lane (r a hair above the block weight): the last
+  // lane with positive weight then
+  const unsigned long long hit = __ballot(s > 0.0 && incl > r);
+  const unsigned long long pos = __ballot(s > 0.0);
+  if (pos == 0ull) {                          // (an all-zero map: m355_sampler_build's caller checks table[nb] > 0)
+    if (lane == 0) loc[p * 3] = loc[p * 3 + 1] = loc[p * 3 + 2] = 0;
+    return;
+  }
+  const int L = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)pos);
+  if (lane == L) {
+    double run = excl;
+    int pick = -1, last = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (w[q] > 0.0) {
+        last = q;
+        run += w[q];
+        if (pick < 0 && run > r) pick = q;
+      }
+    }
+    if (pick < 0) pick = last;
+    const int64_t idx = base + pick;
+    const int k = (int)(idx % g.V2);
+    const int64_t rr = idx / g.V2;
+    const int j = (int)(rr % g.V1), i = (int)(rr / g.V1);
+    loc[p * 3 + 0] = min(max(i - p0 / 2, 0), g.V0 - p0);
+    loc[p * 3 + 1] = min(max(j - p1 / 2, 0), g.V1 - p1);
+    loc[p * 3 + 2] = min(max(k - p2 / 2, 0), g.V2 - p2);
+  }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -337,6 +464,43 @@ static int check_patch_args(int32_t P, int32_t C, int32_t V0, int32_t V1, int32_
   M355_REQUIRE(ps0 <= V0 && ps1 <= V1 && ps2 <= V2, M355_EINVALID_ARG,
                "%s: patch (%d,%d,%d) larger than volume (%d,%d,%d)", who, ps0, ps1, ps2, V0, V1, V2);
   return M355_OK;
+}
+
+static int sampler_geom(const char* who, int V0, int V1, int V2, int p0, int p1, int p2, SamplerGeom* g) {
+  M355_REQUIRE(V0 > 0 && V1 > 0 && V2 > 0 && p0 > 0 && p1 > 0 && p2 > 0, M355_EINVALID_ARG, "%s: non-positive size", who);
+  M355_REQUIRE(p0 <= V0 && p1 <= V1 && p2 <= V2, M355_EINVALID_ARG, "%s: patch (%d,%d,%d) exceeds the volume (%d,%d,%d)", who, p0,
+               p1, p2, V0, V1, V2);
+  M355_REQUIRE(ceil_div((int64_t)V0 * V1 * V2, SAMPLER_BLOCK) < (1ll << 30), M355_EUNSUPPORTED, "%s: volume too large", who);
+  // centre index inside the patch: p // 2; voxels after the centre: p - p // 2 - 1
+  *g = SamplerGeom{V0, V1, V2, p0 / 2, p1 / 2, p2 / 2, p0 - p0 / 2 - 1, p1 - p1 / 2 - 1, p2 - p2 / 2 - 1};
+  return M355_OK;
+}
+
+extern "C" size_t m355_sampler_table_bytes(int32_t V0, int32_t V1, int32_t V2) {
+  if (V0 <= 0 || V1 <= 0 || V2 <= 0) return 0;
+  return (size_t)(ceil_div((int64_t)V0 * V1 * V2, SAMPLER_BLOCK) + 1) * sizeof(double);
+}
+
+extern "C" int m355_sampler_build(const float* prob, int32_t V0, int32_t V1, int32_t V2, int32_t p0, int32_t p1, int32_t p2,
+                                  double* table, void* stream) {
+  SamplerGeom g;
+  if (int rc = sampler_geom("sampler_build", V0, V1, V2, p0, p1, p2, &g)) return rc;
+  M355_REQUIRE(prob && table, M355_EINVALID_ARG, "sampler_build: null pointer");
+  const int nb = (int)ceil_div((int64_t)V0 * V1 * V2, SAMPLER_BLOCK);
+  hipLaunchKernelGGL(sampler_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, prob, table, g);
+  hipLaunchKernelGGL(sampler_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, table, nb);
+  return check_launch("sampler_build");
+}
+
+extern "C" int m355_sampler_draw(const float* prob, const double* table, int32_t V0, int32_t V1, int32_t V2, int32_t p0,
+                                 int32_t p1, int32_t p2, const double* u, int32_t P, int32_t* locations, void* stream) {
+  SamplerGeom g;
+  if (int rc = sampler_geom("sampler_draw", V0, V1, V2, p0, p1, p2, &g)) return rc;
+  M355_REQUIRE(prob && table && u && locations && P > 0, M355_EINVALID_ARG, "sampler_draw: null pointer / no patches");
+  const int nb = (int)ceil_div((int64_t)V0 * V1 * V2, SAMPLER_BLOCK);
+  hipLaunchKernelGGL(sampler_draw_kernel, dim3((unsigned)P), dim3(64), 0, (hipStream_t)stream, prob, table, nb, g, p0, p1, p2,
+                     u, P, locations);
+  return check_launch("sampler_draw");
 }
 
 extern "C" int m355_patch_gather(const float* volume, const int32_t* loc, float* patches, int32_t P,

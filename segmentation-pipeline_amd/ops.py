@@ -1452,8 +1452,10 @@ def norm_act(x, gamma, beta, cfg: NormCfg, add=None, pool=False):
     """normalization_class + activation_class of Block3d (components.py:52-55), optionally
     fused with the residual sum (components.py:67-68): act(norm(x)) + add.  With `cfg.c8` set (16-bit
     precision mode under no_grad) the result is an `Act16` and nothing is written in fp32."""
-    if cfg.c8 and isinstance(x, Act16) and torch.is_grad_enabled():
-        return _norm_act_c8_train(x, gamma, beta, add, cfg, pool=pool)      # c8 training flow
+    if cfg.c8 and torch.is_grad_enabled():                                   # c8 training flow
+        if not isinstance(x, Act16):     # the pre-norm tensor of a conv without a c8 kernel (strided / Blur): joins here
+            x = pack_act16(x, cfg.c8)
+        return _norm_act_c8_train(x, gamma, beta, add, cfg, pool=pool)
     if pool:
         raise _lib.M355Error("norm_act(pool=True) is the c8 training flow's fused pool; use norm_act_pool for fp32 tensors")
     if cfg.c8 and not torch.is_grad_enabled():
@@ -1869,6 +1871,31 @@ def patch_gather(volume, locations, patch_size):
     check(L.m355_patch_gather(_p(volume), _p(locations), _p(patches), P, Cc, V0, V1, V2, ps0, ps1, ps2,
                               _stream()), "patch_gather")
     return patches
+
+
+def sampler_build(prob_map, patch_size):
+    """cumulative table of a [V0, V1, V2] probability map for `sampler_draw` (float64, (V / 1024 + 1) entries, the last
+    one the total weight of the centres whose patch fits)"""
+    L = _lib.lib()
+    _require(prob_map)
+    prob_map = prob_map.contiguous()
+    V0, V1, V2 = prob_map.shape
+    table = torch.empty(int(L.m355_sampler_table_bytes(V0, V1, V2)) // 8, dtype=torch.float64, device=prob_map.device)
+    check(L.m355_sampler_build(_p(prob_map), V0, V1, V2, *[int(p) for p in patch_size], _p(table), _stream()), "sampler_build")
+    return table
+
+
+def sampler_draw(prob_map, table, patch_size, u):
+    """u: float64 [P] uniform in [0, 1) on the device -> int32 [P, 3] patch corners (tio.WeightedSampler semantics)"""
+    L = _lib.lib()
+    _require(prob_map)
+    _require(table, u, dtype=torch.float64)
+    V0, V1, V2 = prob_map.shape
+    P = u.numel()
+    loc = torch.empty((P, 3), dtype=torch.int32, device=prob_map.device)
+    check(L.m355_sampler_draw(_p(prob_map), _p(table), V0, V1, V2, *[int(p) for p in patch_size], _p(u.contiguous()), P,
+                              _p(loc), _stream()), "sampler_draw")
+    return loc
 
 
 PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2, "symmetric": 3, "wrap": 4}

@@ -51,12 +51,21 @@ class UniformSampler:
 
 
 class WeightedSampler(UniformSampler):
-    def __init__(self, patch_size, ops_backend=ops):
+    """tio.WeightedSampler semantics on the device.  The cumulative structure of a probability map is built ONCE per map
+    (`m355_sampler_build`: a two-level table, 8 bytes per 1024 voxels -- cached per (storage, version, shape) of the
+    map tensor); a batch of draws is one uniform-random launch plus ONE `m355_sampler_draw` launch (a binary search over
+    the table and a scan of one 1024-voxel block per patch), then the usual gathers.  Nothing is synchronised with
+    the host after the first use of a map (whose total weight is checked once)."""
+
+    def __init__(self, patch_size, ops_backend=ops, max_cached_maps: int = 8):
         super().__init__(patch_size, ops_backend)
+        self._tables = {}
+        self._max = max_cached_maps
 
     def centre_distribution(self, probability_map: torch.Tensor) -> torch.Tensor:
         """Probability of each voxel being drawn as a patch centre: the map with every centre whose
-        patch would leave the volume zeroed, normalised to 1 (flattened)."""
+        patch would leave the volume zeroed, normalised to 1 (flattened).  Host-side restatement (float64 torch ops) of
+        what the table encodes; the sampling path itself does not use it."""
         pm = probability_map.reshape(probability_map.shape[-3:]).to(torch.float64).clamp_min(0)
         lo = [p // 2 for p in self.patch_size]                      # centre index inside the patch
         hi = [p - p // 2 - 1 for p in self.patch_size]              # voxels after the centre
@@ -68,28 +77,33 @@ class WeightedSampler(UniformSampler):
             raise RuntimeError("probability map has no positive entry where a patch fits")
         return (valid / total).flatten()
 
+    def _table(self, pm: torch.Tensor):
+        key = (pm.data_ptr(), pm._version, tuple(pm.shape), pm.device)
+        ent = self._tables.get(key)
+        if ent is None:
+            table = self._ops.sampler_build(pm, self.patch_size)
+            total = float(table[-1])                  # the one host synchronisation per map
+            if not (total > 0) or total == float("inf"):
+                raise RuntimeError("probability map has no positive entry where a patch fits")
+            if len(self._tables) >= self._max:
+                self._tables.pop(next(iter(self._tables)))
+            ent = self._tables[key] = (table, pm)     # (keeps the map alive: the key holds its address)
+        return ent[0]
+
     def sample_locations(self, probability_map: torch.Tensor, n: int, generator=None) -> torch.Tensor:
-        shape = probability_map.shape[-3:]
-        pdf = self.centre_distribution(probability_map)
-        cdf = torch.cumsum(pdf, dim=0)
-        cdf = cdf / cdf[-1]
-        u = torch.rand(n, dtype=torch.float64, device=cdf.device, generator=generator)
-        # a draw at / beyond the last cdf value (rounding) falls back to the last centre with non-zero
-        # probability -- never to the zeroed border, whose patch would leave the volume
-        last_valid = torch.nonzero(pdf > 0)[-1, 0]
-        flat = torch.minimum(torch.searchsorted(cdf, u, right=True), last_valid)
-        k = flat % shape[2]
-        j = (flat // shape[2]) % shape[1]
-        i = flat // (shape[1] * shape[2])
-        centre = torch.stack([i, j, k], dim=1)
-        corner = centre - torch.tensor([p // 2 for p in self.patch_size], device=centre.device)
-        hi = torch.tensor([s - p for s, p in zip(shape, self.patch_size)], device=centre.device)
-        corner = torch.minimum(corner.clamp_min(0), hi)  # the gather kernel does no bounds checks of its own
-        return corner.to(torch.int32)
+        pm = probability_map.reshape(probability_map.shape[-3:])
+        if pm.dtype != torch.float32 or not pm.is_contiguous():
+            pm = pm.float().contiguous()
+        if any(p > s for p, s in zip(self.patch_size, pm.shape)):
+            raise ValueError(f"patch size {self.patch_size} exceeds volume shape {tuple(pm.shape)}")
+        u = torch.rand(n, dtype=torch.float64, device=pm.device, generator=generator)
+        return self._ops.sampler_draw(pm, self._table(pm), self.patch_size, u)
 
     def __call__(self, volume: torch.Tensor, probability_map: torch.Tensor, n: int, generator=None,
                  extra: Optional[Sequence[torch.Tensor]] = None):
-        loc = self.sample_locations(probability_map.to(volume.device), n, generator)
+        if probability_map.device != volume.device:
+            probability_map = probability_map.to(volume.device)
+        loc = self.sample_locations(probability_map, n, generator)
         out = [self._ops.patch_gather(volume, loc, self.patch_size)]
         for v in extra or ():
             out.append(self._ops.patch_gather(v, loc, self.patch_size))

@@ -135,6 +135,19 @@ class CpuPatchOps:
         return out[:, border[0]:out.shape[1] - border[0], border[1]:out.shape[2] - border[1],
                    border[2]:out.shape[3] - border[2]].contiguous()
 
+    @staticmethod
+    def sampler_build(prob_map, patch_size):
+        """stands in for the device table: [total weight of the valid centres] (the host code only reads the last entry)"""
+        lo = [p // 2 for p in patch_size]
+        hi = [p - p // 2 - 1 for p in patch_size]
+        sl = tuple(slice(l, s - h) for l, h, s in zip(lo, hi, prob_map.shape))
+        return torch.tensor([float(prob_map.clamp_min(0)[sl].double().sum())], dtype=torch.float64)
+
+    @staticmethod
+    def sampler_draw(prob_map, table, patch_size, u):
+        loc, _ = R.weighted_sample_locations(prob_map.numpy(), patch_size, u.numpy())
+        return torch.from_numpy(loc)
+
 
 class TileModel(nn.Module):
     """Not pointwise (neighbouring voxels mix through the rolls, so overlapping tiles really
@@ -505,7 +518,7 @@ def test_samplers_index_arithmetic_and_distribution():
     # a draw beyond the last cdf value (float rounding) must land on a VALID centre, never on the zeroed border
     import segmentation_pipeline_amd.sampling as S
     orig = S.torch.rand
-    S.torch.rand = lambda n, **k: torch.ones(n, dtype=k.get("dtype", torch.float32))
+    S.torch.rand = lambda n, **k: torch.ones(n, dtype=k.get("dtype", torch.float32)) * (1.0 - 2.0 ** -53)
     try:
         locs = ws.sample_locations(pm, 3)
     finally:

@@ -356,6 +356,35 @@ def test_packed_weights_are_shared_across_input_shapes():
     assert sorted(k[0] for k in conv_w._m355_packed[2]) == [0, 1]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_two_streams_over_one_model_run_concurrently(tuning, mode):
+    """the work-queue state of the queue-driven conv kernels used to live in the tail of the packed-
+    weight buffer, so two launches over ONE model on different streams (validation overlapping training) corrupted each
+    other's queues.  It now lives in a per-(device, stream) slot: forwards issued alternately on two streams -- the
+    queue-driven kernels forced on these small shapes, few workgroups so that each walks many items -- reproduce the
+    serial results bit for bit."""
+    import segmentation_pipeline_amd as sp
+    tuning(M355_CONV_PERSISTENT=2, M355_CONV_SLOTS=6, M355_H16_ONESHOT=3)
+    torch.manual_seed(0)
+    model = ModularUNet(4, 3, [16, 32], 2, block_params=dict(GN8), **CONVT).cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    xa, xb = torch.randn((1, 4, 32, 32, 64), generator=g).cuda(), torch.randn((2, 4, 16, 32, 32), generator=g).cuda()
+    with sp.precision(mode), torch.no_grad():
+        ya, yb = model(xa), model(xb)          # serial reference (also packs the weights once)
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(12):                    # one host thread alternates: the two streams' kernels overlap on the GPU
+            with torch.cuda.stream(sa):
+                oa = model(xa)
+            with torch.cuda.stream(sb):
+                ob = model(xb)
+            outs.append((oa, ob))
+        torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa, ya) and torch.equal(ob, yb)
+
+
 def test_volume_feeder_with_a_consumer_that_never_synchronises():
     """the host may run subjects ahead of the GPU (no .item() in the loop).  A slot's pinned staging buffer
     must not be overwritten before the earlier H2D copy out of it has completed, and its device tensors not before the
@@ -546,6 +575,57 @@ def test_device_side_samplers_on_gpu():
     (patches, pmaps), loc = WeightedSampler(8)(vol, pm, 5, generator=g, extra=[pm])
     assert (loc.cpu() == torch.tensor([6, 5, 7], dtype=torch.int32)).all()
     assert (pmaps[:, 0, 4, 4, 4] == 1.0).all()
+
+
+def test_weighted_sampler_kernel_matches_the_cdf_restatement_and_its_distribution():
+    """m355_sampler_build / m355_sampler_draw (N2): for given uniform numbers the drawn corners equal the float64
+    cumulative-sum restatement of tio.WeightedSampler (oracle.torch_ref.weighted_sample_locations; torchio itself is
+    absent: parity unpinned) on a ragged volume with negative / zero / huge entries; on a three-level map (background 1,
+    tissue 10, lesion 100 -- transforms/image_from_labels.py) the empirical centre distribution passes a chi-square test;
+    the table is built once per map version."""
+    from oracle import torch_ref as R
+    from segmentation_pipeline_amd.sampling import WeightedSampler
+    g = torch.Generator().manual_seed(5)
+    shape, patch = (37, 41, 45), (8, 6, 10)
+    pm = torch.rand(shape, generator=g)
+    pm[pm < 0.3] = 0.0
+    pm[5:9, 7:11, 3:30] = -2.0                      # negative: counts as 0
+    pm[20, 20, 20] = 5000.0
+    pm[0, 0, 0] = 1e9                               # a centre whose patch does not fit: never drawn
+    u = torch.rand(4096, dtype=torch.float64, generator=g)
+    u[:4] = torch.tensor([0.0, 1.0 - 2.0 ** -53, 0.5, 1e-300], dtype=torch.float64)
+    ref, weights = R.weighted_sample_locations(pm.numpy(), patch, u.numpy())
+    table = ops.sampler_build(pm.cuda(), patch)
+    loc = ops.sampler_draw(pm.cuda(), table, patch, u.cuda())
+    assert torch.equal(loc.cpu(), torch.from_numpy(ref))
+    assert float(table[-1]) == pytest.approx(float(weights.sum()), rel=1e-12) and float(table[0]) == 0.0
+    # distribution: three levels, patch 4^3 on 24 x 20 x 28
+    lv = torch.ones((24, 20, 28))
+    lv[6:14, 4:12, 8:20] = 10.0
+    lv[9:11, 6:9, 10:14] = 100.0
+    ws = WeightedSampler(4)
+    n = 200000
+    dg = torch.Generator(device="cuda").manual_seed(1)
+    lvd = lv.cuda()
+    locs = ws.sample_locations(lvd, n, generator=dg)
+    assert len(ws._tables) == 1
+    ws.sample_locations(lvd, 8, generator=dg)
+    assert len(ws._tables) == 1                     # cached: same storage, same version
+    centre = (locs.cpu().long() + 2)
+    assert (locs >= 0).all() and (locs.cpu() <= torch.tensor([20, 16, 24])).all()
+    level = lv[centre[:, 0], centre[:, 1], centre[:, 2]]
+    valid = torch.zeros_like(lv)
+    valid[2:23, 2:19, 2:27] = lv[2:23, 2:19, 2:27]
+    obs = torch.tensor([(level == v).sum().item() for v in (1.0, 10.0, 100.0)], dtype=torch.float64)
+    exp = torch.tensor([valid[valid == v].sum().item() for v in (1.0, 10.0, 100.0)], dtype=torch.float64)
+    exp = exp / exp.sum() * n
+    chi2 = float(((obs - exp) ** 2 / exp).sum())
+    assert chi2 < 13.8, (chi2, obs.tolist(), exp.tolist())      # chi-square, 2 degrees of freedom, p = 0.001
+    lvd.mul_(2.0)                                   # an in-place change of the map voids the cached table
+    ws.sample_locations(lvd, 8, generator=dg)
+    assert len(ws._tables) == 2
+    with pytest.raises(RuntimeError):
+        WeightedSampler(4).sample_locations(torch.zeros((8, 8, 8), device="cuda"), 2)
 
 
 def test_volume_feeder_double_buffered_uploads_on_gpu():
