@@ -550,7 +550,7 @@ def run_window(args, rank, world, device):
     if rank != 0:
         return None
     phases = {k: v / 2 * 1e3 for k, v in timings.items()}
-    serial = sum(v for k, v in phases.items() if k in ("exchange", "accumulate", "finalize"))
+    serial = sum(v for k, v in phases.items() if k in ("exchange", "accumulate", "finalize", "aggregate"))
     out = {
         "metric": METRIC, "value": n_tiles * args.steps / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,

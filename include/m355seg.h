@@ -509,6 +509,16 @@ int m355_sampler_build(const float* prob, int32_t V0, int32_t V1, int32_t V2, in
 int m355_sampler_draw(const float* prob, const double* table, int32_t V0, int32_t V1, int32_t V2, int32_t p0, int32_t p1,
                       int32_t p2, const double* u, int32_t P, int32_t* locations, void* stream);
 
+/* The whole aggregation of a sliding window in one pass (torchio GridAggregator('average') as driven by
+ * PatchPredict.predict, prediction.py:124-152): tiles [n0*n1*n2, C, ps0, ps1, ps2] in GridSampler order (tile index =
+ * (a * n1 + b) * n2 + c over the per-axis start lists starts[0..n0), [n0..n0+n1), [n0+n1..n0+n1+n2), device int32, in
+ * coordinates of the padded volume) -> out [C, V0, V1, V2] = per-voxel mean of the covering tiles, where voxel v of the
+ * output is voxel v + border of the padded volume (border = 0: no padding).  Same bits as m355_patch_accumulate over
+ * all tiles in order followed by m355_patch_finalize(_crop).  Every output voxel must be covered by a tile. */
+int m355_patch_aggregate_grid(const float* tiles, const int32_t* starts, int32_t n0, int32_t n1, int32_t n2, float* out,
+                              int32_t C, int32_t V0, int32_t V1, int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2,
+                              int32_t b0, int32_t b1, int32_t b2, void* stream);
+
 /* ------------------------------------------------- sliding-window patches
  * PatchPredict (prediction.py:124-152) delegates tiling/aggregation to torchio
  * 0.18.45 GridSampler / GridAggregator(overlap_mode='average').  These entry

@@ -1102,3 +1102,39 @@ int m355o_patch_finalize_crop(const float* accum, const float* count, float* out
         }
   return 0;
 }
+
+
+/* m355_patch_aggregate_grid: GridAggregator('average') over a whole tile grid (prediction.py:124-152), tiles summed per
+ * voxel in tile order in fp32 (the order of repeated m355o_patch_accumulate calls), then divided by their count */
+int m355o_patch_aggregate_grid(const float* tiles, const int32_t* starts, int32_t n0, int32_t n1, int32_t n2, float* out,
+                               int32_t C, int32_t V0, int32_t V1, int32_t V2, int32_t ps0, int32_t ps1, int32_t ps2,
+                               int32_t b0, int32_t b1, int32_t b2, void* stream) {
+  (void)stream;
+  const int64_t V = (int64_t)V0 * V1 * V2, PS = (int64_t)ps0 * ps1 * ps2;
+  const int32_t *s0 = starts, *s1 = starts + n0, *s2 = starts + n0 + n1;
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < V0; ++i)
+      for (int j = 0; j < V1; ++j)
+        for (int k = 0; k < V2; ++k) {
+          float sum = 0.f;
+          int cnt = 0;
+          for (int a = 0; a < n0; ++a) {
+            const int di = i + b0 - s0[a];
+            if (di < 0 || di >= ps0) continue;
+            for (int b = 0; b < n1; ++b) {
+              const int dj = j + b1 - s1[b];
+              if (dj < 0 || dj >= ps1) continue;
+              for (int q = 0; q < n2; ++q) {
+                const int dk = k + b2 - s2[q];
+                if (dk < 0 || dk >= ps2) continue;
+                const int64_t p = ((int64_t)a * n1 + b) * n2 + q;
+                const float t = tiles[(p * C + c) * PS + ((int64_t)di * ps1 + dj) * ps2 + dk];
+                sum = cnt == 0 ? t : sum + t;
+                ++cnt;
+              }
+            }
+          }
+          out[(int64_t)c * V + ((int64_t)i * V1 + j) * V2 + k] = sum / (float)cnt;
+        }
+  return M355_OK;
+}

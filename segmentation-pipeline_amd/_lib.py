@@ -135,6 +135,7 @@ SIGNATURES = {
     "m355_sampler_build": (C.c_int, [_P] + [_i32] * 6 + [_P, _P]),
     "m355_sampler_draw": (C.c_int, [_P, _P] + [_i32] * 6 + [_P, _i32, _P, _P]),
     "m355_patch_gather": (C.c_int, [_P, _P, _P] + [_i32] * 8 + [_P]),
+    "m355_patch_aggregate_grid": (C.c_int, [_P, _P, _i32, _i32, _i32, _P] + [_i32] * 10 + [_P]),
     "m355_patch_accumulate": (C.c_int, [_P, _P, _P, _P] + [_i32] * 8 + [_P]),
     "m355_patch_gather_padded": (C.c_int, [_P, _P, _P] + [_i32] * 12 + [_f32, _P]),
     "m355_patch_finalize_crop": (C.c_int, [_P, _P, _P] + [_i32] * 7 + [_P]),

@@ -292,12 +292,15 @@ def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dt
     world = dist.get_world_size(group) if (sharded and is_distributed()) else 1
     rank = dist.get_rank(group) if (sharded and is_distributed()) else 0
     per = (n_tiles + world - 1) // world
-    send = torch.zeros((per,) + tuple(tile_shape), dtype=dtype, device=device)
+    if world == 1:      # nothing to exchange: the local tiles ARE the result (no staging copy)
+        return local_out if local_out is not None else torch.zeros((0,) + tuple(tile_shape), dtype=dtype, device=device)
     n_local = len(shard_indices(n_tiles, rank, world))
-    if n_local:
-        send[:n_local] = local_out
-    if world == 1:
-        return send[:n_tiles]
+    if n_local == per and local_out is not None and local_out.is_contiguous():
+        send = local_out                        # every slot filled: send the tile buffer itself
+    else:
+        send = torch.zeros((per,) + tuple(tile_shape), dtype=dtype, device=device)
+        if n_local:
+            send[:n_local] = local_out
     if dst is None:
         recv = torch.empty((world * per,) + tuple(tile_shape), dtype=dtype, device=device)
         dist.all_gather_into_tensor(recv, send, group=group)

@@ -1942,6 +1942,23 @@ def patch_accumulate(patches, locations, accum, count):
                                   ps0, ps1, ps2, _stream()), "patch_accumulate")
 
 
+def patch_aggregate_grid(tiles, axes, volume_shape, border=(0, 0, 0)):
+    """tiles [n0*n1*n2, C, *patch] in GridSampler order over the per-axis start lists `axes` (padded coordinates) ->
+    the averaged volume [C, *volume_shape] (the padded volume's interior when `border` > 0); one pass."""
+    L = _lib.lib()
+    _require(tiles)
+    tiles = tiles.contiguous()
+    P, Cc, ps0, ps1, ps2 = tiles.shape
+    n0, n1, n2 = (len(a) for a in axes)
+    if P != n0 * n1 * n2:
+        raise _lib.M355Error(f"patch_aggregate_grid: {P} tiles for a {n0} x {n1} x {n2} grid")
+    starts = torch.tensor([int(v) for a in axes for v in a], dtype=torch.int32, device=tiles.device)
+    out = torch.empty((Cc,) + tuple(volume_shape), dtype=torch.float32, device=tiles.device)
+    check(L.m355_patch_aggregate_grid(_p(tiles), _p(starts), n0, n1, n2, _p(out), Cc, *[int(v) for v in volume_shape], ps0, ps1,
+                                      ps2, *[int(b) for b in border], _stream()), "patch_aggregate_grid")
+    return out
+
+
 def patch_finalize(accum, count):
     L = _lib.lib()
     _require(accum, count)

@@ -34,6 +34,11 @@ def grid_locations(volume_shape, patch_size, patch_overlap):
     configuration of research/msseg2/msseg2.py:139-146): per axis
     range(0, size - patch + 1, patch - overlap), plus size - patch if the border is not
     reached; patches enumerated in itertools.product order."""
+    return [tuple(c) for c in itertools.product(*grid_axes(volume_shape, patch_size, patch_overlap))]
+
+
+def grid_axes(volume_shape, patch_size, patch_overlap):
+    """the per-axis start lists whose product is `grid_locations`"""
     axes = []
     for size, p, o in zip(volume_shape, patch_size, patch_overlap):
         if p > size:
@@ -44,7 +49,7 @@ def grid_locations(volume_shape, patch_size, patch_overlap):
         if starts[-1] != size - p:
             starts.append(size - p)
         axes.append(starts)
-    return [tuple(c) for c in itertools.product(*axes)]
+    return axes
 
 
 def _triple(v):
@@ -219,7 +224,13 @@ class PatchPredict:
         t = self._stamp("exchange", t, dev)
         if tiles is None:       # result_on="rank0" and this is another rank
             return None
-        # aggregation in grid order: identical bits regardless of world size
+        # aggregation in grid order: identical bits regardless of world size.  One pass over the tile grid (per voxel:
+        # the covering tiles summed in tile order, divided by their count) where the backend has it -- no accumulator /
+        # count volumes, no zero-fill, no read-modify-write; the same bits as the batch-by-batch loop below.
+        if hasattr(k, "patch_aggregate_grid"):
+            out = k.patch_aggregate_grid(tiles, grid_axes(pshape, self.patch_size, self.patch_overlap), vshape, border)
+            self._stamp("aggregate", t, dev)
+            return out
         accum = torch.zeros((c_out,) + pshape, dtype=torch.float32, device=dev)
         count = torch.zeros(pshape, dtype=torch.float32, device=dev)
         all_loc = torch.tensor(locs, dtype=torch.int32, device=dev)

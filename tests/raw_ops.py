@@ -601,6 +601,15 @@ class RawOps:
                   "patch_gather_padded")
         return out
 
+    def patch_aggregate_grid(self, tiles, axes, vshape, border=(0, 0, 0)):
+        tiles = self.to(tiles)
+        P, Cc, ps0, ps1, ps2 = tiles.shape
+        starts = torch.tensor([v for a in axes for v in a], dtype=torch.int32, device=self.device)
+        out = self.empty(Cc, *vshape)
+        self._chk(self.fn("patch_aggregate_grid")(_p(tiles), _p(starts), len(axes[0]), len(axes[1]), len(axes[2]), _p(out), Cc,
+                                                  *vshape, ps0, ps1, ps2, *border, self._stream()), "patch_aggregate_grid")
+        return out
+
     def patch_finalize_crop(self, accum, count, border):
         accum, count = self.to(accum), self.to(count)
         Cc, P0, P1, P2 = accum.shape

@@ -1147,3 +1147,24 @@ def test_conv_transpose3d_c8_backward(hip, oracle, compute):
         dw2, db2 = hip.convt_bwd_weight_h16(x16, dy16, (N, ci, D, H, W), co, compute, unscale=0.5)
         close(dw2, dw * 0.5, 1e-6, 1e-8, "convT dw unscale")
         close(db2, db * 0.5, 1e-6, 1e-8, "convT dbias unscale")
+
+
+def test_patch_aggregate_grid_one_pass(hip, oracle):
+    """m355_patch_aggregate_grid == the oracle (bit-exact: same fp32 sums in tile order, same division) == the batch-by-batch
+    accumulate + finalize it replaces in PatchPredict (bit-exact), ragged grids with a short last step, several channels,
+    and the cropped (padded-volume) form."""
+    import itertools
+    from segmentation_pipeline_amd.prediction import grid_axes
+    for vshape, ps, ov, border in [((20, 17, 23), (8, 6, 10), (2, 2, 4), (0, 0, 0)), ((12, 12, 12), (8, 8, 8), (4, 4, 4), (2, 2, 2)),
+                                   ((9, 30, 11), (9, 7, 5), (0, 3, 1), (0, 1, 0))]:
+        pshape = tuple(v + 2 * b for v, b in zip(vshape, border))
+        axes = grid_axes(pshape, ps, ov)
+        locs = list(itertools.product(*axes))
+        tiles = rnd(len(locs), 3, *ps, seed=4)
+        got = hip.patch_aggregate_grid(tiles, axes, vshape, border)
+        ref = oracle.patch_aggregate_grid(tiles, axes, vshape, border)
+        assert torch.equal(got.cpu(), ref)
+        # the accumulate + finalize path it replaces (padded volume, then the crop)
+        old, _ = hip.patch_aggregate(tiles, torch.tensor(locs, dtype=torch.int32), pshape)
+        sl = (slice(None),) + tuple(slice(b, b + v) for b, v in zip(border, vshape))
+        assert torch.equal(got, old[sl])

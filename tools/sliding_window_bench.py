@@ -48,7 +48,7 @@ for mode in (sys.argv[1:] or ["fp32", "bf16"]):
     for _ in range(reps):
         pt.predict_volume(model, vol)
     tot = sum(timings.values()) / reps
-    serial = sum(v for k, v in timings.items() if k in ("exchange", "accumulate", "finalize")) / reps
+    serial = sum(v for k, v in timings.items() if k in ("exchange", "accumulate", "finalize", "aggregate")) / reps
     print(f"  [{mode}] phases per volume (ms): " + "  ".join(f"{k} {v / reps * 1e3:.2f}" for k, v in timings.items()) +
           f"  | total {tot * 1e3:.1f}; serial (not sharded over GPUs) {serial * 1e3:.2f} ms = {serial / tot * 100:.1f} % "
           f"-> Amdahl bound at 8 GPUs: {tot / (serial + (tot - serial) / 8):.2f}x")
