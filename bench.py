@@ -71,22 +71,31 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, precision="fp32"):
     """HBM bytes per launch of a kernel from the PMC passes of this same command (tools/pmc_collect.sh ->
-    profiles/r02_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).  PMC
+    profiles/r03_pmc_traffic[_bf16|_fp16].json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).  PMC
     counters cannot be read inside the run; the committed figure is only quoted when it was collected on
     exactly these kernel sources (source_hash), otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json" if precision == "fp32" else f"r03_pmc_traffic_{precision}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
         if doc.get("source_hash") != source_hash():
             return None
-        # "conv3_mfma_fwd_p_kernel<4, 32>" also has to find "...<4, 32, false>" (trailing template arguments)
-        stem = kernel_substr[:-1] if kernel_substr.endswith(">") else kernel_substr
+        # "conv3_mfma_fwd_p_kernel<4, 32>" also has to find "...<4, 32, false>" (trailing template arguments); the
+        # 16-bit kernels are reported with their type spelled out ("conv3_h16_kernel<4, 32, __bf16, true, 4, true>"):
+        # "conv3_h16_kernel(one-shot)<4,32>" -> name stem + leading template arguments
+        base = kernel_substr.split("(")[0].split("<")[0]
+        targs = kernel_substr[kernel_substr.index("<") + 1:].rstrip(">") if "<" in kernel_substr else ""
+        best = None
         for name, rec in doc["kernels"].items():
-            if kernel_substr in name or (stem + ",") in name:
-                return rec["hbm_bytes_per_launch"]
+            if base not in name:
+                continue
+            if targs and not (f"<{targs}>" in name or f"<{targs}," in name):
+                continue
+            if best is None or rec["launches"] > best["launches"]:
+                best = rec
+        return None if best is None else best["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -171,7 +180,7 @@ def roofline_of(prof, precision, full_prof=None, traffic=True):
         ach = nbytes / (ms * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
     # (the committed PMC passes are of the cfg2 command: quoted only for launches of that workload)
-    out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", ")) if traffic else None, "kernel": kname, "launches": n,
+    out.update({"traffic": pmc_traffic(kname.split(" ")[0].replace(",", ", "), precision) if traffic else None, "kernel": kname, "launches": n,
                 "avg_launch_ms": ms / n, "avg_gflop_per_launch": flops / n / 1e9,
                 "avg_algorithmic_mb_per_launch": nbytes / n / 1e6,
                 "time_share_of_conv": share})

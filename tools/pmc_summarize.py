@@ -14,6 +14,24 @@ import sys
 from collections import defaultdict
 
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocprofv3 prints some template instantiations mangled (_ZN4m355...)"""
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLED:
+        import shutil
+        import subprocess
+        tool = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+        try:
+            _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip() or name
+        except (OSError, subprocess.CalledProcessError):
+            _DEMANGLED[name] = name
+    return _DEMANGLED[name]
+
+
 def load(pattern):
     per = defaultdict(lambda: [0.0, 0, 0.0])  # kernel -> [sum counter, launches, sum ms]
     files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
@@ -21,7 +39,7 @@ def load(pattern):
     # pile up next to the new one -- only the newest file of a pass is this measurement
     for fn in files[-1:]:
         for r in csv.DictReader(open(fn)):
-            name = re.sub(r"\(.*", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*", "", demangle(r["Kernel_Name"]))
             rec = per[name]
             rec[0] += float(r["Counter_Value"])
             rec[1] += 1
@@ -52,7 +70,8 @@ def source_hash():
 
 def main():
     root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-    out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
+    out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
+    precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
     fetch = load(f"{root}/bench_FETCH_SIZE/**/*counter_collection.csv")
     write = load(f"{root}/bench_WRITE_SIZE/**/*counter_collection.csv")
     kernels = {}
@@ -65,7 +84,7 @@ def main():
                          "write_bytes_per_launch": wb, "avg_ms_profiled": ms / n}
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))
     doc = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on "
-                     "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer`; bytes = (2*FETCH_SIZE + "
+                     f"`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --precision {precision}`; bytes = (2*FETCH_SIZE + "
                      "WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads 1/2 for coalesced streams -- calibrated with "
                      "tools/pmc_calib.py)",
            "source_hash": source_hash(),   # bench.py quotes these figures only for exactly these kernel sources
