@@ -14,22 +14,30 @@ import sys
 from collections import defaultdict
 
 
-_DEMANGLED = {}
-
-
 def demangle(name):
-    """rocprofv3 prints some template instantiations mangled (_ZN4m355...)"""
-    if not name.startswith("_Z"):
+    """rocprofv3 prints some template instantiations of this library mangled (_ZN4m355...; the Itanium names of the
+    16-bit types, DF16b / DF16_, are unknown to its demangler): decode name + template arguments ourselves"""
+    m = re.match(r"_ZN4m355(\d+)", name)
+    if not m:
         return name
-    if name not in _DEMANGLED:
-        import shutil
-        import subprocess
-        tool = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
-        try:
-            _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip() or name
-        except (OSError, subprocess.CalledProcessError):
-            _DEMANGLED[name] = name
-    return _DEMANGLED[name]
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        i = 1
+        while i < len(rest) and rest[i] != "E":
+            if rest.startswith("DF16b", i):
+                args.append("__bf16"); i += 5
+            elif rest.startswith("DF16_", i):
+                args.append("_Float16"); i += 5
+            elif rest.startswith("Lb", i):
+                args.append("true" if rest[i + 2] == "1" else "false"); i += 4
+            elif rest.startswith("Li", i):
+                j = rest.index("E", i)
+                args.append(rest[i + 2:j].replace("n", "-")); i = j + 1
+            else:
+                args.append("?"); break
+    return f"void m355::{base}<{', '.join(args)}>" if args else f"m355::{base}"
 
 
 def load(pattern):
