@@ -2754,7 +2754,10 @@ extern "C" int m355_conv3d_bwd_weight_c8(const m355_conv3d_desc* d, const void* 
   hipStream_t st = (hipStream_t)stream;
   const int nsplit = bww_c8_nsplit(d);
   float* slab = (float*)workspace;
-  if (int rc = launch_bww_c8(d->compute, x16, dy16, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, nsplit, xbs, ybs, st))
+  // edge layers (first conv: Cin <= 4; output conv: Cout <= 4): tap and narrow channel share the MFMA column
+  const bool edge = (d->Cin <= 4 || d->Cout <= 4) && !tuning().no_small;
+  if (int rc = edge ? launch_bww_c8_small(d->compute, x16, dy16, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, nsplit, xbs, ybs, st)
+                    : launch_bww_c8(d->compute, x16, dy16, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, nsplit, xbs, ybs, st))
     return rc;
   BwwClasses kred{};
   kred.of = (int)ceil_div(d->Cout, 32);

@@ -204,6 +204,9 @@ inline int64_t splitk_c8_slots(int64_t S) { return std::max<int64_t>(1, std::min
 // weight gradient from c8 operands (tile 2 x 4 x 32 voxels); slab[split][27][Cout][Cin], summed by slab_reduce_t_kernel
 int launch_bww_c8(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
                   int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st);
+// the same for an edge layer (Cin <= 4 or Cout <= 4): narrow channel and tap share the MFMA column
+int launch_bww_c8_small(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
+                  int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st);
 
 // y[n,o,s] = bias[o] + add[n,o,s] + sum_ks slab[ks][n,o,s]   (fixed order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,

@@ -1312,6 +1312,178 @@ __global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
   }
 }
 
+// ---- the two EDGE layers of a network: Cin <= 4 (first conv) or Cout <= 4 (output conv) ----
+// conv3_bww_c8_kernel pads the narrow side to a 32-column MFMA tile: 27 MFMAs per k-step of which 1/8 of the columns
+// are real (d0.c0 / out conv of cfg2: 0.22 ms each against 0.03 ms of bytes).  Here the narrow channel AND the tap share
+// the column index, as in the fp32 kernel conv3_mfma_bww_small_kernel: column n = 4 * tau + q (tau = one of 8 taps of a
+// wave, q = narrow channel 0..3), so ONE MFMA per k-step and wave covers 8 taps and the four waves cover all 27:
+//     G[p, (tau, q)] = sum_v P[p, v] * Q[q, v + off(tau)]
+//   swap = 0 (Cin <= 4):  P = dy (wide = Cout), Q = x,                                  dW[o = p][c = q][tau]
+//   swap = 1 (Cout <= 4): P = x (wide = Cin),   Q = dy at v - off(tau) = v + off(26 - tau),  dW[o = q][c = p][tau]
+// Both operands arrive as c8.  P sits in LDS voxel-major with 64-byte rows (ds_read_b64_tr_b16 fragments as in the
+// kernel above); Q's halo tile keeps its 16-byte items, and the transposed read takes a PER-LANE address: lane (row r,
+// piece tp) of a 16-lane group points at voxel r + off(tau_tp) -- the hardware hands element e of piece tp to lane
+// 4 * tp + e, which is exactly column (tau_tp, q = e).  Channels 4..7 of Q's block are never read.
+template <typename HT>
+__global__ __launch_bounds__(256, 2) void conv3_bww_c8_small_kernel(
+    const HT* __restrict__ P16, const HT* __restrict__ Q16, float* __restrict__ slab, int N, int CBp, int CP, int CQ, int D,
+    int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit, int ptiles, int64_t pbs16, int64_t qbs16, int swap,
+    int Cin, int Cout) {
+  constexpr int TZ = 2, TY = 4, TX = 32, NV = TZ * TY * TX;          // 256 voxels
+  constexpr int HR = TX + 2, HP = (TY + 2) * HR, HVX = (TZ + 2) * HP;  // 34, 204, 816 halo voxels
+  constexpr int QPER = (HVX + 255) / 256, PPER = NV * 4 / 256;        // 16-byte items per thread: 4 and 4
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) uint4 qs[HVX + 8];  // [halo voxel]  (block 0 of Q; + slack for the dummy taps)
+  __shared__ __attribute__((aligned(16))) uint4 ps[NV * 4];   // [voxel][channel block of the tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  int vid;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int ptile = vid % ptiles, split = vid / ptiles;
+  const int iHW = H * W, S = D * iHW;
+  // staging geometry of the Q halo tile: item e = halo voxel e
+  int qrel[QPER];
+  unsigned qcode[QPER];
+#pragma unroll
+  for (int k = 0; k < QPER; ++k) {
+    const int hv = tid + 256 * k;
+    const int zz = hv / HP, r = hv - zz * HP;
+    const int yy = r / HR, xx = r - yy * HR;
+    qrel[k] = zz * iHW + yy * W + xx;
+    qcode[k] = hv < HVX ? (1u << zz) | (1u << (8 + yy)) | ((unsigned)xx << 16) : 0xffffu;
+  }
+  const int dvz = tid / (TY * TX), dvy = (tid / TX) % TY, dvx = tid % TX;   // P item k: (block k, voxel tid)
+  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
+  const int ntiles = N * tiles_per_n;
+  __amdgpu_buffer_rsrc_t rp, rq;
+  unsigned zymask = 0u;
+  int qbase = 0, pbase = 0, xlim = 0;
+  bool pok = false;
+  auto tile_setup = [&](int tile, bool live) {
+    int t = tile;
+    const int n = t / tiles_per_n;
+    t -= n * tiles_per_n;
+    const int txt = t % tx_tiles;
+    t /= tx_tiles;
+    const int tyt = t % ty_tiles, tzt = t / ty_tiles;
+    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    const int nbp = min(4, CBp - 4 * ptile);
+    rp = __builtin_amdgcn_make_buffer_rsrc((void*)(P16 + (int64_t)n * pbs16 + (int64_t)(4 * ptile) * S * 8), 0,
+                                           live ? nbp * S * 16 : 0, 0x00020000);
+    rq = __builtin_amdgcn_make_buffer_rsrc((void*)(Q16 + (int64_t)n * qbs16), 0, live ? S * 16 : 0, 0x00020000);
+    zymask = 0u;
+    for (int zz = 0; zz < TZ + 2; ++zz)
+      if (z0 + zz - 1 >= 0 && z0 + zz - 1 < D) zymask |= 1u << zz;
+    for (int yy = 0; yy < TY + 2; ++yy)
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) zymask |= 1u << (8 + yy);
+    qbase = (z0 - 1) * iHW + (y0 - 1) * W + x0 - 1;
+    xlim = x0 - 1;
+    const int gz = z0 + dvz, gy = y0 + dvy, gx = x0 + dvx;
+    pok = gz < D && gy < H && gx < W;
+    pbase = gz * iHW + gy * W + gx;
+  };
+  uint4 qr[QPER], pr[PPER];
+  auto fetch = [&]() {
+#pragma unroll
+    for (int k = 0; k < QPER; ++k) {
+      const int xx = (int)(qcode[k] >> 16);
+      const bool ok = ((qcode[k] & 0xffffu) & ~zymask) == 0u && (unsigned)(xlim + xx) < (unsigned)W;
+      qr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)(qbase + qrel[k]) * 16u : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < PPER; ++k)
+      pr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rp, pok ? (unsigned)(k * S + pbase) * 16u : OOB, 0, 0));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < QPER; ++k) {
+      const int hv = tid + 256 * k;
+      if (hv < HVX) qs[hv] = qr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PPER; ++k) ps[tid * 4 + k] = pr[k];
+  };
+  // fragment bases.  A (P tile): as conv3_bww_c8_kernel.  B (Q halo tile): this lane's piece is tap tau = 8 wave +
+  // 4 (grp & 1) + tp at voxel row 8 (grp >> 1) + tq; swap reads the mirrored tap.
+  const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int lb = (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
+  const unsigned char* pb = reinterpret_cast<const unsigned char*>(ps) + lb;
+  const int tau = min(wave * 8 + 4 * (grp & 1) + tp, 26);
+  const int tsrc = swap ? 26 - tau : tau;
+  const unsigned char* qb = reinterpret_cast<const unsigned char*>(qs) +
+                            ((tsrc / 9) * HP + ((tsrc / 3) % 3) * HR + tsrc % 3 + 8 * (grp >> 1) + tq) * 16;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (tid < 8) qs[HVX + tid] = make_uint4(0u, 0u, 0u, 0u);
+  if (split < ntiles) {
+    tile_setup(split, true);
+    fetch();
+    commit();
+  }
+  __syncthreads();
+  for (int tile = split; tile < ntiles; tile += nsplit) {
+    const bool more = tile + nsplit < ntiles;
+    tile_setup(more ? tile + nsplit : tile, more);
+    fetch();
+#pragma unroll
+    for (int r = 0; r < TZ * TY; ++r) {
+      const int z = r / TY, y = r % TY;
+#pragma unroll
+      for (int xk = 0; xk < 2; ++xk) {
+        const typename H16<HT>::x8 a = tr_frag<HT>(pb + ((z * TY + y) * TX + 16 * xk) * 64);
+        // two transposed 4-voxel pieces of this lane's tap: rows r .. r+3 and r+4 .. r+7 of its k-half (16 bytes a row)
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const unsigned char* q0 = qb + (z * HP + y * HR + 16 * xk) * 16;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 64));
+        const s16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = H16<HT>::mfma(a, __builtin_bit_cast(typename H16<HT>::x8, bv), acc);
+      }
+    }
+    __syncthreads();
+    if (more) commit();
+    __syncthreads();
+  }
+  // partial dW -> slab[split][tap][Cout][Cin]: column l32 = (tap of this wave l32 >> 2, narrow channel l32 & 3)
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
+  const int tap = wave * 8 + (l32 >> 2), q = l32 & 3;
+  if (tap < 27 && q < CQ) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pch = ptile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (pch < CP) {
+        const int o = swap ? q : pch, c = swap ? pch : q;
+        sl[((int64_t)tap * Cout + o) * Cin + c] = acc[r];
+      }
+    }
+  }
+}
+
+int launch_bww_c8_small(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
+                        int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st) {
+  const int swap = Cin <= 4 ? 0 : 1;
+  const void* P = swap ? x16 : dy16;
+  const void* Q = swap ? dy16 : x16;
+  const int CP = swap ? Cin : Cout, CQ = swap ? Cout : Cin;
+  const int64_t pbs = swap ? xbs16 : ybs16, qbs = swap ? ybs16 : xbs16;
+  const int ptiles = (int)ceil_div(CP, 32);
+  const int tz = (int)ceil_div(D, 2), ty = (int)ceil_div(H, 4), tx = (int)ceil_div(W, 32);
+  const dim3 grid((unsigned)(ptiles * nsplit));
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(conv3_bww_c8_small_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)P, (const __bf16*)Q, slab, N,
+                       (int)c8_blocks(CP), CP, CQ, D, H, W, tz, ty, tx, nsplit, ptiles, pbs, qbs, swap, Cin, Cout);
+  else
+    hipLaunchKernelGGL(conv3_bww_c8_small_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)P, (const _Float16*)Q,
+                       slab, N, (int)c8_blocks(CP), CP, CQ, D, H, W, tz, ty, tx, nsplit, ptiles, pbs, qbs, swap, Cin, Cout);
+  return check_launch("conv3_bww_c8_small");
+}
+
 int launch_bww_c8(int compute, const void* x16, const void* dy16, float* slab, int N, int Cin, int Cout, int D, int H,
                   int W, int nsplit, int64_t xbs16, int64_t ybs16, hipStream_t st) {
   const int CBin = (int)c8_blocks(Cin), CBout = (int)c8_blocks(Cout);

@@ -1048,7 +1048,8 @@ def test_conv3d_bwd_data_c8_output_and_weight_gradient_c8(hip, oracle, compute, 
     grad_unscale applied to both in the fp32 epilogue"""
     tuning(**env)
     dt = _dt(compute)
-    for (N, ci, co, D, H, W) in [(2, 16, 40, 5, 6, 36), (1, 24, 13, 6, 9, 16), (1, 4, 32, 8, 8, 32), (1, 32, 3, 4, 8, 32)]:
+    for (N, ci, co, D, H, W) in [(2, 16, 40, 5, 6, 36), (1, 24, 13, 6, 9, 16), (1, 4, 32, 8, 8, 32), (1, 32, 3, 4, 8, 32),
+                                 (2, 3, 40, 5, 7, 33), (1, 72, 2, 3, 6, 20), (1, 4, 4, 4, 4, 32)]:
         x, dy = rnd(N, ci, D, H, W, seed=1), rnd(N, co, D, H, W, seed=2)
         w = rnd(co, ci, 3, 3, 3, seed=3) * (1.0 / (27 * co) ** 0.5)
         x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
@@ -1059,7 +1060,10 @@ def test_conv3d_bwd_data_c8_output_and_weight_gradient_c8(hip, oracle, compute, 
             assert (dx16[:, -1, :, ci % 8:].float() == 0).all()
         dw0, _ = hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (D, H, W), compute)
         dw, db = hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (D, H, W), compute)
-        assert torch.equal(dw, dw0)
+        if min(ci, co) > 4:
+            assert torch.equal(dw, dw0)
+        else:   # edge layers: conv3_bww_c8_small_kernel (tap and narrow channel share the MFMA column), another sum order
+            close(dw, dw0, 2e-5, 2e-5 * dw0.abs().max().item(), "edge-layer dw vs the padded-tile kernel")
         dyr = dy.to(dt).float()
         close(db, dyr.double().sum(dim=(0, 2, 3, 4)).float(), 1e-5, 1e-4, "dbias from c8")
         dws, dbs = hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (D, H, W), compute, unscale=2.0 ** -7)
