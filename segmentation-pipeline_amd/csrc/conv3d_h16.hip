@@ -826,6 +826,94 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
   if constexpr (!ONE) queue_leave(work_counter);
 }
 
+// ---- K-channels <= 4: the first conv of a network (Cin = 4: d0.c0) and the data gradient of its output conv (dy has
+// Cout = 3 channels) ----
+// The kernel above spends a whole k-step of 16 on ONE tap of a 16-channel chunk: with <= 4 real channels 3/4 of every
+// MFMA multiplies zeros, 27 MFMAs per 32-voxel group where 7 suffice -- and the single-chunk item is all fixed cost
+// (d0.c0 forward 0.135 ms against 0.02 ms of bytes).  Here a k-step is FOUR taps x 4 channels: the B fragment of a lane
+// is two 8-byte LDS reads (channels 0..3 of the voxel at tap 4s + 2h and at tap 4s + 2h + 1), the A fragments are
+// gathered once per workgroup from the ordinary packed weights (wp[(tap*2 + half)*cout_pad + m][8], half 0, j < 4), so
+// nothing changes for the weight caches.  One output tile (4 x NTW x 32 voxels, one 32-channel tile) per workgroup, c8
+// output through store_conv_tile_c8 with the same statistics slots as the generic plan.
+template <int NTW, typename HT>
+__global__ __launch_bounds__(256, 2) void conv3_c4_h16_kernel(
+    const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias, HT* __restrict__ y16, int Cout,
+    int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int otiles, int64_t xbs16, int64_t ybs16,
+    float* __restrict__ stat) {
+  using hx8 = typename H16<HT>::x8;
+  constexpr int TZ = 4, TY = NTW, RS = 34, PS = (TY + 2) * RS, HV = (TZ + 2) * PS;
+  __shared__ __attribute__((aligned(16))) uint2 xs[HV];        // channels 0..3 of every halo voxel
+  __shared__ __attribute__((aligned(16))) uint4 ws[7 * 2 * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int sp_tiles = tz_tiles * ty_tiles * tx_tiles;
+  int it = blockIdx.x;
+  const int ot = it % otiles;
+  it /= otiles;
+  const int sp = it % sp_tiles, n = it / sp_tiles;
+  const int txt = sp % tx_tiles, tyt = (sp / tx_tiles) % ty_tiles, tzt = sp / (tx_tiles * ty_tiles);
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * 32;
+  const int iHW = H * W;
+  const int64_t S = (int64_t)D * iHW;
+  {
+    const uint4* xin = reinterpret_cast<const uint4*>(x16 + (int64_t)n * xbs16);   // block 0 only
+    for (int e = tid; e < HV; e += 256) {
+      const int zz = e / PS, r = e - zz * PS;
+      const int yy = r / RS, xx = r - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      uint2 v = make_uint2(0u, 0u);
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const uint2*>(xin + ((int64_t)gz * iHW + gy * W + gx));
+      xs[e] = v;
+    }
+    HT* w16 = reinterpret_cast<HT*>(ws);
+    for (int i = tid; i < 7 * 2 * 32 * 8; i += 256) {
+      const int j = i & 7, m = (i >> 3) & 31, h = (i >> 8) & 1, s = i >> 9;
+      const int tap = 4 * s + 2 * h + (j >> 2);
+      w16[i] = tap < 27 ? wp[((int64_t)(tap * 2) * cout_pad + ot * 32 + m) * 8 + (j & 3)] : (HT)0.f;
+    }
+  }
+  __syncthreads();
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  const uint2* xb = xs + wave * PS + l32;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const hx8 a = __builtin_bit_cast(hx8, ws[(s * 2 + half) * 32 + l32]);
+    const int ta = 4 * s + 2 * half, tb = min(ta + 1, 26);   // "tap 27" (s = 6, upper half): zero weights, any valid row
+    const int offa = (ta / 9) * PS + ((ta / 3) % 3) * RS + ta % 3;
+    const int offb = (tb / 9) * PS + ((tb / 3) % 3) * RS + tb % 3;
+#pragma unroll
+    for (int g = 0; g < NTW; ++g) {
+      const uint2 lo = xb[g * RS + offa], hi = xb[g * RS + offb];
+      const uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      acc[g] = H16<HT>::mfma(a, __builtin_bit_cast(hx8, bv), acc[g]);
+    }
+  }
+  const int z = z0 + wave, xg = x0 + l32;
+  float* st = stat ? stat + (((int64_t)n * sp_tiles + sp) * 4 + wave) * Cout * 2 : nullptr;
+  store_conv_tile_c8<NTW, 1, HT>(acc, y16 + (int64_t)n * ybs16, bias, ot * 32, Cout, z, y0, xg, 0, half, H, W, S,
+                                 z < D && xg < W, st);
+}
+
+template <typename HT>
+static bool launch_c4_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias, HT* y16, int N,
+                          int mout, int D, int H, int W, int64_t ybs16, hipStream_t st, float* stat) {
+  const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles * N;
+  if (items <= 0 || items >= (1ll << 31)) return false;
+  const dim3 grid((unsigned)items);
+#define M355_C4(NTW)                                                                                                   \
+  hipLaunchKernelGGL((conv3_c4_h16_kernel<NTW, HT>), grid, dim3(256), 0, st, x16, wp, bias, y16, mout, D, H, W, p.mout_pad, \
+                     p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles, xbs16, ybs16, stat)
+  if (p.ntw == 4) M355_C4(4); else if (p.ntw == 2) M355_C4(2); else if (p.ntw == 1) M355_C4(1); else return false;
+#undef M355_C4
+  return true;
+}
+
 template <int NTW, int GX, typename HT>
 static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
@@ -912,6 +1000,10 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
   if (!prepacked) pack_w3_h16_t<HT>(p, w, wpb, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
+  // edge layers with <= 4 K-channels and a c8 output: four taps per k-step (conv3_c4_h16_kernel)
+  if (kin <= 4 && out16 && p.ksplit == 1 && p.gx == 32 && p.nw == 4 && !softmax && !tuning().no_small &&
+      launch_c4_h16<HT>(p, in16, in16_bs, wpb, kb, (HT*)out, N, mout, D, H, W, out_bs, st, stat))
+    return check_launch("conv3_c4_h16");
 #define M355_H16_CASE(NTW, GX)                                                                               \
   if (p.ntw == NTW && p.gx == GX) {                                                                          \
     launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st,       \
