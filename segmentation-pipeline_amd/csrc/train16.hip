@@ -387,7 +387,8 @@ extern "C" int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, in
   M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE, "norm_act_bwd_c8: workspace too small");
   const int64_t dense = c8_blocks(d->C) * d->S * 8;
   const int64_t xbs = dense_or(x16_batch_stride, dense), ybs = dense_or(dy16_batch_stride, dense);
-  const int64_t dxbs = dense_or(dx16_batch_stride, dense), pbs = dense_or(dpool16_batch_stride, dense / 8);
+  const int64_t dxbs = dense_or(dx16_batch_stride, dense);
+  const int64_t pbs = dpool16 ? dense_or(dpool16_batch_stride, c8_blocks(d->C) * (d->S / 8) * 8) : 0;   // (pooled: S / 8 voxels)
   M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)dpool16 | (uintptr_t)dx16) & 15) == 0 && xbs % 8 == 0 &&
                    ybs % 8 == 0 && dxbs % 8 == 0 && pbs % 8 == 0, M355_EINVALID_ARG, "norm_act_bwd_c8: c8 tensor not 16B aligned");
   hipStream_t st = (hipStream_t)stream;

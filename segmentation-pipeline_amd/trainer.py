@@ -82,6 +82,75 @@ def train_step(model, criterion, optimizer, predictor, batch, device, timer: Opt
     return loss_dict, batch
 
 
+class GraphedTrainStep:
+    """One training iteration (train() -> forward -> criterion -> zero_grad -> backward -> optimizer.step, the order of
+    segmentation_trainer.py:162-180) captured ONCE into a hipGraph and replayed: one launch per step instead of the
+    ~400 of a production architecture.  Where the step is host-bound -- msseg2 in the 16-bit modes: the GPU needs
+    ~8 ms, the Python / ctypes enqueue ~10 ms -- the replay runs at GPU speed; where it is GPU-bound (cfg2, fp32
+    anything) it changes nothing.  The loss trajectory is bit-identical to the eager loop (tests).
+
+    Works because every launch of the library goes to the current stream, workspaces come from torch's allocator (the
+    graph's private pool during capture), the packed weights are refreshed by a kernel that is part of the captured
+    step (the capture starts right after an eager optimizer step, when every packed form is stale), and the work-queue
+    state lives in the per-stream pool of the library.  Static shapes: batches are copied into the captured input
+    buffers.  Not capturable (raises): active Dropout3d (host-side mask draw), BatchNorm with momentum=None (host
+    read of num_batches_tracked), a PatchParallel wrapper (collectives), optimizers that read state on the host
+    (use capturable=True for Adam)."""
+
+    def __init__(self, model, criterion, optimizer, warmup: int = 3):
+        self.model, self.criterion, self.optimizer, self.warmup = model, criterion, optimizer, max(1, warmup)
+        self._graphs = {}
+
+    def _check(self):
+        from torch import nn
+        if isinstance(self.model, D.PatchParallel):
+            raise NotImplementedError("GraphedTrainStep: capture the wrapped module, not the PatchParallel wrapper")
+        for m in self.model.modules():
+            if isinstance(m, nn.Dropout3d) and m.p > 0:
+                raise NotImplementedError("GraphedTrainStep: Dropout3d draws its mask on the host")
+            if isinstance(m, nn.BatchNorm3d) and m.momentum is None and m.track_running_stats:
+                raise NotImplementedError("GraphedTrainStep: BatchNorm3d(momentum=None) reads num_batches_tracked on the host")
+
+    def _eager(self, x, y):
+        self.optimizer.zero_grad(set_to_none=True)
+        ld = self.criterion(self.model(x), y)
+        ld["loss"].backward()
+        self.optimizer.step()
+        return ld
+
+    def __call__(self, batch):
+        """batch: {"X": ..., "y": ...} device tensors -> loss dict (tensors valid until the next call)"""
+        from . import ops
+        x, y = batch["X"], batch["y"]
+        self.model.train()
+        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, ops.get_precision())
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._check()
+            sx, sy = x.clone(), y.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):          # eager steps: optimizer state, caches, allocator (they DO train)
+                    ld = self._eager(sx, sy)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            out = {k: v.detach().clone() for k, v in ld.items()}
+            graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                ld = self.criterion(self.model(sx), sy)
+                ld["loss"].backward()
+                self.optimizer.step()
+            self._graphs[key] = (graph, sx, sy, {k: v.detach() for k, v in ld.items()})
+            self.steps_done = self.warmup
+            return out                                # (the result of the last warm-up step; the capture did not execute)
+        graph, sx, sy, static = ent
+        sx.copy_(x)
+        sy.copy_(y)
+        graph.replay()
+        return {k: v.clone() for k, v in static.items()}
+
+
 class TrainLoop:
     """The iteration loop of SegmentationTrainer.train (segmentation_trainer.py:162-280) around
     `train_step`, without the torchio / logger plumbing: max_iterations, wall-clock budget with the

@@ -1099,7 +1099,7 @@ def test_norm_act_bwd_c8(hip, oracle, compute):
     GroupNorm / BatchNorm geometry, ReLU / LeakyReLU / none, N = 2, ragged channel counts, eval mode."""
     dt = _dt(compute)
     cases = [(2, 16, 4, 6, 8, 4, 1, 1, "both"), (1, 12, 2, 4, 6, 0, 2, 1, "dy"), (1, 40, 4, 4, 32, 8, 1, 1, "pool"),
-             (2, 13, 2, 6, 8, 0, 1, 0, "both"), (1, 8, 34, 32, 32, 2, 0, 1, "dy")]
+             (2, 13, 2, 6, 8, 0, 1, 0, "both"), (1, 8, 34, 32, 32, 2, 0, 1, "dy"), (2, 120, 3, 3, 3, 0, 1, 1, "dy")]
     for (N, Cc, D, H, W, groups, act, training, src) in cases:
         x, dy = rnd(N, Cc, D, H, W, seed=1), rnd(N, Cc, D, H, W, seed=6)
         dp = rnd(N, Cc, D // 2, H // 2, W // 2, seed=7)
@@ -1190,3 +1190,46 @@ def test_patch_aggregate_grid_one_pass(hip, oracle):
         old, _ = hip.patch_aggregate(tiles, torch.tensor(locs, dtype=torch.int32), pshape)
         sl = (slice(None),) + tuple(slice(b, b + v) for b, v in zip(border, vshape))
         assert torch.equal(got, old[sl])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_c8_training_flow_residual_blur_batchnorm_architecture(golden, mode):
+    """The msseg2 family (residual blocks, BatchNorm, BlurConv3d / BlurConvTranspose3d, class weights [1, 100]) through the
+    c8-only training flow: the Blur convolutions have no c8 kernel and join through the differentiable unpack / pack
+    functions (odd voxel counts on the deep levels included).  Against the reference's fp32 golden: probabilities within the
+    mode's tolerance, every parameter gradient in the reference's direction, and close to the round-2 twin flow."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd import ops
+    from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+    from test_model_gpu import BUILDERS
+    g = golden("unet_res_blur.npz")
+
+    def run():
+        model = BUILDERS["unet_res_blur.npz"][0]()
+        model.load_state_dict(g.state_dict("m.sd."))
+        model = model.cuda().train()
+        with sp.precision(mode):
+            p = model(g.t("x").cuda())
+            ld = HybridLogisticDiceLoss(logistic_class_weights=[1, 100])(p, g.t("y").cuda())
+            ld["loss"].backward()
+        return p.detach().cpu(), {k: v.grad.cpu().double().flatten() for k, v in model.named_parameters() if v.grad is not None}
+    p, grads = run()
+    try:
+        ops.H16_TRAIN_C8ONLY = False
+        p_twin, grads_twin = run()
+    finally:
+        ops.H16_TRAIN_C8ONLY = True
+    tol = 2e-2 if mode == "bf16" else 5e-3
+    assert (p - g.t("m.probs_train")).abs().max().item() <= tol
+    assert (p - p_twin).abs().max().item() <= tol
+    assert set(grads) == set(grads_twin)
+    dot = na = nb = 0.0
+    for k, got in grads.items():
+        ref = g.t(f"m.grad.{k}").double().flatten()
+        assert torch.isfinite(got).all(), k
+        if ref.norm() < 1e-9 * max(r.norm() for r in grads.values()):
+            continue      # (a conv bias in front of BatchNorm: analytically zero)
+        cos = float(got @ ref / (got.norm() * ref.norm() + 1e-300))
+        assert cos >= (0.9 if mode == "bf16" else 0.97), (k, cos)
+        dot, na, nb = dot + float(got @ ref), na + float(got @ got), nb + float(ref @ ref)
+    assert dot / (na * nb) ** 0.5 >= (0.995 if mode == "bf16" else 0.9995)

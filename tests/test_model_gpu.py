@@ -356,6 +356,51 @@ def test_packed_weights_are_shared_across_input_shapes():
     assert sorted(k[0] for k in conv_w._m355_packed[2]) == [0, 1]
 
 
+@pytest.mark.parametrize("mode,norm", [("fp32", "group"), ("bf16", "group"), ("bf16", "batch")])
+def test_graphed_train_step_reproduces_the_eager_trajectory(mode, norm):
+    """trainer.GraphedTrainStep: the whole training iteration replayed from a hipGraph -- losses, final weights and
+    BatchNorm running statistics bit-identical to the eager loop over 8 steps with changing batches (fp32, and the c8
+    training flow of the 16-bit modes incl. the batched weight re-pack inside the captured step)."""
+    import copy
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    bp = dict(GN8) if norm == "group" else {}
+    m_e = ModularUNet(4, 3, [8, 16], 2, block_params=bp, **CONVT).cuda().train()
+    m_g = copy.deepcopy(m_e)
+    g = torch.Generator().manual_seed(21)
+    batches = []
+    for _ in range(8):
+        x = torch.randn((2, 4, 16, 16, 16), generator=g)
+        lab = torch.randint(0, 3, (2, 16, 16, 16), generator=g)
+        batches.append({"X": x.cuda(), "y": torch.nn.functional.one_hot(lab, 3).permute(0, 4, 1, 2, 3).float().contiguous().cuda()})
+    crit = HybridLogisticDiceLoss()
+    with sp.precision(mode):
+        opt_e = torch.optim.SGD(m_e.parameters(), lr=1e-2, momentum=0.9)
+        opt_g = torch.optim.SGD(m_g.parameters(), lr=1e-2, momentum=0.9)
+        step = GraphedTrainStep(m_g, crit, opt_g, warmup=3)
+        losses_e, losses_g = [], []
+        # the graphed stepper spends its first call on 3 eager warm-up steps of batch 0: mirror that
+        for _ in range(3):
+            opt_e.zero_grad(set_to_none=True)
+            ld = crit(m_e(batches[0]["X"]), batches[0]["y"])
+            ld["loss"].backward()
+            opt_e.step()
+        losses_e.append(ld["loss"].detach().clone())
+        losses_g.append(step(batches[0])["loss"])
+        for b in batches[1:]:
+            opt_e.zero_grad(set_to_none=True)
+            ld = crit(m_e(b["X"]), b["y"])
+            ld["loss"].backward()
+            opt_e.step()
+            losses_e.append(ld["loss"].detach().clone())
+            losses_g.append(step(b)["loss"])
+    assert torch.equal(torch.stack(losses_e), torch.stack(losses_g))
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert len(step._graphs) == 1
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_two_streams_over_one_model_run_concurrently(tuning, mode):
     """the work-queue state of the queue-driven conv kernels used to live in the tail of the packed-

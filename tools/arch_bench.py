@@ -29,8 +29,16 @@ def run(name, model, shape, ncls, cw=None, steps=10, warmup=3):
         for _ in range(steps): model(x)
         t_hinf = (time.perf_counter() - t0) / steps
         torch.cuda.synchronize(); t_inf = (time.perf_counter() - t0) / steps
+    # the same iteration replayed from a hipGraph (trainer.GraphedTrainStep): where the eager step is host-bound
+    from segmentation_pipeline_amd.trainer import GraphedTrainStep
+    gs = GraphedTrainStep(model, crit, opt, warmup=1)
+    batch = {"X": x, "y": y}
+    gs(batch); gs(batch)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): gs(batch)
+    torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / steps
     print(f"{name}: train {t_train*1e3:.1f} ms/step ({shape[0]/t_train:.2f} patches/s), infer {t_inf*1e3:.1f} ms ({shape[0]/t_inf:.2f} patches/s)"
-          f" [host enqueue {t_host*1e3:.1f} / {t_hinf*1e3:.1f} ms]", flush=True)
+          f" [host enqueue {t_host*1e3:.1f} / {t_hinf*1e3:.1f} ms]; train step replayed from a hipGraph {t_graph*1e3:.1f} ms/step", flush=True)
 
 only = sys.argv[1] if len(sys.argv) > 1 else ""   # "msseg2" / "dmri_hippo" / "all": run one of the two (profiling)
 only = "" if only == "all" else only
