@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer table of the conv launches (ops.CONV_PROFILE) of one train step of the two architectures the reference
 trained (tools/arch_bench.py): launches grouped by (op, GFLOP, algorithmic MB, plan), mean ms, TFLOP/s.
-usage: python tools/layer_table.py [msseg2|dmri_hippo|cfg2]"""
+usage: python tools/layer_table.py [msseg2|dmri_hippo|cfg2] [fp32|bf16|fp16]"""
 import os
 import sys
 import torch
@@ -11,6 +11,8 @@ from segmentation_pipeline_amd.models import ModularUNet, NestedResUNet, BlurCon
 from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "msseg2"
+if len(sys.argv) > 2:
+    ops.set_precision(sys.argv[2])
 torch.manual_seed(0)
 if which == "msseg2":
     model = ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
@@ -57,7 +59,7 @@ for (tag, flops, e0, e1, plan, nbytes) in prof:
 # per launch: the MEDIAN over the steps (an event pair also spans host-side stalls between the two records)
 groups = {k: [statistics.median(v) * len(v), len(v)] for k, v in samples.items()}
 tot = sum(g[0] for g in groups.values()) / STEPS
-print(f"{which}: conv launches of one train step, {tot:.2f} ms (event-timed, includes packing / reductions)")
+print(f"{which} [{ops.get_precision()}]: conv launches of one train step, {tot:.2f} ms (event-timed, includes packing / reductions)")
 for (tag, gf, mb, plan), (ms, n) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
     print(f"  {tag:18s} {gf:8.2f} GF {mb:7.1f} MB plan {str(plan):18s} x{n // STEPS:<3d} {ms / n:7.3f} ms  {gf / (ms / n):7.1f} TF/s  "
           f"{ms / STEPS:7.2f} ms/step")
