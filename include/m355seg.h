@@ -373,6 +373,18 @@ int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_b
 int m355_avgpool3d_2x_bwd_h16(const void* dpool16, const void* dskip16, void* dx16, int32_t N, int32_t C, int32_t D,
                               int32_t H, int32_t W, int64_t dpool16_batch_stride, int64_t dskip16_batch_stride,
                               int64_t dx16_batch_stride, int32_t compute, void* stream);
+/* nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True) c8 -> c8 and its (gather-form, deterministic)
+ * backward: the `up` of NestedResUNet (segmentation_pipeline/models/nested_residual_unet.py:74,92-101) in the c8
+ * flow.  D, H, W: the LOW-resolution size; fp32 interpolation with ATen's align_corners weights, one rounding. */
+int m355_upsample_trilinear2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                      int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
+int m355_upsample_trilinear2x_bwd_h16(const void* dy16, void* dx16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                      int64_t dy16_batch_stride, int64_t dx16_batch_stride, int32_t compute,
+                                      void* stream);
+/* y16[n][c][s] = x16[n][c][s] * scale[n * C + c]: nn.Dropout3d on a c8 activation (nested_residual_unet.py:43-44,
+ * components.py:70-71) and its backward (the same call on the gradient); saturating for fp16. */
+int m355_act16_channel_scale(const void* x16, const float* scale, void* y16, int32_t N, int32_t C, int64_t S,
+                             int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
 /* nn.ConvTranspose3d(kernel_size=2, stride=2) backward from c8 operands on the 16-bit matrix core (operands rounded to
  * the 16-bit type, fp32 accumulate): dx16 (desc->Cin channels, c8) from dy16 (desc->Cout channels at twice the
  * resolution); dw fp32 [Cin][Cout][2][2][2] and dbias (may be NULL), both multiplied by grad_unscale.

@@ -7,6 +7,7 @@
 // (modular_unet.py:97), Dropout3d and the residual add of Block3d
 // (models/components.py:58-60,67-71), StochasticMatrix softmax (components.py:170-185).
 #include "common.hpp"
+#include "h16.hpp"
 
 namespace m355 {
 
@@ -423,6 +424,125 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ src,
   }
 }
 
+// ------------------------------------------------- trilinear upsample / channel scale on the c8 layout (h16.hpp)
+// NestedResUNet (models/nested_residual_unet.py:74,92-101) in a 16-bit precision mode: activations and their gradients
+// only exist as c8 items (8 channels of a voxel = 16 bytes), so a thread computes ONE output voxel for 8 channels --
+// index decomposition and interpolation weights are shared by the 8 -- in fp32 with the same expressions as
+// trilinear2_fwd_kernel, and rounds once.  grid-stride over N * CB * output voxels.
+template <typename HT>
+__global__ __launch_bounds__(256) void trilinear2_fwd_c8_kernel(const HT* __restrict__ x16, HT* __restrict__ y16, int N,
+                                                                int CB, int D, int H, int W, int64_t xbs, int64_t ybs) {
+  using hx8 = typename H16<HT>::x8;
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const int64_t S = (int64_t)D * H * W, OS = S * 8;
+  const int64_t total = (int64_t)N * CB * OS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ox = (int)(i % OW);
+    int64_t r = i / OW;
+    const int oy = (int)(r % OH);
+    r /= OH;
+    const int oz = (int)(r % OD);
+    r /= OD;
+    const int cb = (int)(r % CB);
+    const int n = (int)(r / CB);
+    const Lin lz = lin_coord(oz, D, OD), ly = lin_coord(oy, H, OH), lx = lin_coord(ox, W, OW);
+    const hx8* xp = reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs) + (int64_t)cb * S;
+    float row[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const hx8* p = xp + ((int64_t)((q & 2) ? lz.i1 : lz.i0) * H + ((q & 1) ? ly.i1 : ly.i0)) * W;
+      const hx8 a = p[lx.i0], b = p[lx.i1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[q][j] = lx.l0 * (float)a[j] + lx.l1 * (float)b[j];
+    }
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v0 = ly.l0 * row[0][j] + ly.l1 * row[1][j];
+      const float v1 = ly.l0 * row[2][j] + ly.l1 * row[3][j];
+      o[j] = (HT)(lz.l0 * v0 + lz.l1 * v1);
+    }
+    (reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs) + (int64_t)cb * OS)[((int64_t)oz * OH + oy) * OW + ox] = o;
+  }
+}
+
+// gather-form backward on c8 gradients (deterministic; window as in trilinear2_bwd_kernel): fp32 sums, one rounding
+// (saturating for fp16, whose gradients carry the loss scale).
+template <typename HT>
+__global__ __launch_bounds__(256) void trilinear2_bwd_c8_kernel(const HT* __restrict__ dy16, HT* __restrict__ dx16, int N,
+                                                                int CB, int D, int H, int W, int64_t dybs, int64_t dxbs) {
+  using hx8 = typename H16<HT>::x8;
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const int64_t S = (int64_t)D * H * W, OS = S * 8;
+  const int64_t total = (int64_t)N * CB * S;
+  const float rz = lin_ratio(D, OD), ry = lin_ratio(H, OH), rx = lin_ratio(W, OW);
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ix = (int)(i % W);
+    int64_t r = i / W;
+    const int iy = (int)(r % H);
+    r /= H;
+    const int iz = (int)(r % D);
+    r /= D;
+    const int cb = (int)(r % CB);
+    const int n = (int)(r / CB);
+    const hx8* dp = reinterpret_cast<const hx8*>(dy16 + (int64_t)n * dybs) + (int64_t)cb * OS;
+    float wx[8], wy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wx[k] = lin_weight(2 * ix - 3 + k, ix, W, OW, rx);
+      wy[k] = lin_weight(2 * iy - 3 + k, iy, H, OH, ry);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kz = 0; kz < 8; ++kz) {
+      const int oz = 2 * iz - 3 + kz;
+      const float wz = lin_weight(oz, iz, D, OD, rz);
+      if (wz == 0.f) continue;
+#pragma unroll
+      for (int ky = 0; ky < 8; ++ky) {
+        if (wy[ky] == 0.f) continue;
+        const int oy = 2 * iy - 3 + ky;
+        const hx8* row = dp + ((int64_t)oz * OH + oy) * OW;
+        const float wzy = wz * wy[ky];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (wx[k] == 0.f) continue;
+          const hx8 g = row[2 * ix - 3 + k];
+          const float w = wzy * wx[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, (float)g[j], acc[j]);
+        }
+      }
+    }
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = to_h16_sat<HT>(acc[j]);
+    (reinterpret_cast<hx8*>(dx16 + (int64_t)n * dxbs) + (int64_t)cb * S)[((int64_t)iz * H + iy) * W + ix] = o;
+  }
+}
+
+// y16[n][c][s] = x16[n][c][s] * scale[n * C + c]   (nn.Dropout3d on a c8 activation, and its backward)
+template <typename HT>
+__global__ __launch_bounds__(256) void channel_scale_c8_kernel(const HT* __restrict__ x16, const float* __restrict__ scale,
+                                                               HT* __restrict__ y16, int N, int C, int CB, int64_t S,
+                                                               int64_t xbs, int64_t ybs) {
+  using hx8 = typename H16<HT>::x8;
+  const int64_t total = (int64_t)N * CB * S;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int64_t s = i % S;
+    const int64_t r = i / S;
+    const int cb = (int)(r % CB);
+    const int n = (int)(r / CB);
+    const hx8 v = (reinterpret_cast<const hx8*>(x16 + (int64_t)n * xbs) + (int64_t)cb * S)[s];
+    hx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      o[j] = to_h16_sat<HT>(c < C ? (float)v[j] * scale[(int64_t)n * C + c] : 0.f);
+    }
+    (reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs) + (int64_t)cb * S)[s] = o;
+  }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -550,6 +670,68 @@ extern "C" int m355_upsample_trilinear2x_bwd(const float* dy, float* dx, int32_t
   hipLaunchKernelGGL(trilinear2_bwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, N, C, D, H, W, dybs, dxbs);
   return check_launch("upsample_trilinear2x_bwd");
+}
+
+static int check_c8_op(const char* who, const void* a, const void* b, int N, int C, int D, int H, int W, int compute,
+                       int64_t abs16, int64_t bbs16) {
+  M355_REQUIRE(a && b, M355_EINVALID_ARG, "%s: null pointer", who);
+  M355_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, M355_EINVALID_ARG, "%s: non-positive dimension", who);
+  M355_REQUIRE(compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16, M355_EINVALID_ARG,
+               "%s: compute must be M355_COMPUTE_BF16 or M355_COMPUTE_F16", who);
+  M355_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0 && abs16 % 8 == 0 && bbs16 % 8 == 0, M355_EINVALID_ARG,
+               "%s: c8 tensor not 16B aligned", who);
+  return M355_OK;
+}
+
+extern "C" int m355_upsample_trilinear2x_fwd_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H,
+                                                 int32_t W, int64_t x16_batch_stride, int64_t y16_batch_stride,
+                                                 int32_t compute, void* stream) {
+  const int CB = (int)c8_blocks(C);
+  const int64_t S = (int64_t)D * H * W;
+  const int64_t xbs = dense_or(x16_batch_stride, CB * S * 8), ybs = dense_or(y16_batch_stride, CB * S * 64);
+  if (int rc = check_c8_op("upsample_trilinear2x_fwd_h16", x16, y16, N, C, D, H, W, compute, xbs, ybs)) return rc;
+  const int64_t total = (int64_t)N * CB * S * 8;
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(trilinear2_fwd_c8_kernel<__bf16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)x16, (__bf16*)y16, N, CB, D, H, W, xbs, ybs);
+  else
+    hipLaunchKernelGGL(trilinear2_fwd_c8_kernel<_Float16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)x16, (_Float16*)y16, N, CB, D, H, W, xbs, ybs);
+  return check_launch("upsample_trilinear2x_fwd_h16");
+}
+
+extern "C" int m355_upsample_trilinear2x_bwd_h16(const void* dy16, void* dx16, int32_t N, int32_t C, int32_t D, int32_t H,
+                                                 int32_t W, int64_t dy16_batch_stride, int64_t dx16_batch_stride,
+                                                 int32_t compute, void* stream) {
+  const int CB = (int)c8_blocks(C);
+  const int64_t S = (int64_t)D * H * W;
+  const int64_t dybs = dense_or(dy16_batch_stride, CB * S * 64), dxbs = dense_or(dx16_batch_stride, CB * S * 8);
+  if (int rc = check_c8_op("upsample_trilinear2x_bwd_h16", dy16, dx16, N, C, D, H, W, compute, dybs, dxbs)) return rc;
+  const int64_t total = (int64_t)N * CB * S;
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(trilinear2_bwd_c8_kernel<__bf16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)dy16, (__bf16*)dx16, N, CB, D, H, W, dybs, dxbs);
+  else
+    hipLaunchKernelGGL(trilinear2_bwd_c8_kernel<_Float16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)dy16, (_Float16*)dx16, N, CB, D, H, W, dybs, dxbs);
+  return check_launch("upsample_trilinear2x_bwd_h16");
+}
+
+extern "C" int m355_act16_channel_scale(const void* x16, const float* scale, void* y16, int32_t N, int32_t C, int64_t S,
+                                        int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute,
+                                        void* stream) {
+  const int CB = (int)c8_blocks(C);
+  const int64_t xbs = dense_or(x16_batch_stride, CB * S * 8), ybs = dense_or(y16_batch_stride, CB * S * 8);
+  M355_REQUIRE(scale && S > 0, M355_EINVALID_ARG, "act16_channel_scale: null scale or empty tensor");
+  if (int rc = check_c8_op("act16_channel_scale", x16, y16, N, C, 1, 1, 1, compute, xbs, ybs)) return rc;
+  const int64_t total = (int64_t)N * CB * S;
+  if (compute == M355_COMPUTE_BF16)
+    hipLaunchKernelGGL(channel_scale_c8_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x16, scale, (__bf16*)y16, N, C, CB, S, xbs, ybs);
+  else
+    hipLaunchKernelGGL(channel_scale_c8_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x16, scale, (_Float16*)y16, N, C, CB, S, xbs, ybs);
+  return check_launch("act16_channel_scale");
 }
 
 extern "C" int m355_softmax_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t inner,

@@ -34,6 +34,17 @@ struct H16<_Float16> {
   }
 };
 
+template <typename HT>
+__device__ __forceinline__ HT to_h16_sat(float v);
+template <>
+__device__ __forceinline__ __bf16 to_h16_sat<__bf16>(float v) { return (__bf16)v; }
+template <>
+__device__ __forceinline__ _Float16 to_h16_sat<_Float16>(float v) {
+  // a scaled gradient past the fp16 range saturates instead of becoming inf (which would turn every downstream sum
+  // into NaN); NaN stays NaN
+  return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+}
+
 static inline int64_t c8_blocks(int64_t C) { return (C + 7) / 8; }
 
 // fp32 NCDHW -> c8 (round to nearest even) and back; implemented in conv3d_h16.hip

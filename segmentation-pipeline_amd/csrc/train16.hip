@@ -29,17 +29,6 @@ __device__ __forceinline__ float act16_grad_t(float pre, int act, float slope) {
   return 1.f;
 }
 
-template <typename HT>
-__device__ __forceinline__ HT to_h16_sat(float v);
-template <>
-__device__ __forceinline__ __bf16 to_h16_sat<__bf16>(float v) { return (__bf16)v; }
-template <>
-__device__ __forceinline__ _Float16 to_h16_sat<_Float16>(float v) {
-  // a scaled gradient past the fp16 range saturates instead of becoming inf (which would turn every downstream sum
-  // into NaN); NaN stays NaN
-  return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-}
-
 // ---------------------------------------------------------------- scaled layout conversion
 template <typename HT>
 __global__ __launch_bounds__(256) void pack_act16_scaled_kernel(const float* __restrict__ x, HT* __restrict__ x16, int C,

@@ -324,7 +324,7 @@ class Block3d(nn.Module):
         drop = self.dropout is not None and self.training and self.dropout.p > 0.0
         final_out = None if drop else out
         flow = ops.h16_flow()
-        c8_out = bool(flow) and not drop and (c8_out or (out is not None and out.buf16 is not None))
+        c8_out = bool(flow) and (c8_out or (out is not None and out.buf16 is not None))
         last_norm = (getattr(self.layers, f'norm{self._num_convs - 1}', None) is not None or
                      getattr(self.layers, f'activation{self._num_convs - 1}', None) is not None) if self._num_convs else False
         # the residual branch is added inside the last norm/act pass: in the c8 flow it is a c8 tensor too
@@ -361,9 +361,7 @@ class Block3d(nn.Module):
             # Dropout3d: whole channels zeroed with probability p, survivors scaled by 1/(1-p)
             p = self.dropout.p
             noise = torch.empty(h.shape[0] * h.shape[1], device=h.device).bernoulli_(1.0 - p).div_(1.0 - p)
-            h = ops.channel_scale(h, noise)
-            if out is not None:
-                h = ops.copy_into(h, out)
+            h = ops.channel_scale(h, noise, out=out)     # (a c8 activation stays c8, scaled into its slot)
         return h
 
 

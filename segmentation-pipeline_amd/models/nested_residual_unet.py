@@ -37,20 +37,20 @@ class NestedResUNet(nn.Module):
             if dropout_p != 0.0:
                 self.dropout = nn.Dropout3d(p=dropout_p)
 
-        def forward(self, x, out: Optional[ops.OutSlot] = None):
-            res = run_conv(self.res_conv, x) if self.residual else None
+        def forward(self, x, out: Optional[ops.OutSlot] = None, c8: int = 0):
+            """`c8`: 16-bit compute code -> `x`, every intermediate and the result are c8 activations (ops.Act16)"""
+            res = run_conv(self.res_conv, x, c8_out=bool(c8)) if self.residual else None
             drop = self.dropout is not None and self.training and self.dropout.p > 0.0
             s1 = {} if wants_batch_stats(self.bn1) else None
-            h = run_norm_act(self.bn1, self.activation1, run_conv(self.conv1, x, stats=s1), stats=s1)
+            h = run_norm_act(self.bn1, self.activation1, run_conv(self.conv1, x, stats=s1, c8_out=bool(c8)), stats=s1, c8=c8)
             s2 = {} if wants_batch_stats(self.bn2) else None
-            h = run_norm_act(self.bn2, self.activation2, run_conv(self.conv2, h, stats=s2), stats=s2, add=res,
-                             out=None if drop else out)
+            h = run_norm_act(self.bn2, self.activation2, run_conv(self.conv2, h, stats=s2, c8_out=bool(c8)), stats=s2,
+                             add=res, out=None if drop else out, c8=c8)
             if drop:
+                # Dropout3d: whole channels zeroed with probability p, survivors scaled by 1/(1-p); written into the slot
                 p = self.dropout.p
                 noise = torch.empty(h.shape[0] * h.shape[1], device=h.device).bernoulli_(1.0 - p).div_(1.0 - p)
-                h = ops.channel_scale(h, noise)
-                if out is not None:
-                    h = ops.copy_into(h, out)
+                h = ops.channel_scale(h, noise, out=out)
             return h
 
     def __init__(
@@ -97,10 +97,20 @@ class NestedResUNet(nn.Module):
         N = x.shape[0]
         sp = [tuple(s >> lvl for s in x.shape[2:]) for lvl in range(4)]
 
+        # 16-bit precision modes: activations (and, while training, their gradients) live only in the c8 layout the conv
+        # kernels read (ops.Act16); the concat buffers are c8 buffers whose slots start at multiples of 8 channels
+        flow = ops.h16_flow() if F % 8 == 0 else 0
+        if flow:
+            x = ops.pack_act16(x, flow)
+
         def buf(parts, lvl):
+            if flow:
+                return ops.Act16.empty(N, F * parts, sp[lvl], flow, x.device)
             return torch.empty((N, F * parts) + sp[lvl], dtype=x.dtype, device=x.device)
 
         def slot(b, i):
+            if flow:
+                return ops.OutSlot(None, F * i, F * (i + 1), buf16=b)
             return ops.OutSlot(b, F * i, F * (i + 1))
 
         down, up = ops.avgpool3d_2x, ops.upsample_trilinear2x
@@ -109,18 +119,21 @@ class NestedResUNet(nn.Module):
         b11, b12 = buf(3, 1), buf(3, 1)
         b21 = buf(3, 2)
 
-        x0_0 = self.conv0_0(x, out=slot(b01, 0))
-        x1_0 = self.conv1_0(down(x0_0), out=slot(b11, 0))
-        x0_1 = self.conv0_1(ops.Concat(b01, [x0_0, up(x1_0, out=slot(b01, 1))]), out=slot(b02, 0))
+        x0_0 = self.conv0_0(x, out=slot(b01, 0), c8=flow)
+        x1_0 = self.conv1_0(down(x0_0), out=slot(b11, 0), c8=flow)
+        x0_1 = self.conv0_1(ops.Concat(b01, [x0_0, up(x1_0, out=slot(b01, 1))]), out=slot(b02, 0), c8=flow)
 
-        x2_0 = self.conv2_0(down(x1_0), out=slot(b21, 0))
+        x2_0 = self.conv2_0(down(x1_0), out=slot(b21, 0), c8=flow)
         x1_1 = self.conv1_1(ops.Concat(b11, [x1_0, up(x2_0, out=slot(b11, 1)), down(x0_1, out=slot(b11, 2))]),
-                            out=slot(b12, 0))
-        x0_2 = self.conv0_2(ops.Concat(b02, [x0_1, up(x1_1, out=slot(b02, 1))]), out=slot(b03, 0))
+                            out=slot(b12, 0), c8=flow)
+        x0_2 = self.conv0_2(ops.Concat(b02, [x0_1, up(x1_1, out=slot(b02, 1))]), out=slot(b03, 0), c8=flow)
 
-        x3_0 = self.conv3_0(down(x2_0))
-        x2_1 = self.conv2_1(ops.Concat(b21, [x2_0, up(x3_0, out=slot(b21, 1)), down(x1_1, out=slot(b21, 2))]))
-        x1_2 = self.conv1_2(ops.Concat(b12, [x1_1, up(x2_1, out=slot(b12, 1)), down(x0_2, out=slot(b12, 2))]))
-        x0_3 = self.conv0_3(ops.Concat(b03, [x0_2, up(x1_2, out=slot(b03, 1))]))
+        x3_0 = self.conv3_0(down(x2_0), c8=flow)
+        x2_1 = self.conv2_1(ops.Concat(b21, [x2_0, up(x3_0, out=slot(b21, 1)), down(x1_1, out=slot(b21, 2))]), c8=flow)
+        x1_2 = self.conv1_2(ops.Concat(b12, [x1_1, up(x2_1, out=slot(b12, 1)), down(x0_2, out=slot(b12, 2))]), c8=flow)
+        x0_3 = self.conv0_3(ops.Concat(b03, [x0_2, up(x1_2, out=slot(b03, 1))]), c8=flow)
 
-        return _run_hypothesis(self.hypothesis, run_conv(self.out_conv, x0_3))
+        if isinstance(self.hypothesis, nn.Softmax) and self.hypothesis.dim == 1:
+            # out conv + Softmax(dim=1) (:103-104) as one op: the softmax runs in the conv epilogue where the variant has one
+            return run_conv(self.out_conv, x0_3, softmax=True)
+        return _run_hypothesis(self.hypothesis, ops.as_f32(run_conv(self.out_conv, x0_3)))

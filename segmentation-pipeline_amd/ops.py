@@ -1584,10 +1584,44 @@ def _into_c8_slot(y32, out: Optional[OutSlot], compute):
     return pack_act16(y32, compute, out.act16() if out is not None else None)
 
 
+class _UpsampleC8Fn(torch.autograd.Function):
+    """trilinear x2 upsampling c8 -> c8 (straight into its concat slot); backward: the gather-form kernel on the c8
+    gradient"""
+
+    @staticmethod
+    def forward(ctx, x_t, x: Act16, y16: Act16):
+        N, Cc, D, H, W = x.shape
+        check(_lib.lib().m355_upsample_trilinear2x_fwd_h16(x.ptr(), y16.ptr(), N, Cc, D, H, W, x.batch_stride(),
+                                                           y16.batch_stride(), x.compute, _stream()),
+              "upsample_trilinear2x_fwd_h16")
+        ctx.info = (N, Cc, D, H, W, x.compute)
+        return y16.alias()
+
+    @staticmethod
+    def backward(ctx, dy16):
+        N, Cc, D, H, W, compute = ctx.info
+        dy16, dybs = _c8t(dy16)
+        dx16 = torch.empty((N, (Cc + 7) // 8, D * H * W, 8), dtype=_DT16[compute], device=dy16.device)
+        check(_lib.lib().m355_upsample_trilinear2x_bwd_h16(_p(dy16), _p(dx16), N, Cc, D, H, W, dybs, 0, compute, _stream()),
+              "upsample_trilinear2x_bwd_h16")
+        return dx16, None, None
+
+
 def upsample_trilinear2x(x, out: Optional[OutSlot] = None):
-    """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)"""
+    """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True); c8 -> c8 in the 16-bit flows."""
     if isinstance(x, Act16):
-        return _into_c8_slot(_UpsampleFn.apply(x.to_f32(), None), out, x.compute)
+        N, Cc, D, H, W = x.shape
+        y16 = out.act16() if out is not None else None
+        if y16 is None:
+            y16 = Act16.empty(N, Cc, (2 * D, 2 * H, 2 * W), x.compute, x.device)
+        elif y16.shape != (N, Cc, 2 * D, 2 * H, 2 * W):
+            raise _lib.M355Error(f"c8 slot shape {y16.shape} != op output shape {(N, Cc, 2 * D, 2 * H, 2 * W)}")
+        if _act16_tracks(x):
+            return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, _UpsampleC8Fn.apply(x.t, x, y16))
+        check(_lib.lib().m355_upsample_trilinear2x_fwd_h16(x.ptr(), y16.ptr(), N, Cc, D, H, W, x.batch_stride(),
+                                                           y16.batch_stride(), x.compute, _stream()),
+              "upsample_trilinear2x_fwd_h16")
+        return y16
     return _UpsampleFn.apply(x, out)
 
 
@@ -1691,9 +1725,50 @@ class _ChannelScaleFn(torch.autograd.Function):
         return dx, None
 
 
-def channel_scale(x, scale):
-    """y[n,c,...] = x[n,c,...] * scale[n,c]  (Dropout3d with a pre-drawn mask)."""
-    return _ChannelScaleFn.apply(as_f32(x), scale.contiguous().view(-1))
+def _channel_scale_c8(src_ptr, sbs, scale, dst_ptr, dbs, N, Cc, S, compute):
+    check(_lib.lib().m355_act16_channel_scale(src_ptr, _p(scale), dst_ptr, N, Cc, S, sbs, dbs, compute, _stream()),
+          "act16_channel_scale")
+
+
+class _ChannelScaleC8Fn(torch.autograd.Function):
+    """Dropout3d with a pre-drawn mask on a c8 activation (into its concat slot); backward: the same kernel on the c8
+    gradient"""
+
+    @staticmethod
+    def forward(ctx, x_t, scale, x: Act16, y16: Act16):
+        N, Cc = x.shape[:2]
+        _channel_scale_c8(x.ptr(), x.batch_stride(), scale, y16.ptr(), y16.batch_stride(), N, Cc, x.S, x.compute)
+        ctx.info = (N, Cc, x.S, x.compute)
+        ctx.save_for_backward(scale)
+        return y16.alias()
+
+    @staticmethod
+    def backward(ctx, dy16):
+        (scale,) = ctx.saved_tensors
+        N, Cc, S, compute = ctx.info
+        dy16, dybs = _c8t(dy16)
+        dx16 = torch.empty((N, (Cc + 7) // 8, S, 8), dtype=_DT16[compute], device=dy16.device)
+        _channel_scale_c8(_p(dy16), dybs, scale, _p(dx16), 0, N, Cc, S, compute)
+        return dx16, None, None, None
+
+
+def channel_scale(x, scale, out: Optional[OutSlot] = None):
+    """y[n,c,...] = x[n,c,...] * scale[n,c]  (Dropout3d with a pre-drawn mask); `out`: written into this concat slot.
+    A c8 activation stays c8."""
+    scale = scale.contiguous().view(-1)
+    if isinstance(x, Act16):
+        _require(scale)
+        y16 = out.act16() if out is not None else None
+        if y16 is None:
+            y16 = Act16.empty(x.shape[0], x.C, x.spatial, x.compute, x.device)
+        elif y16.shape != x.shape:
+            raise _lib.M355Error(f"c8 slot shape {y16.shape} != op output shape {x.shape}")
+        if _act16_tracks(x):
+            return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, _ChannelScaleC8Fn.apply(x.t, scale, x, y16))
+        _channel_scale_c8(x.ptr(), x.batch_stride(), scale, y16.ptr(), y16.batch_stride(), x.shape[0], x.C, x.S, x.compute)
+        return y16
+    y = _ChannelScaleFn.apply(x, scale)
+    return y if out is None else copy_into(y, out)
 
 
 class _AddFn(torch.autograd.Function):

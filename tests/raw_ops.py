@@ -315,6 +315,34 @@ class RawOps:
                                                   self._stream()), "avgpool3d_2x_bwd_h16")
         return dx16
 
+    def upsample_trilinear2x_fwd_h16(self, x16, Cc, spatial, compute, pad_batch=0):
+        """c8 -> c8 at twice the resolution; pad_batch: unused channel blocks per sample of the destination"""
+        D, H, W = spatial
+        N, CBp = x16.shape[:2]
+        CB = (Cc + 7) // 8
+        y16 = torch.full((N, CB + pad_batch, 8 * D * H * W, 8), 7.0, dtype=x16.dtype, device=self.device)
+        self._chk(self.fn("upsample_trilinear2x_fwd_h16")(_p(x16), _p(y16), N, Cc, D, H, W, CBp * D * H * W * 8,
+                                                          (CB + pad_batch) * D * H * W * 64, compute, self._stream()),
+                  "upsample_trilinear2x_fwd_h16")
+        return y16
+
+    def upsample_trilinear2x_bwd_h16(self, dy16, Cc, spatial, compute):
+        """`spatial`: the LOW-resolution size"""
+        D, H, W = spatial
+        N, CBp = dy16.shape[:2]
+        dx16 = torch.full((N, (Cc + 7) // 8, D * H * W, 8), 7.0, dtype=dy16.dtype, device=self.device)
+        self._chk(self.fn("upsample_trilinear2x_bwd_h16")(_p(dy16), _p(dx16), N, Cc, D, H, W, CBp * D * H * W * 64, 0, compute,
+                                                          self._stream()), "upsample_trilinear2x_bwd_h16")
+        return dx16
+
+    def act16_channel_scale(self, x16, scale, Cc, compute):
+        scale = self.to(scale)
+        N, CBp, S, _ = x16.shape
+        y16 = torch.full((N, (Cc + 7) // 8, S, 8), 7.0, dtype=x16.dtype, device=self.device)
+        self._chk(self.fn("act16_channel_scale")(_p(x16), _p(scale), _p(y16), N, Cc, S, CBp * S * 8, 0, compute,
+                                                 self._stream()), "act16_channel_scale")
+        return y16
+
     def convt_h16_bwd_supported(self, x_shape, Cout):
         d = self.conv_desc(x_shape, Cout, 2, 2, 0)
         return bool(self.lib.m355_conv_transpose3d_h16_bwd_supported(C.byref(d)))

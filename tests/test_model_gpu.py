@@ -493,6 +493,45 @@ def test_dropout_train_runs_and_eval_is_identity(dropout_p):
     p.mean().backward()
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("arch", ["nested", "modular"])
+def test_dropout_in_the_c8_training_flow(mode, arch):
+    """Dropout3d (dmri_hippo: NestedResUNet(dropout_p=0.2), research/dmri_hippo/configs/main_config.py:123-127) in a
+    16-bit mode: the channel mask is applied to the c8 activation on its way into the concat slot, forward and backward.
+    With the same seed the c8 flow and the round-2 twin flow draw the same masks: probabilities agree to the mode's
+    tolerance, gradients point the same way; dropped channels really are zero in effect (the result differs from p = 0)."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+    torch.manual_seed(3)
+    if arch == "nested":
+        m = NestedResUNet(3, 2, 8, dropout_p=0.3).cuda().train()
+        x = torch.randn(2, 3, 16, 16, 16, device="cuda")
+    else:
+        m = ModularUNet(3, 2, [8, 16, 24], 3, block_params={'dropout_p': 0.3, **GN8}, **CONVT).cuda().train()
+        x = torch.randn(2, 3, 16, 16, 16, device="cuda")
+    y = torch.nn.functional.one_hot(torch.randint(0, 2, (2, 16, 16, 16), device="cuda"), 2).permute(0, 4, 1, 2, 3).float().contiguous()
+
+    def run(c8only, seed=11):
+        ops.H16_TRAIN_C8ONLY = c8only
+        m.zero_grad()
+        torch.manual_seed(seed)
+        try:
+            with sp.precision(mode):
+                p = m(x)
+                HybridLogisticDiceLoss()(p, y)["loss"].backward()
+        finally:
+            ops.H16_TRAIN_C8ONLY = True
+        return p.detach(), torch.cat([v.grad.flatten() for v in m.parameters()]).double()
+    p_c8, g_c8 = run(True)
+    p_tw, g_tw = run(False)
+    assert torch.isfinite(p_c8).all() and torch.isfinite(g_c8).all()
+    assert (p_c8 - p_tw).abs().max().item() <= (4e-2 if mode == "bf16" else 1e-2)
+    cos = float(g_c8 @ g_tw / (g_c8.norm() * g_tw.norm()))
+    assert cos >= (0.98 if mode == "bf16" else 0.998), cos
+    p_other, _ = run(True, seed=12)
+    assert (p_c8 - p_other).abs().max().item() > 1e-3, "a different mask made no difference"
+
+
 def test_full_size_cfg2_properties():
     """BASELINE cfg2 at full size (1x4x128^3, 18.08 M params): size-independent properties."""
     torch.manual_seed(0)
