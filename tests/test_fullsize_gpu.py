@@ -407,4 +407,21 @@ def test_dmri_hippo_full_size_nested_res_unet_vs_cpu_oracle():
         with torch.no_grad(), sp.precision(mode):
             err = (model(x.cuda()).cpu() - p_ref.detach()).abs().max().item()
         assert 1e-7 < err <= tol, (mode, err)
+    # ... and a TRAINING step in the 16-bit modes (round 3: NestedResUNet on the c8-only flow -- c8 trilinear upsampling,
+    # residual adds, tensors with three consumers whose c8 gradients autograd sums): all parameter gradients together
+    # against the fp32 oracle's -- direction and size
+    names = [k for k, _ in model.named_parameters()]
+    ref_all = torch.cat([sd[k].grad.double().flatten() for k in names])
+    for mode, tol, cos_min in (("bf16", 2e-2, 0.998), ("fp16", 5e-3, 0.9995)):
+        model.zero_grad(set_to_none=True)
+        with sp.precision(mode):
+            p16 = model(x.cuda())
+            HybridLogisticDiceLoss()(p16, y.cuda())["loss"].backward()
+        assert (p16.detach().cpu() - p_ref.detach()).abs().max().item() <= tol, mode
+        got = torch.cat([v.grad.cpu().double().flatten() for _, v in model.named_parameters()])
+        assert torch.isfinite(got).all(), mode
+        cos = float(got @ ref_all / (got.norm() * ref_all.norm()))
+        ratio = float(got.norm() / ref_all.norm())
+        print(f"dmri_hippo {mode} c8 training flow vs fp32 oracle: all-parameter cosine {cos:.5f}, norm ratio {ratio:.4f}")
+        assert cos >= cos_min and abs(ratio - 1) <= 0.05, (mode, cos, ratio)
     torch.cuda.empty_cache()
