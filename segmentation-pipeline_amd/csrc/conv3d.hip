@@ -2375,6 +2375,26 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
   return M355_OK;
 }
 
+bool m355::plan_h16r(const FwdPlan& p, int N, int kin, int D, int H, int W, FwdPlan* r) {
+  const int mode = tuning().h16r;
+  if (!mode || !p.mfma || p.gx != 32 || p.ksplit != 1 || D < 8 || H < 4) return false;
+  if (kin <= 4 && !tuning().no_small) return false;          // conv3_c4_h16_kernel owns the <= 4-channel edge layers
+  const int64_t items = ceil_div(D, 8) * ceil_div(H, 4) * (int64_t)p.tx_tiles * p.otiles * N;
+  const int64_t cus = num_cus();
+  // one workgroup per CU, equal items: the launch takes ceil(items / CUs) item times -- it must fill the chip, and
+  // its last round should not be mostly empty (mode 2: wherever the geometry allows, for tests / sweeps)
+  if (mode == 1 && (items < cus || items * 5 < ceil_div(items, cus) * cus * 4)) return false;
+  if (r) {
+    *r = p;
+    r->ntw = 4;
+    r->nw = 8;
+    r->oneshot = 0;
+    r->tz_tiles = (int)ceil_div(D, 8);
+    r->ty_tiles = (int)ceil_div(H, 4);
+  }
+  return true;
+}
+
 // Per (sample, output channel): how many (sum, sum of squares) partials the forward kernel writes
 // when statistics are fused (4 waves x spatial tiles); 0 = this descriptor has no fused statistics
 // (not 3x3x3 s1 p1, small-Cout kernel, bf16 operand mode, or a split-K plan).
@@ -2390,8 +2410,10 @@ extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d
 // c8-output forward of the 16-bit modes: split-K plans emit the partials from their reduction pass
 static int64_t conv_stats_slots_c8(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
-  const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
+  FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return splitk_c8_slots((int64_t)d->D * d->H * d->W);
+  FwdPlan r;
+  if (plan_h16r(p, d->N, d->Cin, d->D, d->H, d->W, &r)) p = r;
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots_c8(const m355_conv3d_desc* d) { return d ? conv_stats_slots_c8(d) : 0; }

@@ -152,6 +152,11 @@ int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_b
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
                  int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
                  const void* prepacked = nullptr, bool out16 = false, bool softmax = false);
+// Register-resident-weights kernel (conv3d_h16r.hip) for the c8-output forms (forward, data gradient) of a 16-bit plan:
+// plan_h16r -> true and the tile counts (8 x 4 x 32 voxels, 8 statistics slots per tile) when that kernel runs the layer.
+bool plan_h16r(const FwdPlan& p, int N, int kin, int D, int H, int W, FwdPlan* r);
+int launch_h16r(const FwdPlan& r, int compute, const void* x16, int64_t xbs16, const void* wp, const float* bias, void* y16,
+                int N, int kin, int mout, int D, int H, int W, int64_t ybs16, hipStream_t st, float* stat);
 void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
                         hipStream_t st);
 

@@ -54,7 +54,10 @@ def main():
                 else:
                     ms = timeit(lambda: hip.conv3d_fwd_h16_c8(x16, ci, (sp, sp, sp), w, compute=compute))
             elif o == "bwd_data" and compute and ci > 4:
-                ms = timeit(lambda: hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
+                if "--f32out" in sys.argv:
+                    ms = timeit(lambda: hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
+                else:   # c8 in, c8 out (the c8 training flow)
+                    ms = timeit(lambda: hip.conv3d_bwd_data_h16_c8(dy16, co, w, tuple(x.shape), compute))
             elif o == "fwd":
                 ms = timeit(lambda: hip.conv3d_fwd(x, w, compute=compute))
             elif o == "bwd_data":
