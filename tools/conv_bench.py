@@ -45,7 +45,7 @@ def main():
         dy = torch.randn(1, co, sp, sp, sp, device="cuda")
         flops = 2.0 * 27 * ci * co * sp ** 3
         row = f"{name:8s} {ci:4d} {co:4d} {sp:4d} "
-        if compute and ci > 4:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
+        if compute:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
             x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
         for o in ops:
             if o == "fwd" and compute and ci > 4:   # c8 in, c8 out (the inference flow); --f32out: fp32 NCDHW output
@@ -64,6 +64,8 @@ def main():
                 ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
             elif compute and ci > 4 and co > 4 and "--f32in" not in sys.argv:   # c8 operands (the 16-bit training flow)
                 ms = timeit(lambda: hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (sp, sp, sp), compute, with_bias=False))
+            elif compute and "--f32in" not in sys.argv:   # the edge layers of the c8 training flow (conv3_bww_c8_small_kernel)
+                ms = timeit(lambda: hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (sp, sp, sp), compute, with_bias=False))
             else:
                 ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False, compute=compute))
             tot[o][0] += ms
