@@ -1179,12 +1179,18 @@ __global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
     int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit, int ctiles,
     int otiles, int64_t xbs16, int64_t ybs16) {
   constexpr int TZ = 2, TY = 4, TX = 32, NV = TZ * TY * TX;          // 256 voxels
-  constexpr int HR = TX + 2, HP = (TY + 2) * HR, HVX = (TZ + 2) * HP;  // 34, 204, 816 halo voxels
-  constexpr int XI = HVX * 4, XPER = (XI + 255) / 256;                // 16-byte items of the x tile: 3264 -> 13
-  constexpr int DI = NV * 4, DPER = DI / 256;                         // of the dy tile: 1024 -> 4
+  constexpr int HR = TX + 2, HP = (TY + 2) * HR;                       // 34, 204 halo voxels per row / plane
+  constexpr int HV2 = 2 * HP;                                          // a PAIR of halo planes: 408 voxels
+  constexpr int XI2 = HV2 * 4, XPER2 = (XI2 + 255) / 256;              // 16-byte items of a plane pair: 1632 -> 7
+  constexpr int DI = NV * 4, DPER = DI / 256;                          // of the dy tile: 1024 -> 4
   constexpr unsigned OOB = 0x80000000u;
-  __shared__ __attribute__((aligned(16))) uint4 xs[XI];   // [halo voxel][channel block of the tile]
-  __shared__ __attribute__((aligned(16))) uint4 ds[DI];   // [voxel][channel block]
+  // The x halo tile (4 planes) is a RING of four plane slots: a workgroup walks its tiles along z, consecutive tiles
+  // share two of their four halo planes, and only the two new ones are fetched (26 KB instead of 52 KB per tile; with
+  // the dy tile 42 KB instead of 68 KB).  The kernel is bound by what a CU can miss per clock (~10 B/clk, DESIGN 4.5:
+  // 68 KB per tile and workgroup = 2x its MFMA time), so the bytes are the time.  Absolute halo plane z0 - 1 + zz of
+  // the tile at z0 = 2 * tzt lives in slot (2 * (tzt & 1) + zz) & 3.
+  __shared__ __attribute__((aligned(16))) uint4 xs[4 * HP * 4];   // [slot][halo row][halo column][channel block of the tile]
+  __shared__ __attribute__((aligned(16))) uint4 ds[DI];           // [voxel][channel block]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1200,71 +1206,92 @@ __global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
   const int ctile = pair % ctiles, otile = pair / ctiles;
   const int iHW = H * W, S = D * iHW;
 
-  // tile-invariant part of the staging: item e of the x tile = (channel block e / HVX, halo voxel e % HVX)
-  int xrel[XPER];
-  unsigned xcode[XPER];
+  // tile-invariant part of the staging: item e of a plane pair = (channel block e / HV2, pair voxel e % HV2)
+  int xrel[XPER2], xdst[XPER2];
+  unsigned xcode[XPER2];
 #pragma unroll
-  for (int k = 0; k < XPER; ++k) {
+  for (int k = 0; k < XPER2; ++k) {
     const int e = tid + 256 * k;
-    const int cbl = e / HVX, hv = e - cbl * HVX;
+    const int cbl = e / HV2, hv = e - cbl * HV2;
     const int zz = hv / HP, r = hv - zz * HP;
     const int yy = r / HR, xx = r - yy * HR;
     xrel[k] = cbl * S + zz * iHW + yy * W + xx;
-    xcode[k] = e < XI ? (1u << zz) | (1u << (8 + yy)) | ((unsigned)xx << 16) : 0xffffu;  // past the end: never valid
+    xdst[k] = hv * 4 + cbl;                                                 // within the pair's two slots
+    xcode[k] = e < XI2 ? (1u << zz) | (1u << (8 + yy)) | ((unsigned)xx << 16) : 0xffffu;  // past the end: never valid
   }
   const int dv = tid, dvz = dv / (TY * TX), dvy = (dv / TX) % TY, dvx = dv % TX;  // dy item k: (block k, voxel tid)
 
-  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
-  const int ntiles = N * tiles_per_n;
-  __amdgpu_buffer_rsrc_t rx, rd;
-  unsigned zymask = 0u;
-  int xbase = 0, dbase = 0, xlim = 0;
-  bool dok = false;
-  auto tile_setup = [&](int tile, bool live) {
-    int t = tile;
-    const int n = t / tiles_per_n;
-    t -= n * tiles_per_n;
-    const int txt = t % tx_tiles;
-    t /= tx_tiles;
-    const int tyt = t % ty_tiles, tzt = t / ty_tiles;
+  // tiles: z fastest inside a (sample, y tile, x tile) column; split s owns the contiguous range [s * per, (s + 1) * per)
+  const int ntiles = N * tz_tiles * ty_tiles * tx_tiles;
+  const int per = ntiles / nsplit, rem = ntiles - per * nsplit;       // the first `rem` splits take one tile more
+  const int t_begin = split * per + min(split, rem), t_end = t_begin + per + (split < rem ? 1 : 0);
+  __amdgpu_buffer_rsrc_t rxu, rxl, rd;
+  unsigned zymask_u = 0u, zymask_l = 0u;
+  int xbase_u = 0, xbase_l = 0, dbase = 0, xlim = 0, slot_u = 0, slot_l = 0;
+  bool dok = false, cold = false;
+  auto tile_setup = [&](int tile, bool live) {   // staging state of the tile that is fetched next
+    const int tzt = tile % tz_tiles;
+    int col = tile / tz_tiles;
+    const int txt = col % tx_tiles;
+    col /= tx_tiles;
+    const int tyt = col % ty_tiles, n = col / ty_tiles;
     const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+    cold = tzt == 0 || tile == t_begin;          // nothing of this column is in the ring yet: both plane pairs
     const int nbx = min(4, CBin - 4 * ctile), nbd = min(4, CBout - 4 * otile);
-    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x16 + (int64_t)n * xbs16 + (int64_t)(4 * ctile) * S * 8), 0,
-                                           live ? nbx * S * 16 : 0, 0x00020000);
+    const void* xb = x16 + (int64_t)n * xbs16 + (int64_t)(4 * ctile) * S * 8;
+    rxu = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, live ? nbx * S * 16 : 0, 0x00020000);
+    rxl = rxu;
     rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy16 + (int64_t)n * ybs16 + (int64_t)(4 * otile) * S * 8), 0,
                                            live ? nbd * S * 16 : 0, 0x00020000);
-    zymask = 0u;
-    for (int zz = 0; zz < TZ + 2; ++zz)
-      if (z0 + zz - 1 >= 0 && z0 + zz - 1 < D) zymask |= 1u << zz;
+    unsigned ym = 0u;
     for (int yy = 0; yy < TY + 2; ++yy)
-      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) zymask |= 1u << (8 + yy);
-    xbase = (z0 - 1) * iHW + (y0 - 1) * W + x0 - 1;
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ym |= 1u << (8 + yy);
+    zymask_l = ym, zymask_u = ym;                // lower pair: planes z0 - 1, z0; upper pair: z0 + 1, z0 + 2
+    if (z0 - 1 >= 0) zymask_l |= 1u;
+    if (z0 < D) zymask_l |= 2u;
+    if (z0 + 1 < D) zymask_u |= 1u;
+    if (z0 + 2 < D) zymask_u |= 2u;
+    xbase_l = (z0 - 1) * iHW + (y0 - 1) * W + x0 - 1;
+    xbase_u = xbase_l + 2 * iHW;
     xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
+    slot_l = (2 * (tzt & 1)) & 3;
+    slot_u = (slot_l + 2) & 3;
     const int gz = z0 + dvz, gy = y0 + dvy, gx = x0 + dvx;
     dok = gz < D && gy < H && gx < W;
     dbase = gz * iHW + gy * W + gx;
   };
-  uint4 xr[XPER], dr[DPER];
-  auto fetch = [&]() {
+  uint4 xr[XPER2], dr[DPER];
+  auto fetch = [&]() {   // the two NEW halo planes of the next tile + its dy tile (in flight during this tile's MFMAs)
 #pragma unroll
-    for (int k = 0; k < XPER; ++k) {
+    for (int k = 0; k < XPER2; ++k) {
       const int xx = (int)(xcode[k] >> 16);
-      const bool ok = ((xcode[k] & 0xffffu) & ~zymask) == 0u && (unsigned)(xlim + xx) < (unsigned)W;
-      xr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(xbase + xrel[k]) * 16u : OOB, 0, 0));
+      const bool ok = ((xcode[k] & 0xffffu) & ~zymask_u) == 0u && (unsigned)(xlim + xx) < (unsigned)W;
+      xr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxu, ok ? (unsigned)(xbase_u + xrel[k]) * 16u : OOB, 0, 0));
     }
 #pragma unroll
     for (int k = 0; k < DPER; ++k)
       dr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rd, dok ? (unsigned)(k * S + dbase) * 16u : OOB, 0, 0));
   };
   auto commit = [&]() {
+    uint4* xu = xs + slot_u * HP * 4;
 #pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-      const int e = tid + 256 * k;
-      const int cbl = e / HVX, hv = e - cbl * HVX;
-      if (e < XI) xs[hv * 4 + cbl] = xr[k];
-    }
+    for (int k = 0; k < XPER2; ++k)
+      if (tid + 256 * k < XI2) xu[xdst[k]] = xr[k];
 #pragma unroll
     for (int k = 0; k < DPER; ++k) ds[dv * 4 + k] = dr[k];
+    if (cold) {   // (uniform) start of a column / of this split's range: the other two planes, loaded here and now -- once
+                  // per ~16-64 tiles, not worth 28 staging registers held through every MFMA phase
+      uint4* xl = xs + slot_l * HP * 4;
+#pragma unroll
+      for (int k = 0; k < XPER2; ++k) {
+        const int xx = (int)(xcode[k] >> 16);
+        const bool ok = ((xcode[k] & 0xffffu) & ~zymask_l) == 0u && (unsigned)(xlim + xx) < (unsigned)W;
+        xr[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxl, ok ? (unsigned)(xbase_l + xrel[k]) * 16u : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < XPER2; ++k)
+        if (tid + 256 * k < XI2) xl[xdst[k]] = xr[k];
+    }
   };
 
   // transposed-read bases: lane 4q + p of a 16-lane group addresses voxel row q, channels 4p .. 4p+3 of its
@@ -1272,11 +1299,12 @@ __global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
   const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   const int lb = (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
   const unsigned char* db = reinterpret_cast<const unsigned char*>(ds) + lb;
-  const unsigned char* xt[7];
+  int tdz[7], tyx[7];   // this wave's taps: plane offset dz, byte offset of (dy, dx) inside a plane
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = min(wave * 7 + t, 26);
-    xt[t] = reinterpret_cast<const unsigned char*>(xs) + lb + ((tap / 9) * HP + ((tap / 3) % 3) * HR + tap % 3) * 64;
+    tdz[t] = tap / 9;
+    tyx[t] = (((tap / 3) % 3) * HR + tap % 3) * 64;
   }
 
   f32x16 acc[7];
@@ -1285,31 +1313,87 @@ __global__ __launch_bounds__(256, 2) void conv3_bww_c8_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  if (split < ntiles) {
-    tile_setup(split, true);
+  if (t_begin < t_end) {
+    tile_setup(t_begin, true);
     fetch();
     commit();
   }
   __syncthreads();
-  for (int tile = split; tile < ntiles; tile += nsplit) {
-    const bool more = tile + nsplit < ntiles;
-    tile_setup(more ? tile + nsplit : tile, more);
+#ifdef M355_H16_STAMPS
+  unsigned long long ph_mfma = 0, ph_b1 = 0, ph_commit = 0, ph_b2 = 0, ph_n = 0;
+  const unsigned long long t_life = __builtin_amdgcn_s_memtime();
+#endif
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    STAMP(t0);
+    // fragment bases of THIS tile: voxel plane z, tap plane dz -> ring slot (2 * parity + z + dz) & 3
+    const int par2 = 2 * ((tile % tz_tiles) & 1);
+    const unsigned char* xt[7][2];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int z = 0; z < 2; ++z)
+        xt[t][z] = reinterpret_cast<const unsigned char*>(xs) + lb + tyx[t] + ((par2 + z + tdz[t]) & 3) * (HP * 64);
+    const bool more = tile + 1 < t_end;
+    tile_setup(more ? tile + 1 : tile, more);
     fetch();   // unconditional (zero-sized descriptors after the last tile): keeps the loop one basic block
+    // 16 k-steps (voxel row r = (z, y), x half xk) x 7 taps = 112 MFMAs per wave, software-pipelined by one k-step: the
+    // A fragment and the 7 B fragments of step g + 1 are requested between the MFMAs of step g (left to the compiler
+    // every MFMA waited lgkmcnt(0) for its own fragment: ~70 cycles per MFMA instead of 32).  A scheduling barrier per
+    // step keeps the compiler from regrouping the stream by accumulator.
+    {
+      using hx8 = typename H16<HT>::x8;
+      auto afrag = [&](int g) {
+        const int r = g >> 1, xk = g & 1, z = r / TY, y = r % TY;
+        return tr_frag<HT>(db + ((z * TY + y) * TX + 16 * xk) * 64);
+      };
+      auto bfrag = [&](int g, int t) {
+        const int r = g >> 1, xk = g & 1, z = r / TY, y = r % TY;
+        return tr_frag<HT>(xt[t][z] + (y * HR + 16 * xk) * 64);
+      };
+      hx8 aq[2], bq[2][7];
+      aq[0] = afrag(0);
 #pragma unroll
-    for (int r = 0; r < TZ * TY; ++r) {
-      const int z = r / TY, y = r % TY;
+      for (int t = 0; t < 7; ++t) bq[0][t] = bfrag(0, t);
 #pragma unroll
-      for (int xk = 0; xk < 2; ++xk) {
-        const typename H16<HT>::x8 a = tr_frag<HT>(db + ((z * TY + y) * TX + 16 * xk) * 64);
+      for (int g = 0; g < 16; ++g) {
+        if (g + 1 < 16) aq[(g + 1) & 1] = afrag(g + 1);
 #pragma unroll
-        for (int t = 0; t < 7; ++t)
-          acc[t] = H16<HT>::mfma(a, tr_frag<HT>(xt[t] + (z * HP + y * HR + 16 * xk) * 64), acc[t]);
+        for (int t = 0; t < 7; ++t) {
+          if (g + 1 < 16) bq[(g + 1) & 1][t] = bfrag(g + 1, t);
+          acc[t] = H16<HT>::mfma(aq[g & 1], bq[g & 1][t], acc[t]);
+        }
+        if (g + 1 < 16) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // A fragment of the next step
+#pragma unroll
+          for (int t = 0; t < 7; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // B fragment (next step, tap t)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA (this step, tap t)
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(t1);
     __syncthreads();  // every wave is done reading this tile
+    STAMP(t2);
     if (more) commit();
+    STAMP(t3);
     __syncthreads();
+#ifdef M355_H16_STAMPS
+    {
+      STAMP(t4);
+      ph_mfma += t1 - t0; ph_b1 += t2 - t1; ph_commit += t3 - t2; ph_b2 += t4 - t3; ph_n += 1;
+    }
+#endif
   }
+#ifdef M355_H16_STAMPS
+  if (tid == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = m355_h16_stamps[blockIdx.x];
+    o[0] = ph_mfma; o[1] = ph_b1; o[2] = ph_commit; o[3] = ph_b2; o[4] = 0; o[5] = ph_n;
+    o[6] = __builtin_amdgcn_s_memtime() - t_life;
+    o[7] = 0;
+  }
+#endif
 
   // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
   float* sl = slab + (int64_t)split * 27 * Cout * Cin;
