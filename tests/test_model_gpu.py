@@ -532,6 +532,31 @@ def test_dropout_in_the_c8_training_flow(mode, arch):
     assert (p_c8 - p_other).abs().max().item() > 1e-3, "a different mask made no difference"
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_nested_res_unet_with_filters_not_a_multiple_of_8_keeps_the_twin_flow(mode):
+    """NestedResUNet(filters=4): concat slots would not start on c8 block boundaries, so the model stays on fp32 tensors
+    with c8 conv operands (the round-2 twin flow) in the 16-bit modes -- same results as fp32 within the mode's tolerance,
+    gradients in the same direction."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+    torch.manual_seed(5)
+    m = NestedResUNet(3, 2, 4).cuda().train()
+    x = torch.randn(2, 3, 16, 16, 16, device="cuda")
+    y = torch.nn.functional.one_hot(torch.randint(0, 2, (2, 16, 16, 16), device="cuda"), 2).permute(0, 4, 1, 2, 3).float().contiguous()
+
+    def run(prec):
+        m.zero_grad()
+        with sp.precision(prec):
+            p = m(x)
+            HybridLogisticDiceLoss()(p, y)["loss"].backward()
+        return p.detach(), torch.cat([v.grad.flatten() for v in m.parameters()]).double()
+    p32, g32 = run("fp32")
+    p16, g16 = run(mode)
+    assert torch.isfinite(g16).all()
+    assert (p16 - p32).abs().max().item() <= (4e-2 if mode == "bf16" else 1e-2)
+    assert float(g16 @ g32 / (g16.norm() * g32.norm())) >= (0.97 if mode == "bf16" else 0.995)
+
+
 def test_full_size_cfg2_properties():
     """BASELINE cfg2 at full size (1x4x128^3, 18.08 M params): size-independent properties."""
     torch.manual_seed(0)
