@@ -397,6 +397,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
   __shared__ __attribute__((aligned(16))) hx8 ws[DB ? 2 : 1][WI];
   __shared__ int next_item_s;
 
+#ifdef M355_H16_STAMPS
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -739,6 +742,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (NTW <= 4 ? 2 : 1))) void c
     o[0] = ph_mfma; o[1] = ph_b1; o[2] = ph_commit; o[3] = ph_b2; o[4] = ph_epi; o[5] = ph_n;
     o[6] = __builtin_amdgcn_s_memtime() - t_begin;
     o[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    // (timeline probe: tools/h16_timeline.py) 100 MHz ticks at kernel entry / exit of this workgroup, XCC id in the top bits
+    o[3] = r_entry;
+    o[4] = __builtin_amdgcn_s_memrealtime();
+    o[7] |= (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32;   // HW_REG_XCC_ID
   }
 #endif
   if constexpr (!ONE) queue_leave(work_counter);
