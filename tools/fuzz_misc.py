@@ -56,6 +56,19 @@ def main():
             res["up fwd"] = err(hip.upsample_fwd(x), uo)
             du = rnd(*uo.shape, seed=i + 6)
             res["up bwd"] = err(hip.upsample_bwd(du, x.shape), oracle.upsample_bwd(du, x.shape))
+            # the c8 kernels of the 16-bit flows: == the oracle on the rounded operand, rounded once (one 16-bit ulp)
+            for compute, dt, ulp in ((1, torch.bfloat16, 2.0 ** -8), (2, torch.float16, 2.0 ** -11)):
+                xr, dur = x.to(dt).float(), du.to(dt).float()
+                y16 = hip.upsample_trilinear2x_fwd_h16(hip.act16_pack(x, compute), C_, (D, H, W), compute)
+                ref = oracle.upsample_fwd(xr)
+                got = y16.float().cpu().permute(0, 1, 3, 2).reshape(N, -1, 8 * D * H * W)[:, :C_].reshape(ref.shape)
+                bad16 = ((got - ref).abs() > ulp * ref.abs() * 1.01 + 1e-5 * max(1.0, ref.abs().max().item())).sum().item()
+                res[f"up fwd c8 ({'bf16' if compute == 1 else 'fp16'}) elements off"] = float(bad16)
+                dx16 = hip.upsample_trilinear2x_bwd_h16(hip.act16_pack(du, compute), C_, (D, H, W), compute)
+                refb = oracle.upsample_bwd(dur, x.shape)
+                gotb = dx16.float().cpu().permute(0, 1, 3, 2).reshape(N, -1, D * H * W)[:, :C_].reshape(refb.shape)
+                bad16 = ((gotb - refb).abs() > ulp * refb.abs() * 1.01 + 2e-5 * max(1.0, refb.abs().max().item())).sum().item()
+                res[f"up bwd c8 ({'bf16' if compute == 1 else 'fp16'}) elements off"] = float(bad16)
         res["s2d"] = err(hip.space_to_depth(x), oracle.space_to_depth(x))
         # softmax + loss over the channels
         if C_ >= 2:
