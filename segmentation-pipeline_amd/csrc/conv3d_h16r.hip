@@ -34,7 +34,7 @@
 
 namespace m355 {
 
-// DBG (diagnostic variants of the loop, M355_H16R_DBG -- wrong results, for timing the parts only): bit 0 = no halo loads
+// DBG (diagnostic variants of the loop, only in the --stamps build: M355_H16R_DBG -- wrong results, for timing the parts only): bit 0 = no halo loads
 // / LDS commits, 1 = no weight re-loads, 2 = no MFMAs, 3 = clock stamps over the output, 4 = no LDS commits, 5 = no halo
 // loads, 6 = halo loads from a cache-resident region
 template <typename HT, int DBG = 0>
@@ -297,9 +297,12 @@ int launch_h16r(const FwdPlan& p, int compute, const void* x16, int64_t xbs16, c
                      (HT*)y16, (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.otiles, \
                      p.nchunks, N, xbs16, ybs16, stat, stagger)
   static const int stagger = getenv("M355_H16R_STAGGER") ? atoi(getenv("M355_H16R_STAGGER")) : 0;
+#ifdef M355_H16_STAMPS
+  // diagnostic build (build.py --stamps, M355_LIB_PATH): loop variants with WRONG results, for timing the parts
+  // (tools/h16r_probe.py; bit 3 adds the in-kernel clock stamps)
   static const int dbg = getenv("M355_H16R_DBG") ? atoi(getenv("M355_H16R_DBG")) : 0;
-  if (compute == M355_COMPUTE_BF16) {
-    switch (dbg) {   // diagnostic loop variants (WRONG results; bit 3 adds the in-kernel clock stamps): tools/h16r_probe.py
+  if (compute == M355_COMPUTE_BF16 && dbg) {
+    switch (dbg) {
       case 8: M355_H16R_LAUNCH(__bf16, 8); break;      // everything
       case 9: M355_H16R_LAUNCH(__bf16, 9); break;      // no halo loads / LDS commits
       case 10: M355_H16R_LAUNCH(__bf16, 10); break;    // no weight re-loads
@@ -310,9 +313,13 @@ int launch_h16r(const FwdPlan& p, int compute, const void* x16, int64_t xbs16, c
       case 72: M355_H16R_LAUNCH(__bf16, 72); break;    // halo loads from a cache-resident region
       default: M355_H16R_LAUNCH(__bf16, 0);
     }
-  } else {
-    M355_H16R_LAUNCH(_Float16, 0);
+    return check_launch("conv3_h16r(diagnostic)");
   }
+#endif
+  if (compute == M355_COMPUTE_BF16)
+    M355_H16R_LAUNCH(__bf16, 0);
+  else
+    M355_H16R_LAUNCH(_Float16, 0);
 #undef M355_H16R_LAUNCH
   return check_launch("conv3_h16r");
 }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Timing of the register-weights 16-bit conv kernel on the cfg2 wide layers (c8 in, c8 out, weights pre-packed once per
-call by the wrapper).  M355_H16R_DBG selects diagnostic loop variants (wrong results)."""
+call by the wrapper).  M355_H16R_DBG selects diagnostic loop variants (wrong results) of the diagnostic build:
+    python segmentation-pipeline_amd/build.py --stamps
+    M355_LIB_PATH=segmentation-pipeline_amd/libm355seg_dbg.so M355_H16R_DBG=11 python tools/h16r_probe.py"""
 import os, sys, torch
 os.environ.setdefault("M355_H16R", "1")     # (the kernel is opt-in; M355_H16R=0 times conv3_h16_kernel instead)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
