@@ -48,4 +48,45 @@ for N, ci, co, D, H, W, env in CASES:
                           f"max diff {(a - r).abs().max().item():.3e}")
                     sys.exit(1)
     print(f"ok {iters} x {(N, ci, co, D, H, W)} {env}", flush=True)
+# the c8 kernels of the 16-bit training flow: one-shot / queue-driven forward with fused statistics, data gradient, the
+# ring-buffered + software-pipelined weight gradient, and the opt-in register-weights kernel (double-buffered halo, one
+# barrier per chunk)
+C8_CASES = [  # (N, Cin, Cout, D, H, W, env)
+    (1, 32, 32, 32, 32, 64, {}),
+    (1, 96, 32, 16, 20, 64, {"M355_BWW_NSPLIT": "7"}),
+    (2, 24, 72, 9, 13, 33, {"M355_H16_ONESHOT": "3", "M355_CONV_SLOTS": "11"}),
+    (1, 40, 64, 17, 12, 64, {"M355_H16R": "2"}),
+    (1, 64, 32, 8, 8, 96, {"M355_H16R": "2", "M355_BWW_NSPLIT": "3"}),
+]
+KN = ("M355_CONV_SLOTS", "M355_CONV_KSPLIT", "M355_CONV_PERSISTENT", "M355_BWW_NSPLIT", "M355_H16_ONESHOT", "M355_H16R")
+for N, ci, co, D, H, W, env in C8_CASES:
+    for k in KN:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    _reload()
+    for compute in (1, 2):
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(N, ci, D, H, W, generator=g)
+        w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1)
+        b = torch.randn(co, generator=g)
+        dy = torch.randn(N, co, D, H, W, generator=g)
+        x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
+        ref = None
+        for i in range(max(20, iters // 4)):
+            y16, part = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
+            dx16 = hip.conv3d_bwd_data_h16_c8(dy16, co, w, (N, ci, D, H, W), compute)
+            dw, db = hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (D, H, W), compute)
+            up16 = hip.upsample_trilinear2x_bwd_h16(hip.upsample_trilinear2x_fwd_h16(x16, ci, (D, H, W), compute), ci, (D, H, W), compute)
+            cur = [y16, part, dx16, dw, db, up16]
+            if ref is None:
+                ref = [t.clone() for t in cur]
+            else:
+                for j, (a, r) in enumerate(zip(cur, ref)):
+                    if not torch.equal(a, r):
+                        print(f"NON-DETERMINISTIC (c8): case {(N, ci, co, D, H, W, env)} compute {compute} output {j} iteration {i}")
+                        sys.exit(1)
+    print(f"ok c8 {(N, ci, co, D, H, W)} {env}", flush=True)
+for k in KN:
+    os.environ.pop(k, None)
+_reload()
 print("soak ok")
