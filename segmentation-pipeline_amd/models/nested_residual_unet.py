@@ -113,24 +113,38 @@ class NestedResUNet(nn.Module):
                 return ops.OutSlot(None, F * i, F * (i + 1), buf16=b)
             return ops.OutSlot(b, F * i, F * (i + 1))
 
-        down, up = ops.avgpool3d_2x, ops.upsample_trilinear2x
+        up = ops.upsample_trilinear2x
+
+        def down(t, out=None):
+            """-> (t as it continues into its other consumers, AvgPool3d(2, 2)(t)).  c8 training flow: one autograd node
+            for the pair, whose backward adds the un-pooled gradient to the gradient of the other consumers in the pool
+            backward pass (instead of a separate sum of two full-resolution c8 gradients)"""
+            if flow and torch.is_grad_enabled() and isinstance(t, ops.Act16) and t.requires_grad:
+                return ops.avgpool3d_2x_with_skip(t, out=out)
+            return t, ops.avgpool3d_2x(t, out=out)
+
         # each buffer is the input of one nested block: [own-row predecessor | up | down]
         b01, b02, b03 = buf(2, 0), buf(2, 0), buf(2, 0)
         b11, b12 = buf(3, 1), buf(3, 1)
         b21 = buf(3, 2)
 
         x0_0 = self.conv0_0(x, out=slot(b01, 0), c8=flow)
-        x1_0 = self.conv1_0(down(x0_0), out=slot(b11, 0), c8=flow)
+        x0_0, p0_0 = down(x0_0)
+        x1_0 = self.conv1_0(p0_0, out=slot(b11, 0), c8=flow)
+        x1_0, p1_0 = down(x1_0)
         x0_1 = self.conv0_1(ops.Concat(b01, [x0_0, up(x1_0, out=slot(b01, 1))]), out=slot(b02, 0), c8=flow)
+        x0_1, p0_1 = down(x0_1, out=slot(b11, 2))
 
-        x2_0 = self.conv2_0(down(x1_0), out=slot(b21, 0), c8=flow)
-        x1_1 = self.conv1_1(ops.Concat(b11, [x1_0, up(x2_0, out=slot(b11, 1)), down(x0_1, out=slot(b11, 2))]),
-                            out=slot(b12, 0), c8=flow)
+        x2_0 = self.conv2_0(p1_0, out=slot(b21, 0), c8=flow)
+        x2_0, p2_0 = down(x2_0)
+        x1_1 = self.conv1_1(ops.Concat(b11, [x1_0, up(x2_0, out=slot(b11, 1)), p0_1]), out=slot(b12, 0), c8=flow)
+        x1_1, p1_1 = down(x1_1, out=slot(b21, 2))
         x0_2 = self.conv0_2(ops.Concat(b02, [x0_1, up(x1_1, out=slot(b02, 1))]), out=slot(b03, 0), c8=flow)
+        x0_2, p0_2 = down(x0_2, out=slot(b12, 2))
 
-        x3_0 = self.conv3_0(down(x2_0), c8=flow)
-        x2_1 = self.conv2_1(ops.Concat(b21, [x2_0, up(x3_0, out=slot(b21, 1)), down(x1_1, out=slot(b21, 2))]), c8=flow)
-        x1_2 = self.conv1_2(ops.Concat(b12, [x1_1, up(x2_1, out=slot(b12, 1)), down(x0_2, out=slot(b12, 2))]), c8=flow)
+        x3_0 = self.conv3_0(p2_0, c8=flow)
+        x2_1 = self.conv2_1(ops.Concat(b21, [x2_0, up(x3_0, out=slot(b21, 1)), p1_1]), c8=flow)
+        x1_2 = self.conv1_2(ops.Concat(b12, [x1_1, up(x2_1, out=slot(b12, 1)), p0_2]), c8=flow)
         x0_3 = self.conv0_3(ops.Concat(b03, [x0_2, up(x1_2, out=slot(b03, 1))]), c8=flow)
 
         if isinstance(self.hypothesis, nn.Softmax) and self.hypothesis.dim == 1:

@@ -1527,11 +1527,16 @@ class _PoolSkipFn(torch.autograd.Function):
         return dx
 
 
-def avgpool3d_2x_with_skip(x):
-    """-> (x as it continues into the skip connection, AvgPool3d(2, 2)(x)); see _PoolSkipFn."""
+def avgpool3d_2x_with_skip(x, out: Optional[OutSlot] = None):
+    """-> (x as it continues into the skip connection, AvgPool3d(2, 2)(x)); see _PoolSkipFn.  `out` (c8 flow): the pooled
+    tensor is written into this concat slot."""
     if isinstance(x, Act16):
         N, Cc, D, H, W = x.shape
-        y16 = Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        y16 = out.act16() if out is not None else None
+        if y16 is None:
+            y16 = Act16.empty(N, Cc, (D // 2, H // 2, W // 2), x.compute, x.device)
+        elif y16.shape != (N, Cc, D // 2, H // 2, W // 2):
+            raise _lib.M355Error(f"c8 slot shape {y16.shape} != op output shape {(N, Cc, D // 2, H // 2, W // 2)}")
         skip_t, pooled_t = _PoolC8Fn.apply(x.t, x, y16, True)
         return (Act16(x.data, x.C, x.spatial, x.compute, x.cb0, skip_t),
                 Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, pooled_t))
