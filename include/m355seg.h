@@ -381,6 +381,14 @@ int m355_upsample_trilinear2x_fwd_h16(const void* x16, void* y16, int32_t N, int
 int m355_upsample_trilinear2x_bwd_h16(const void* dy16, void* dx16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                                       int64_t dy16_batch_stride, int64_t dx16_batch_stride, int32_t compute,
                                       void* stream);
+/* space-to-depth / depth-to-space by 2 on c8 activations: the rearrangement around the stride-1 3x3x3 form of
+ * BlurConv3d / BlurConvTranspose3d (segmentation_pipeline/models/components.py:91-154) in the 16-bit flows.  N, C, D, H,
+ * W describe the FULL-resolution tensor (C channels, even sizes); the packed tensor has 8 * C channels (channel
+ * c * 8 + pz * 4 + py * 2 + px = element of c8 block c) at half the resolution.  Each is the other's backward. */
+int m355_space_to_depth2_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                             int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
+int m355_depth_to_space2_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                             int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream);
 /* y16[n][c][s] = x16[n][c][s] * scale[n * C + c]: nn.Dropout3d on a c8 activation (nested_residual_unet.py:43-44,
  * components.py:70-71) and its backward (the same call on the gradient); saturating for fp16. */
 int m355_act16_channel_scale(const void* x16, const float* scale, void* y16, int32_t N, int32_t C, int64_t S,

@@ -88,6 +88,8 @@ SIGNATURES = {
     "m355_upsample_trilinear2x_fwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_upsample_trilinear2x_bwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_act16_channel_scale": (C.c_int, [_P, _P, _P, _i32, _i32, _i64, _i64, _i64, _i32, _P]),
+    "m355_space_to_depth2_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
+    "m355_depth_to_space2_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_conv_transpose3d_h16_bwd_supported": (_i32, [_CD]),
     "m355_conv_transpose3d_h16_bwd_workspace": (_sz, [_CD]),
     "m355_conv_transpose3d_bwd_data_h16": (C.c_int, [_CD, _P, _i64, _P, _P, _i64, _i32, _P]),

@@ -543,6 +543,66 @@ __global__ __launch_bounds__(256) void channel_scale_c8_kernel(const HT* __restr
   }
 }
 
+// space-to-depth / depth-to-space by 2 on c8 activations (the Blur convolutions of the msseg2 family in the 16-bit
+// flows: models/components.py:91-154 run as a stride-1 3x3x3 convolution over the space-to-depth input, resp. producing
+// the 8 output parities).  Packed channel c * 8 + p (p = pz * 4 + py * 2 + px) IS element p of c8 block c of the packed
+// tensor, so the operation is an 8 x 8 transpose of 16-bit values per (half-resolution voxel, block of 8 channels):
+//   TO_DEPTH: 8 items of the full tensor (the 2 x 2 x 2 voxels, 8 channels each) -> 8 items of the packed tensor (8 packed
+//   blocks = the 8 channels, 8 parities each); otherwise the inverse.  C = channels of the FULL tensor.
+template <typename HT, bool TO_DEPTH>
+__global__ __launch_bounds__(256) void s2d_c8_kernel(const HT* __restrict__ src, HT* __restrict__ dst, int N, int C, int D,
+                                                     int H, int W, int64_t fbs, int64_t pbs) {
+  // D, H, W: full resolution; fbs / pbs: batch strides (elements) of the full / packed c8 tensors
+  using hx8 = typename H16<HT>::x8;
+  const int HD = D / 2, HH = H / 2, HW = W / 2;
+  const int CB = (C + 7) / 8;
+  const int64_t S = (int64_t)D * H * W, PS = (int64_t)HD * HH * HW;
+  const int64_t total = (int64_t)N * CB * PS;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int x = (int)(i % HW);
+    int64_t r = i / HW;
+    const int y = (int)(r % HH);
+    r /= HH;
+    const int z = (int)(r % HD);
+    r /= HD;
+    const int cb = (int)(r % CB);
+    const int n = (int)(r / CB);
+    const int64_t pv = ((int64_t)z * HH + y) * HW + x;
+    const int64_t fv0 = ((int64_t)(2 * z) * H + 2 * y) * W + 2 * x;
+    if (TO_DEPTH) {
+      const hx8* fin = reinterpret_cast<const hx8*>(src + (int64_t)n * fbs) + (int64_t)cb * S;
+      hx8 it[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) it[p] = fin[fv0 + ((int64_t)(p >> 2) * H + ((p >> 1) & 1)) * W + (p & 1)];
+      hx8* pout = reinterpret_cast<hx8*>(dst + (int64_t)n * pbs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (cb * 8 + j >= C) break;
+        hx8 o;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) o[p] = it[p][j];
+        pout[(int64_t)(cb * 8 + j) * PS + pv] = o;
+      }
+    } else {
+      const hx8* pin = reinterpret_cast<const hx8*>(src + (int64_t)n * pbs);
+      hx8 it[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const hx8 zero = {};
+        it[j] = cb * 8 + j < C ? pin[(int64_t)(cb * 8 + j) * PS + pv] : zero;
+      }
+      hx8* fout = reinterpret_cast<hx8*>(dst + (int64_t)n * fbs) + (int64_t)cb * S;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        hx8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = it[j][p];
+        fout[fv0 + ((int64_t)(p >> 2) * H + ((p >> 1) & 1)) * W + (p & 1)] = o;
+      }
+    }
+  }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -732,6 +792,37 @@ extern "C" int m355_act16_channel_scale(const void* x16, const float* scale, voi
     hipLaunchKernelGGL(channel_scale_c8_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)x16, scale, (_Float16*)y16, N, C, CB, S, xbs, ybs);
   return check_launch("act16_channel_scale");
+}
+
+static int s2d_c8_common(const void* x16, void* y16, int N, int C, int D, int H, int W, int64_t xbs_, int64_t ybs_,
+                         int compute, void* stream, bool to_depth, const char* who) {
+  M355_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, M355_EUNSUPPORTED, "%s: odd spatial size (%d,%d,%d)", who, D, H, W);
+  const int64_t S = (int64_t)D * H * W;
+  const int64_t fdense = c8_blocks(C) * S * 8, pdense = (int64_t)C * (S / 8) * 8;   // packed: C blocks of 8 parities
+  const int64_t fbs = dense_or(to_depth ? xbs_ : ybs_, fdense), pbs = dense_or(to_depth ? ybs_ : xbs_, pdense);
+  if (int rc = check_c8_op(who, x16, y16, N, C, D, H, W, compute, fbs, pbs)) return rc;
+  const int64_t total = (int64_t)N * c8_blocks(C) * (S / 8);
+  const dim3 grid(grid_for(total, 256, 65536));
+#define M355_S2D(HT, TD) \
+  hipLaunchKernelGGL((s2d_c8_kernel<HT, TD>), grid, dim3(256), 0, (hipStream_t)stream, (const HT*)x16, (HT*)y16, N, C, D, H, W, fbs, pbs)
+  if (compute == M355_COMPUTE_BF16) {
+    if (to_depth) M355_S2D(__bf16, true); else M355_S2D(__bf16, false);
+  } else {
+    if (to_depth) M355_S2D(_Float16, true); else M355_S2D(_Float16, false);
+  }
+#undef M355_S2D
+  return check_launch(who);
+}
+
+extern "C" int m355_space_to_depth2_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                        int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream) {
+  return s2d_c8_common(x16, y16, N, C, D, H, W, x16_batch_stride, y16_batch_stride, compute, stream, true,
+                       "space_to_depth2_h16");
+}
+extern "C" int m355_depth_to_space2_h16(const void* x16, void* y16, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                                        int64_t x16_batch_stride, int64_t y16_batch_stride, int32_t compute, void* stream) {
+  return s2d_c8_common(x16, y16, N, C, D, H, W, x16_batch_stride, y16_batch_stride, compute, stream, false,
+                       "depth_to_space2_h16");
 }
 
 extern "C" int m355_softmax_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t inner,

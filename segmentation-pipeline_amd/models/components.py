@@ -126,13 +126,16 @@ class BlurConv3d(nn.Conv3d):
 
     def forward(self, x):
         stride, pad = _uniform_int(self.stride, "stride"), _uniform_int(self.padding, "padding")
-        even = isinstance(x, torch.Tensor) and all(s % 2 == 0 for s in x.shape[2:])
+        # (a c8 activation of the 16-bit flows is converted by space_to_depth2 -- it must not fall to the generic
+        # strided kernel below, which is a direct fp32 kernel)
+        even = isinstance(x, (torch.Tensor, ops.Act16)) and all(s % 2 == 0 for s in x.shape[2:])
         if _uniform_int(self.kernel_size, "kernel_size") == 3 and stride == 2 and pad == 1 and even:
             # effective 4x4x4 / stride 2 / padding 1 = a stride-1 3x3x3 conv over the space-to-depth input
             # (MFMA path); standardisation + box blur + rearrangement of the filter in one HIP kernel
             wexp = _derived_weight(self, "s2d", lambda: ops.blur_weight(
                 self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization))
-            return ops.conv3d(ops.space_to_depth2(x), wexp, None, stride=1, padding=1)
+            # (16-bit flows: a c8 activation is rearranged in c8 and the conv returns c8 for the block that follows)
+            return ops.conv3d(ops.space_to_depth2(x), wexp, None, stride=1, padding=1, c8_out=isinstance(x, ops.Act16))
         return run_conv(self, x)
 
 
@@ -156,7 +159,8 @@ class BlurConvTranspose3d(nn.ConvTranspose3d):
             # depth-to-space (MFMA path); filter transform in one HIP kernel
             wexp = _derived_weight(self, "d2s", lambda: ops.blur_weight(
                 self.weight, _blur_scale(self.kernel, self.weight), self.weight_standardization, transposed=True))
-            return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1), out=out)
+            c8 = isinstance(x, ops.Act16) and (out is None or out.buf16 is not None)   # 16-bit flows: parities in c8, then c8 -> c8
+            return ops.depth_to_space2(ops.conv3d(x, wexp, None, stride=1, padding=1, c8_out=c8), out=out)
         w = self.weight
         if self.weight_standardization:
             w = ops.weight_standardize(w)

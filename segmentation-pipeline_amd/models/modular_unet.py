@@ -25,7 +25,7 @@ def _run_downsample(m, x):
             raise NotImplementedError("only AvgPool3d(kernel_size=2, stride=2) has a HIP kernel")
         return None if x is None else ops.avgpool3d_2x(x)
     if isinstance(m, BlurConv3d):
-        return m(ops.as_f32(x))
+        return m(x)      # (a c8 activation of the 16-bit flows stays c8: space-to-depth and the conv run on c8)
     if isinstance(m, nn.Conv3d):  # WSConv3d / strided nn.Conv3d
         return run_conv(m, x)
     raise NotImplementedError(f"downsample_class {type(m).__name__} has no HIP kernel")

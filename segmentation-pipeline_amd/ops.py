@@ -1858,12 +1858,66 @@ class _S2DFn(torch.autograd.Function):
         return dx, None, None
 
 
+def _s2d_c8(src_ptr, sbs, dst_ptr, dbs, full_shape, compute, to_depth):
+    """c8 -> c8; `full_shape` = (N, C, D, H, W) of the FULL-resolution tensor"""
+    N, Cc, D, H, W = full_shape
+    L = _lib.lib()
+    fn = L.m355_space_to_depth2_h16 if to_depth else L.m355_depth_to_space2_h16
+    check(fn(src_ptr, dst_ptr, N, Cc, D, H, W, sbs, dbs, compute, _stream()),
+          "space_to_depth2_h16" if to_depth else "depth_to_space2_h16")
+
+
+class _S2DC8Fn(torch.autograd.Function):
+    """space-to-depth (to_depth=True) or depth-to-space by 2 on c8 activations; each is the other's backward (on the c8
+    gradient)"""
+
+    @staticmethod
+    def forward(ctx, x_t, x: Act16, y16: Act16, to_depth: bool):
+        full = x.shape if to_depth else y16.shape
+        _s2d_c8(x.ptr(), x.batch_stride(), y16.ptr(), y16.batch_stride(), full, x.compute, to_depth)
+        ctx.info = (full, x.compute, to_depth, x.shape)
+        return y16.alias()
+
+    @staticmethod
+    def backward(ctx, dy16):
+        full, compute, to_depth, xshape = ctx.info
+        dy16, dybs = _c8t(dy16)
+        S = xshape[2] * xshape[3] * xshape[4]
+        dx16 = torch.empty((xshape[0], (xshape[1] + 7) // 8, S, 8), dtype=_DT16[compute], device=dy16.device)
+        _s2d_c8(_p(dy16), dybs, _p(dx16), 0, full, compute, not to_depth)
+        return dx16, None, None, None
+
+
+def _s2d_act16(x: Act16, to_depth: bool, out: Optional[OutSlot]):
+    N, Cc, D, H, W = x.shape
+    if to_depth:
+        oshape = (N, Cc * 8, D // 2, H // 2, W // 2)
+    else:
+        if Cc % 8:
+            raise _lib.M355Error(f"depth_to_space2: {Cc} channels are not 8 parities per output channel")
+        oshape = (N, Cc // 8, 2 * D, 2 * H, 2 * W)
+    y16 = out.act16() if out is not None else None
+    if y16 is None:
+        y16 = Act16.empty(oshape[0], oshape[1], oshape[2:], x.compute, x.device)
+    elif y16.shape != oshape:
+        raise _lib.M355Error(f"c8 slot shape {y16.shape} != op output shape {oshape}")
+    if _act16_tracks(x):
+        return Act16(y16.data, y16.C, y16.spatial, y16.compute, y16.cb0, _S2DC8Fn.apply(x.t, x, y16, to_depth))
+    _s2d_c8(x.ptr(), x.batch_stride(), y16.ptr(), y16.batch_stride(), x.shape if to_depth else oshape, x.compute, to_depth)
+    return y16
+
+
 def space_to_depth2(x):
-    """[N, C, D, H, W] -> [N, 8C, D/2, H/2, W/2], channel c*8 + (pz*4 + py*2 + px)."""
+    """[N, C, D, H, W] -> [N, 8C, D/2, H/2, W/2], channel c*8 + (pz*4 + py*2 + px).  A c8 activation stays c8 (the packed
+    channels of input channel c are exactly c8 block c)."""
+    if isinstance(x, Act16) and all(v % 2 == 0 for v in x.shape[2:]):
+        return _s2d_act16(x, True, None)
     return _S2DFn.apply(as_f32(x), True, None)
 
 
 def depth_to_space2(x, out: Optional[OutSlot] = None):
+    if isinstance(x, Act16) and x.C % 8 == 0 and (out is None or out.buf16 is not None):
+        return _s2d_act16(x, False, out)
     if out is not None and out.buf16 is not None:
         return pack_act16(_S2DFn.apply(as_f32(x), False, None), out.buf16.compute, out.act16())
     return _S2DFn.apply(as_f32(x), False, out)

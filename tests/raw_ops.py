@@ -343,6 +343,24 @@ class RawOps:
                                                  self._stream()), "act16_channel_scale")
         return y16
 
+    def s2d_h16(self, x16, full_shape, compute, to_depth, pad_batch=0):
+        """space-to-depth (to_depth) / depth-to-space by 2, c8 -> c8; `full_shape` = (N, C, D, H, W) of the full-resolution
+        tensor; pad_batch: unused channel blocks per sample of the destination"""
+        N, Cc, D, H, W = full_shape
+        S = D * H * W
+        CBp = x16.shape[1]
+        if to_depth:
+            y16 = torch.full((N, Cc + pad_batch, S // 8, 8), 7.0, dtype=x16.dtype, device=self.device)
+            xbs, ybs = CBp * S * 8, (Cc + pad_batch) * (S // 8) * 8
+            fn = self.fn("space_to_depth2_h16")
+        else:
+            CB = (Cc + 7) // 8
+            y16 = torch.full((N, CB + pad_batch, S, 8), 7.0, dtype=x16.dtype, device=self.device)
+            xbs, ybs = CBp * (S // 8) * 8, (CB + pad_batch) * S * 8
+            fn = self.fn("depth_to_space2_h16")
+        self._chk(fn(_p(x16), _p(y16), N, Cc, D, H, W, xbs, ybs, compute, self._stream()), "s2d_h16")
+        return y16
+
     def convt_h16_bwd_supported(self, x_shape, Cout):
         d = self.conv_desc(x_shape, Cout, 2, 2, 0)
         return bool(self.lib.m355_conv_transpose3d_h16_bwd_supported(C.byref(d)))

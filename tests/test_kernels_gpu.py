@@ -1206,6 +1206,29 @@ def test_trilinear_upsample_c8(hip, compute):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_space_to_depth_c8(hip, oracle, compute):
+    """m355_space_to_depth2_h16 / m355_depth_to_space2_h16 == the fp32 rearrangement of the 16-bit values (pure data
+    movement: bit-exact), each the inverse of the other; channel counts that are no multiple of 8 (zero padding of the
+    last block is kept), N = 2, a padded destination."""
+    dt = _dt(compute)
+    for (N, Cc, D, H, W, pad) in [(2, 16, 4, 6, 8, 0), (1, 13, 2, 4, 6, 1), (1, 40, 6, 2, 10, 0), (1, 3, 2, 2, 2, 2)]:
+        x = rnd(N, Cc, D, H, W, seed=1)
+        xr = x.to(dt).float()
+        ref = oracle.space_to_depth(xr)                                   # [N, 8C, D/2, H/2, W/2]
+        x16 = hip.act16_pack(x, compute)
+        p16 = hip.s2d_h16(x16, (N, Cc, D, H, W), compute, True, pad_batch=pad)
+        got = _c8_to_ncdhw(p16[:, :Cc], 8 * Cc, (D // 2, H // 2, W // 2))
+        assert torch.equal(got, ref)
+        if pad:
+            assert (p16[:, Cc:] == 7.0).all(), "wrote outside its channel blocks"
+        back = hip.s2d_h16(p16[:, :Cc].contiguous(), (N, Cc, D, H, W), compute, False, pad_batch=pad)
+        CB = (Cc + 7) // 8
+        assert torch.equal(back[:, :CB], x16), "depth-to-space is not the inverse (incl. the zero padding of the last block)"
+        if pad:
+            assert (back[:, CB:] == 7.0).all()
+
+
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
 def test_channel_scale_c8(hip, compute):
     """m355_act16_channel_scale (Dropout3d mask on a c8 activation): one rounding of x16 * scale[n, c]; channels past C
     stay zero; fp16 saturates instead of overflowing"""

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Who still packs fp32 -> c8 in a 16-bit train step of msseg2 (diagnostic): call sites of ops.pack_act16 / _pack_scaled /
+Act16.to_f32, counted over one step."""
+import collections, os, sys, traceback, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import segmentation_pipeline_amd as sp
+from segmentation_pipeline_amd import ops
+from segmentation_pipeline_amd.models import ModularUNet, BlurConv3d, BlurConvTranspose3d
+from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+sp.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
+m = ModularUNet(2, 2, [40, 40, 80, 80, 120, 120], 6, block_params={'residual': True}, downsample_class=BlurConv3d,
+                downsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1}, upsample_class=BlurConvTranspose3d,
+                upsample_params={'kernel_size': 3, 'stride': 2, 'padding': 1, 'output_padding': 0}).cuda().train()
+x = torch.randn(1, 2, 96, 96, 96, device="cuda")
+y = torch.nn.functional.one_hot(torch.randint(0, 2, (1, 96, 96, 96), device="cuda"), 2).permute(0, 4, 1, 2, 3).float().contiguous()
+cnt = collections.Counter()
+def wrap(name, fn):
+    def w(*a, **k):
+        st = traceback.extract_stack(limit=7)[:-1]
+        cnt[(name, " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in reversed(st[-5:])))] += 1
+        return fn(*a, **k)
+    return w
+ops.pack_act16 = wrap("pack_act16", ops.pack_act16)
+ops._pack_scaled = wrap("_pack_scaled", ops._pack_scaled)
+ops._unpack_scaled = wrap("_unpack_scaled", ops._unpack_scaled)
+ops.Act16.to_f32 = wrap("to_f32", ops.Act16.to_f32)
+crit = HybridLogisticDiceLoss(logistic_class_weights=[1, 100])
+crit(m(x), y)["loss"].backward()
+torch.cuda.synchronize()
+for (n, st), c in cnt.most_common(30):
+    print(c, n, st)
