@@ -359,6 +359,24 @@ def test_msseg2_full_size_residual_blur_bn_vs_cpu_oracle():
         with torch.no_grad(), sp.precision(mode):
             err = (model(x.cuda()).cpu() - p_ref.detach()).abs().max().item()
         assert 1e-7 < err <= tol, (mode, err)
+    # ... and a TRAINING step in the 16-bit modes: the whole network on the c8-only flow, the Blur convolutions included
+    # (c8 space-to-depth / depth-to-space around their stride-1 form): all parameter gradients together against the fp32
+    # oracle's -- direction and size (class weights [1, 100])
+    names = [k for k, v in model.named_parameters() if sd[k].grad is not None]
+    ref_all = torch.cat([sd[k].grad.double().flatten() for k in names])
+    params = dict(model.named_parameters())
+    for mode, tol, cos_min in (("bf16", 2e-2, 0.9995), ("fp16", 5e-3, 0.9999)):
+        model.zero_grad(set_to_none=True)
+        with sp.precision(mode):
+            p16 = model(x.cuda())
+            HybridLogisticDiceLoss(logistic_class_weights=[1, 100])(p16, y.cuda())["loss"].backward()
+        assert (p16.detach().cpu() - p_ref.detach()).abs().max().item() <= tol, mode
+        got = torch.cat([params[k].grad.cpu().double().flatten() for k in names])
+        assert torch.isfinite(got).all(), mode
+        cos = float(got @ ref_all / (got.norm() * ref_all.norm()))
+        ratio = float(got.norm() / ref_all.norm())
+        print(f"msseg2 {mode} c8 training flow vs fp32 oracle: all-parameter cosine {cos:.5f}, norm ratio {ratio:.4f}")
+        assert cos >= cos_min and abs(ratio - 1) <= 0.05, (mode, cos, ratio)
     torch.cuda.empty_cache()
 
 
