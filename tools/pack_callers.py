@@ -40,7 +40,12 @@ ops._pack_scaled = wrap("_pack_scaled", ops._pack_scaled)
 ops._unpack_scaled = wrap("_unpack_scaled", ops._unpack_scaled)
 ops.Act16.to_f32 = wrap("to_f32", ops.Act16.to_f32)
 crit = HybridLogisticDiceLoss()
-crit(m(x), y)["loss"].backward()
+if "infer" in sys.argv:     # the no-grad c8 flow
+    m.eval()
+    with torch.no_grad():
+        m(x)
+else:
+    crit(m(x), y)["loss"].backward()
 torch.cuda.synchronize()
 for (n, st), c in cnt.most_common(30):
     print(c, n, st)
