@@ -93,9 +93,10 @@ class GraphedTrainStep:
     graph's private pool during capture), the packed weights are refreshed by a kernel that is part of the captured
     step (the capture starts right after an eager optimizer step, when every packed form is stale), and the work-queue
     state lives in the per-stream pool of the library.  Static shapes: batches are copied into the captured input
-    buffers.  Not capturable (raises): active Dropout3d (host-side mask draw), BatchNorm with momentum=None (host
-    read of num_batches_tracked), a PatchParallel wrapper (collectives), optimizers that read state on the host
-    (use capturable=True for Adam)."""
+    buffers.  Dropout3d is fine: its channel masks are drawn on the device with torch's CUDA generator, which advances its
+    philox offset on every replay (a new mask per step; tools/graph_dropout_probe.py).  Not capturable (raises): BatchNorm
+    with momentum=None (host read of num_batches_tracked), a PatchParallel wrapper (collectives); optimizers that read
+    state on the host need capturable=True (Adam)."""
 
     def __init__(self, model, criterion, optimizer, warmup: int = 3):
         self.model, self.criterion, self.optimizer, self.warmup = model, criterion, optimizer, max(1, warmup)
@@ -106,8 +107,6 @@ class GraphedTrainStep:
         if isinstance(self.model, D.PatchParallel):
             raise NotImplementedError("GraphedTrainStep: capture the wrapped module, not the PatchParallel wrapper")
         for m in self.model.modules():
-            if isinstance(m, nn.Dropout3d) and m.p > 0:
-                raise NotImplementedError("GraphedTrainStep: Dropout3d draws its mask on the host")
             if isinstance(m, nn.BatchNorm3d) and m.momentum is None and m.track_running_stats:
                 raise NotImplementedError("GraphedTrainStep: BatchNorm3d(momentum=None) reads num_batches_tracked on the host")
 

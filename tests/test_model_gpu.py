@@ -356,6 +356,27 @@ def test_packed_weights_are_shared_across_input_shapes():
     assert sorted(k[0] for k in conv_w._m355_packed[2]) == [0, 1]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_graphed_train_step_redraws_dropout_masks(mode):
+    """Dropout3d inside a captured train step (dmri_hippo: NestedResUNet(dropout_p=0.2)): the channel masks come from torch's
+    CUDA generator, which moves on with every replay -- with lr = 0 the mask is the only thing that changes, and the
+    losses of consecutive replays differ; eval() forwards outside the graph stay deterministic."""
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    m = NestedResUNet(3, 2, 8, dropout_p=0.5).cuda()
+    x = torch.randn(2, 3, 16, 16, 16, device="cuda")
+    y = torch.nn.functional.one_hot(torch.randint(0, 2, (2, 16, 16, 16), device="cuda"), 2).permute(0, 4, 1, 2, 3).float().contiguous()
+    with sp.precision(mode):
+        step = GraphedTrainStep(m, HybridLogisticDiceLoss(), torch.optim.SGD(m.parameters(), lr=0.0))
+        losses = [float(step({"X": x, "y": y})["loss"]) for _ in range(7)]
+        assert all(l == l and abs(l) < 10 for l in losses)
+        assert len(set(losses[1:])) >= 5, losses      # (call 0 returns the last eager warm-up step)
+        m.eval()
+        with torch.no_grad():
+            assert torch.equal(m(x), m(x))
+
+
 @pytest.mark.parametrize("mode,norm", [("fp32", "group"), ("bf16", "group"), ("bf16", "batch")])
 def test_graphed_train_step_reproduces_the_eager_trajectory(mode, norm):
     """trainer.GraphedTrainStep: the whole training iteration replayed from a hipGraph -- losses, final weights and
