@@ -289,6 +289,7 @@ def parse_args(argv=None):
                     help="wire type of the gradient all-reduce buckets (bf16 halves the RCCL volume; fp32 master gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra bf16 (BASELINE cfg3) measurement of the cfg2 / fp32 line")
     ap.add_argument("--launch-probe", default=None, help=argparse.SUPPRESS)   # tests: each rank writes its env here and exits
     args = ap.parse_args(argv)
     if args.workload == "cfg3":
@@ -337,6 +338,13 @@ def main():
         out = run_window(args, rank, world, device)
     else:
         out = run_train(args, rank, world, device, force_ddp)
+        if args.workload == "cfg2" and args.precision == "fp32" and not args.no_cfg3:
+            # BASELINE cfg3 (same net, bf16 operands) under the same clock as the headline: K train steps + K forwards
+            torch.cuda.empty_cache()
+            c3 = run_train(args, rank, world, device, force_ddp, precision="bf16")
+            sp.set_precision(args.precision)
+            if rank == 0:
+                out["cfg3"] = c3
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -369,13 +377,20 @@ def dtype_label(precision):
     return "f32" if precision == "fp32" else f"{precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere"
 
 
-def run_train(args, rank, world, device, force_ddp):
+def run_train(args, rank, world, device, force_ddp, precision=None):
+    """precision=None: the workload's own line (args.precision).  precision="bf16" on a cfg2 / fp32 invocation: the
+    BASELINE cfg3 numbers (same network, same patch, 16-bit operands) measured by the SAME command after the fp32
+    timed region, returned as the extra "cfg3" object of the same JSON line (so the driver's clock covers them)."""
     from segmentation_pipeline_amd import distributed as D
     from segmentation_pipeline_amd import ops
     from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
     from segmentation_pipeline_amd.prediction import StandardPredict
     from segmentation_pipeline_amd.trainer import PhaseTimer, hard_dice_from_counts, train_step
 
+    import segmentation_pipeline_amd as sp
+    extra = precision is not None
+    precision = precision or args.precision
+    sp.set_precision(precision)
     cfg = WORKLOADS[args.workload]
     cin, cout, filters, depth, patch = cfg
     model = build_model(cfg).to(device)
@@ -409,7 +424,7 @@ def run_train(args, rank, world, device, force_ddp):
     if ops.CONV_PROFILE is not None:
         torch.cuda.synchronize()
         prof_w, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        ops.CONV_PROFILE_KEYS, ops.CONV_PROFILE_EVERY = dominant_keys(prof_w, args.precision)
+        ops.CONV_PROFILE_KEYS, ops.CONV_PROFILE_EVERY = dominant_keys(prof_w, precision)
     # A full (generation-2) collection of CPython's cyclic GC walks every object alive -- ~90 ms with torch
     # imported -- and lands at an arbitrary step (measured with tools/step_trace.py: one such host stall drains
     # the launch queue and idles the GPU for ~8 ms; on a 12 ms step that is +2..4 ms/step of noise in a 10-20 step
@@ -430,10 +445,12 @@ def run_train(args, rank, world, device, force_ddp):
     value = world * args.batch * args.steps / elapsed
 
     # per-phase breakdown (TorchTimer semantics: a sync per stamp), outside the timed region
-    timer = PhaseTimer(device)
-    for _ in range(2):
-        train_step(runner, crit, opt, predictor, batch, device, timer)
-    phases = {k: v / 2 * 1e3 for k, v in timer.timestamps.items()}
+    phases = None
+    if not extra:
+        timer = PhaseTimer(device)
+        for _ in range(2):
+            train_step(runner, crit, opt, predictor, batch, device, timer)
+        phases = {k: v / 2 * 1e3 for k, v in timer.timestamps.items()}
 
     # ---- inference: K no-grad forwards ----
     infer, prof_inf = None, None
@@ -447,7 +464,7 @@ def run_train(args, rank, world, device, force_ddp):
                 model(x)
             if ops.CONV_PROFILE is not None:
                 torch.cuda.synchronize()
-                ops.CONV_PROFILE_KEYS, _ = dominant_keys(ops.CONV_PROFILE, args.precision)
+                ops.CONV_PROFILE_KEYS, _ = dominant_keys(ops.CONV_PROFILE, precision)
             ops.CONV_PROFILE = None
             barrier()
             t0 = time.perf_counter()
@@ -466,12 +483,24 @@ def run_train(args, rank, world, device, force_ddp):
         ti = max_over_ranks(ti, device)
         infer = {"value": world * args.batch * args.steps / ti, "unit": "patches/s", "ms_per_step": ti / args.steps * 1e3}
 
+    gc.unfreeze()
     if rank != 0:
         return None
     # ---- roofline of the dominant conv kernel of the timed train region (and of the inference region) ----
-    roofline = roofline_of(prof, args.precision, prof_w)
+    roofline = roofline_of(prof, precision, prof_w)
     if infer is not None and prof_inf:
-        infer["roofline"] = roofline_of(prof_inf, args.precision)
+        infer["roofline"] = roofline_of(prof_inf, precision)
+    if extra:
+        # the cfg3 object of the headline line: same keys as a line of its own, without the CPU leg / Dice block
+        return {"ms_per_step": elapsed / args.steps * 1e3, "value": value, "unit": "patches/s",
+                "infer_ms": infer["ms_per_step"] if infer else None, "infer_value": infer["value"] if infer else None,
+                "steps": args.steps, "warmup": args.warmup, "dtype": dtype_label(precision), "roofline": roofline,
+                "infer_roofline": infer.get("roofline") if infer else None,
+                "conv_kernels": conv_summary_of(prof_w, 1) if prof_w else None,
+                "final_loss": float(loss_dict["loss"].detach()),
+                "gpu_soft_dice_loss_step0": gpu_dice0,
+                "workload": "BASELINE cfg3 on this rank count: the cfg2 network and patch with bf16 conv operands "
+                            "(fp32 accumulate), timed by this same command after the fp32 region"}
     # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
     conv_summary = conv_summary_of(prof_w, 1) if prof_w else conv_summary_of(prof, args.steps)
     wire = 2 if args.bucket_dtype == "bf16" else 4
@@ -479,7 +508,7 @@ def run_train(args, rank, world, device, force_ddp):
     out = {
         "metric": METRIC, "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(args.precision), "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(precision), "data": "synthetic",
         "config": {"workload": f"{args.workload}: train step (fwd+loss+bwd+SGD) of ModularUNet({cin},{cout},"
                                f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
                    "global_batch": world * args.batch, "params": n_params,

@@ -14,7 +14,15 @@
  *    explicit (in elements) wherever a tensor may be a channel slice of a
  *    larger concat buffer; 0 means dense (C*D*H*W).
  *  - Caller owns every buffer, including workspace.  The library never
- *    allocates, frees or retains device memory.
+ *    frees device memory and keeps no pointer to a tensor or workspace after a
+ *    call returns.  The ONE piece of device state it keeps is the work-queue
+ *    pool of the queue-driven conv kernels (256 KB per device: 4096 slots of
+ *    eight ticket counters + an exit counter, all zero between launches).  A
+ *    caller that hands that pool over with m355_queue_pool_set() before its
+ *    first conv launch on a device -- the Python host does, from torch's
+ *    allocator -- gets a library that makes no device allocation at all;
+ *    otherwise the pool is hipMalloc'ed + hipMemset on first use (never inside
+ *    a stream capture) and lives until the process exits.
  *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as
  *    void*); no implicit synchronisation.
  *  - Return 0 (M355_OK) or a negative status; never throws, never aborts.
@@ -31,8 +39,11 @@ extern "C" {
 #endif
 
 /* 2: m355_conv3d_desc.reserved became `flags` (packed weights, fused softmax); c8 / 16-bit entry points; ensembles;
- * padded sliding window; weight standardisation */
-#define M355_ABI_VERSION 2
+ * padded sliding window; weight standardisation
+ * 3: c8-only training flow (norm / pool / conv-transpose / trilinear / dropout / space-to-depth backward on c8 tensors,
+ *    loss-scaled pack / unpack), device-side sampler, one-pass grid aggregation, caller-provided work-queue pool
+ *    (m355_queue_pool_*), fused norm-backward tail */
+#define M355_ABI_VERSION 3
 
 enum {
   M355_OK = 0,
@@ -68,6 +79,13 @@ const char* m355_last_error(void);
 /* The M355_* tuning overrides (test / sweep hooks: M355_CONV_NTW, M355_CONV_KSPLIT, M355_CONV_SLOTS, ...) are
  * read from the environment once, when the library is loaded; call this after changing them. */
 void m355_reload_tuning(void);
+/* Work-queue pool (see "Conventions"): `zeroed_device_buffer` = m355_queue_pool_bytes() bytes of zero-filled device
+ * memory on `device`, 64-byte aligned, owned by the caller and kept alive (and otherwise untouched) for as long as the
+ * library is used on that device.  Call before the first conv launch on the device; M355_EUNSUPPORTED once a different
+ * pool is in use there.  Every queue-driven launch takes a 64-byte slot keyed by (device, stream, capture id): launches
+ * on different streams, and launch sequences captured into different hipGraphs, never share one. */
+size_t m355_queue_pool_bytes(void);
+int m355_queue_pool_set(void* zeroed_device_buffer, size_t bytes, int32_t device);
 
 /* ------------------------------------------------------------------ conv3d
  * Replaces nn.Conv3d as used by Block3d (models/components.py:36,42,51) and the
@@ -95,8 +113,8 @@ enum {
    * m355_conv3d_pack for THIS descriptor (same shapes, compute mode and direction) instead of the torch-layout
    * filter: the per-launch repacking kernel is skipped.  Weights only change at optimizer.step, so a caller
    * packs once per parameter version.  The buffer is read-only for the conv kernels: any number of launches, on any
-   * streams, may share it concurrently (the work-queue state of the queue-driven kernels lives in a per-stream slot
-   * of a small pool the library owns -- the one allocation it makes, 256 KB per device on first use). */
+   * streams, may share it concurrently (the work-queue state of the queue-driven kernels lives in a per-(stream,
+   * capture) slot of the work-queue pool, see "Conventions" above and m355_queue_pool_set). */
   M355_CONV_W_PACKED = 1,
   /* forward only: nn.Softmax(dim=1) over the Cout output channels applied in the conv epilogue (the out conv +
    * hypothesis of ModularUNet, models/modular_unet.py:99-100); allowed when m355_conv3d_fuses_softmax(desc) != 0

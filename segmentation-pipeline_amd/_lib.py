@@ -45,7 +45,7 @@ class NormDesc(C.Structure):
 
 
 _P = C.c_void_p
-ABI_VERSION = 2   # M355_ABI_VERSION of include/m355seg.h this binding was written against
+ABI_VERSION = 3   # M355_ABI_VERSION of include/m355seg.h this binding was written against
 _i32, _i64, _f32, _sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _CD, _ND = C.POINTER(ConvDesc), C.POINTER(NormDesc)
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "m355_version": (C.c_int, []),
     "m355_last_error": (C.c_char_p, []),
     "m355_reload_tuning": (None, []),
+    "m355_queue_pool_bytes": (_sz, []),
+    "m355_queue_pool_set": (C.c_int, [_P, _sz, _i32]),
     "m355_conv3d_fuses_softmax": (_i32, [_CD]),
     "m355_conv3d_packed_bytes": (_sz, [_CD, _i32]),
     "m355_conv3d_pack": (C.c_int, [_CD, _i32, _P, _P, _P]),
@@ -191,6 +193,28 @@ def lib():
         if _lib.m355_version() != ABI_VERSION:
             raise M355Error(f"ABI version mismatch: library reports {_lib.m355_version()}, expected {ABI_VERSION}")
     return _lib
+
+
+_queue_pools = {}   # device index -> the zero-filled tensor handed to m355_queue_pool_set (kept alive here)
+
+
+def ensure_queue_pool(device):
+    """Hand the library its work-queue pool for `device` from torch's allocator (once per device): with this host the
+    library never allocates device memory itself (include/m355seg.h, "Conventions")."""
+    idx = device.index if device.index is not None else 0
+    if idx in _queue_pools:
+        return
+    import torch
+    L = lib()
+    n = int(L.m355_queue_pool_bytes())
+    with torch.cuda.device(idx):
+        if torch.cuda.is_current_stream_capturing():
+            return   # (a capture's warm-up ran eagerly before: the pool exists unless the caller skipped the warm-up)
+        buf = torch.zeros(n, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream().synchronize()
+    rc = L.m355_queue_pool_set(C.c_void_p(buf.data_ptr()), n, idx)
+    # M355_EUNSUPPORTED: another binding in this process already set / allocated one -- fine, it is in use
+    _queue_pools[idx] = buf if rc == M355_OK else None
 
 
 def reload_tuning():

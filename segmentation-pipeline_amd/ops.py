@@ -119,6 +119,9 @@ def _require(*tensors, dtype=torch.float32):
 
 
 def _workspace(nbytes, device):
+    # (every conv launch asks for its workspace here first: the one place that hands the library its work-queue pool)
+    if device.index not in _lib._queue_pools:
+        _lib.ensure_queue_pool(device)
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 

@@ -87,12 +87,13 @@ class GraphedTrainStep:
     segmentation_trainer.py:162-180) captured ONCE into a hipGraph and replayed: one launch per step instead of the
     ~400 of a production architecture.  Where the step is host-bound -- msseg2 in the 16-bit modes: the GPU needs
     ~8 ms, the Python / ctypes enqueue ~10 ms -- the replay runs at GPU speed; where it is GPU-bound (cfg2, fp32
-    anything) it changes nothing.  The loss trajectory is bit-identical to the eager loop (tests).
+    anything) it changes nothing.  The loss trajectory is bit-identical to the plain eager loop, call by call (tests): the first
+    `warmup` calls are eager steps on their own batches, the next call captures and replays.
 
     Works because every launch of the library goes to the current stream, workspaces come from torch's allocator (the
     graph's private pool during capture), the packed weights are refreshed by a kernel that is part of the captured
     step (the capture starts right after an eager optimizer step, when every packed form is stale), and the work-queue
-    state lives in the per-stream pool of the library.  Static shapes: batches are copied into the captured input
+    state lives in a per-(stream, capture) slot of the library's work-queue pool.  Static shapes: batches are copied into the captured input
     buffers.  Dropout3d is fine: its channel masks are drawn on the device with torch's CUDA generator, which advances its
     philox offset on every replay (a new mask per step; tools/graph_dropout_probe.py).  Not capturable (raises): BatchNorm
     with momentum=None (host read of num_batches_tracked), a PatchParallel wrapper (collectives); optimizers that read
@@ -105,7 +106,8 @@ class GraphedTrainStep:
     def _check(self):
         from torch import nn
         if isinstance(self.model, D.PatchParallel):
-            raise NotImplementedError("GraphedTrainStep: capture the wrapped module, not the PatchParallel wrapper")
+            raise NotImplementedError("GraphedTrainStep: capture the wrapped module, not the PatchParallel wrapper "
+                                      "(SegmentedGraphTrainStep replays the step between the gradient collectives)")
         for m in self.model.modules():
             if isinstance(m, nn.BatchNorm3d) and m.momentum is None and m.track_running_stats:
                 raise NotImplementedError("GraphedTrainStep: BatchNorm3d(momentum=None) reads num_batches_tracked on the host")
@@ -118,7 +120,12 @@ class GraphedTrainStep:
         return ld
 
     def __call__(self, batch):
-        """batch: {"X": ..., "y": ...} device tensors -> loss dict (tensors valid until the next call)"""
+        """batch: {"X": ..., "y": ...} device tensors -> loss dict (tensors valid until the next call).
+
+        The trajectory is that of the plain eager loop, call by call: the first `warmup` calls of a (shape, dtype,
+        precision) key ARE eager steps, each on its own incoming batch (they fill the optimizer state, the packed-weight
+        caches and the allocator); call warmup + 1 captures the step -- a capture executes nothing -- and replays it on
+        that call's batch.  (Round 3 ran `warmup` steps on the first batch instead: batch 0 was applied three times.)"""
         from . import ops
         x, y = batch["X"], batch["y"]
         self.model.train()
@@ -126,28 +133,24 @@ class GraphedTrainStep:
         ent = self._graphs.get(key)
         if ent is None:
             self._check()
+            ent = self._graphs[key] = {"eager_calls": 0, "graph": None}
+        if ent["graph"] is None:
+            if ent["eager_calls"] < self.warmup:
+                ent["eager_calls"] += 1
+                return {k: v.detach() for k, v in self._eager(x, y).items()}
             sx, sy = x.clone(), y.clone()
-            side = torch.cuda.Stream(device=x.device)
-            side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):
-                for _ in range(self.warmup):          # eager steps: optimizer state, caches, allocator (they DO train)
-                    ld = self._eager(sx, sy)
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            out = {k: v.detach().clone() for k, v in ld.items()}
             graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
                 ld = self.criterion(self.model(sx), sy)
                 ld["loss"].backward()
                 self.optimizer.step()
-            self._graphs[key] = (graph, sx, sy, {k: v.detach() for k, v in ld.items()})
-            self.steps_done = self.warmup
-            return out                                # (the result of the last warm-up step; the capture did not execute)
-        graph, sx, sy, static = ent
-        sx.copy_(x)
-        sy.copy_(y)
-        graph.replay()
-        return {k: v.clone() for k, v in static.items()}
+            ent.update(graph=graph, sx=sx, sy=sy, static={k: v.detach() for k, v in ld.items()})
+        else:
+            ent["sx"].copy_(x)
+            ent["sy"].copy_(y)
+        ent["graph"].replay()
+        return {k: v.clone() for k, v in ent["static"].items()}
 
 
 class TrainLoop:

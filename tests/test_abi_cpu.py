@@ -30,7 +30,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_and_reports_version():
     L = _lib.lib()
-    assert L.m355_version() == 2
+    assert L.m355_version() == 3 == _lib.ABI_VERSION
+    assert L.m355_queue_pool_bytes() == 4096 * 64
+    # argument validation of the pool hand-over needs no GPU
+    assert L.m355_queue_pool_set(None, 4096 * 64, 0) == -1 and b"queue_pool_set" in L.m355_last_error()
+    assert L.m355_queue_pool_set(ctypes.c_void_p(64), 16, 0) == -1
     assert L.m355_last_error() is not None
 
 

@@ -371,7 +371,7 @@ def test_graphed_train_step_redraws_dropout_masks(mode):
         step = GraphedTrainStep(m, HybridLogisticDiceLoss(), torch.optim.SGD(m.parameters(), lr=0.0))
         losses = [float(step({"X": x, "y": y})["loss"]) for _ in range(7)]
         assert all(l == l and abs(l) < 10 for l in losses)
-        assert len(set(losses[1:])) >= 5, losses      # (call 0 returns the last eager warm-up step)
+        assert len(set(losses[1:])) >= 5, losses
         m.eval()
         with torch.no_grad():
             assert torch.equal(m(x), m(x))
@@ -401,15 +401,9 @@ def test_graphed_train_step_reproduces_the_eager_trajectory(mode, norm):
         opt_g = torch.optim.SGD(m_g.parameters(), lr=1e-2, momentum=0.9)
         step = GraphedTrainStep(m_g, crit, opt_g, warmup=3)
         losses_e, losses_g = [], []
-        # the graphed stepper spends its first call on 3 eager warm-up steps of batch 0: mirror that
-        for _ in range(3):
-            opt_e.zero_grad(set_to_none=True)
-            ld = crit(m_e(batches[0]["X"]), batches[0]["y"])
-            ld["loss"].backward()
-            opt_e.step()
-        losses_e.append(ld["loss"].detach().clone())
-        losses_g.append(step(batches[0])["loss"])
-        for b in batches[1:]:
+        # an UNMODIFIED eager loop: the stepper's first 3 calls are eager steps on their own batches, call 4 captures
+        # and replays (the round-3 stepper applied batch 0 three times)
+        for b in batches:
             opt_e.zero_grad(set_to_none=True)
             ld = crit(m_e(b["X"]), b["y"])
             ld["loss"].backward()
@@ -419,7 +413,7 @@ def test_graphed_train_step_reproduces_the_eager_trajectory(mode, norm):
     assert torch.equal(torch.stack(losses_e), torch.stack(losses_g))
     for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         assert torch.equal(a, b), k
-    assert len(step._graphs) == 1
+    assert len(step._graphs) == 1 and next(iter(step._graphs.values()))["graph"] is not None
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -449,6 +443,67 @@ def test_two_streams_over_one_model_run_concurrently(tuning, mode):
         torch.cuda.synchronize()
     for oa, ob in outs:
         assert torch.equal(oa, ya) and torch.equal(ob, yb)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_two_captured_graphs_replayed_concurrently_do_not_share_queue_state(tuning, mode):
+    """VERDICT r3 item 6 / ADVICE r3: torch captures every graph on one shared side stream, so keyed by stream alone a
+    captured validation forward (prediction.GraphedForward) and a captured train step (trainer.GraphedTrainStep) baked in
+    the SAME work-queue slot; replayed concurrently on two streams they would corrupt each other's tickets.  The slot is
+    now keyed by (device, stream, capture id).  Queue-driven kernels forced, few workgroups (many items each); the
+    validation model is a frozen copy so that the expected outputs do not depend on the interleaving."""
+    import copy
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.prediction import GraphedForward
+    from segmentation_pipeline_amd.trainer import GraphedTrainStep
+    tuning(M355_CONV_PERSISTENT=2, M355_CONV_SLOTS=6, M355_H16_ONESHOT=3)
+    torch.manual_seed(0)
+    m_t = ModularUNet(4, 3, [16, 32], 2, block_params=dict(GN8), **CONVT).cuda()
+    m_s = copy.deepcopy(m_t)                     # serial twin of the training model
+    m_v = copy.deepcopy(m_t).eval()              # the validation model (never updated)
+    g = torch.Generator().manual_seed(5)
+    xv = torch.randn((1, 4, 32, 32, 64), generator=g).cuda()
+    batches = []
+    for _ in range(10):
+        x = torch.randn((2, 4, 16, 32, 32), generator=g)
+        lab = torch.randint(0, 3, (2, 16, 32, 32), generator=g)
+        batches.append({"X": x.cuda(), "y": torch.nn.functional.one_hot(lab, 3).permute(0, 4, 1, 2, 3).float().contiguous().cuda()})
+    crit = HybridLogisticDiceLoss()
+    with sp.precision(mode):
+        # serial reference: plain eager training + eager validation forward
+        opt_s = torch.optim.SGD(m_s.parameters(), lr=1e-2, momentum=0.9)
+        losses_s = []
+        for b in batches:
+            m_s.train()
+            opt_s.zero_grad(set_to_none=True)
+            ld = crit(m_s(b["X"]), b["y"])
+            ld["loss"].backward()
+            opt_s.step()
+            losses_s.append(ld["loss"].detach().clone())
+        with torch.no_grad():
+            yv = m_v(xv)
+        torch.cuda.synchronize()
+        # both captured (each capture runs on torch's shared capture stream), then replayed on two streams
+        opt_t = torch.optim.SGD(m_t.parameters(), lr=1e-2, momentum=0.9)
+        step = GraphedTrainStep(m_t, crit, opt_t, warmup=2)
+        fwd = GraphedForward(m_v, copy_output=True)
+        losses_t = [step(b)["loss"] for b in batches[:3]]          # 2 eager + capture/replay
+        assert torch.equal(fwd(xv), yv)                            # capture + first replay of the forward
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for b in batches[3:]:
+            with torch.cuda.stream(sa):
+                losses_t.append(step(b)["loss"])
+            with torch.cuda.stream(sb):
+                outs.append(fwd(xv))
+                outs.append(fwd(xv))
+        torch.cuda.synchronize()
+    assert torch.equal(torch.stack(losses_s), torch.stack(losses_t))
+    for o in outs:
+        assert torch.equal(o, yv)
+    for (k, a), (_, b) in zip(m_s.state_dict().items(), m_t.state_dict().items()):
+        assert torch.equal(a, b), k
 
 
 def test_volume_feeder_with_a_consumer_that_never_synchronises():
