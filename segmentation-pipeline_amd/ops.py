@@ -327,12 +327,39 @@ FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"
 # instead of ~37 small packs spread over the step, each on the critical path in front of its conv.
 _pack_registry = {}
 PACK_BATCH = os.environ.get("M355_PACK_BATCH", "1") != "0"
+# While a train step is being CAPTURED into a hipGraph the batched re-pack must contain exactly the captured model's
+# forms: `pack_scope(params)` marks them stale (so the re-pack kernel is part of the captured step whatever ran before --
+# another model's eager forward between this model's last optimizer step and the capture refreshes ALL stale registered
+# forms, and a capture that then finds its weights "fresh" would replay with the packed weights of the capture step
+# forever) and keeps other models' forms out of the graph.
+_pack_scope = None
+
+
+class pack_scope:
+    def __init__(self, params):
+        self.ids = {id(p) for p in params}
+        self.params = list(params)
+
+    def __enter__(self):
+        global _pack_scope
+        self.prev, _pack_scope = _pack_scope, self.ids
+        for p in self.params:
+            cache = getattr(p, "_m355_packed", None)
+            if cache is not None:
+                p._m355_packed = (-1, cache[1], cache[2])
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_scope
+        _pack_scope = self.prev
 
 
 def _repack_stale(L, device):
     """Refresh, in place and with one launch, every cached packed form whose parameter has a new version."""
     items = []
     for key, ref in list(_pack_registry.items()):
+        if _pack_scope is not None and key not in _pack_scope:
+            continue
         w = ref()
         cache = getattr(w, "_m355_packed", None) if w is not None else None
         if cache is None or cache[1] != w.data_ptr() or w.device != device:

@@ -141,7 +141,8 @@ class GraphedTrainStep:
             sx, sy = x.clone(), y.clone()
             graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
+            # (pack_scope: the captured step starts with the re-pack of exactly this model's weight forms)
+            with ops.pack_scope(list(self.model.parameters())), torch.cuda.graph(graph):
                 ld = self.criterion(self.model(sx), sy)
                 ld["loss"].backward()
                 self.optimizer.step()

@@ -127,6 +127,101 @@ def test_sgd_trajectory_matches_reference(golden):
         assert maxerr(v, final[k]) <= 1e-5, k
 
 
+def _adam_update_error(model, g):
+    """relative L2 distance between this model's total parameter update (final - initial) and the reference's, over all
+    parameters jointly, and the worst BatchNorm running-statistics error"""
+    sd0, sdf = g.state_dict("sd0."), g.state_dict("sd_final.")
+    num = den = 0.0
+    worst_buf = 0.0
+    params = dict(model.named_parameters())
+    for k, v in model.state_dict().items():
+        if k in params:
+            d_ref = (sdf[k].double() - sd0[k].double())
+            d_gpu = (v.detach().cpu().double() - sd0[k].double())
+            num += float(((d_gpu - d_ref) ** 2).sum())
+            den += float((d_ref ** 2).sum())
+        elif v.is_floating_point():
+            worst_buf = max(worst_buf, maxerr(v, sdf[k]))
+    return (num / den) ** 0.5, worst_buf
+
+
+def _adam_batches(g, n=4):
+    return [{"X": g.t(f"x{i}").cuda(), "y": g.t(f"y{i}").cuda()} for i in range(n)]
+
+
+def test_adam_trajectory_matches_reference(golden):
+    """The reference's own optimiser configuration end to end (research/dmri_hippo/configs/main_config.py:123-128:
+    NestedResUNet + Adam(lr=2e-4) + HybridLogisticDiceLoss; loop order segmentation_trainer.py:162-180): 4 Adam steps on
+    changing batches against the trajectory of the real reference modules on torch-CPU (tools/gen_golden.py::gen_round4).
+    Adam's first step moves EVERY element by lr * sign(g) (m / sqrt(v) = g / |g|), so an element whose gradient is below
+    the fp32 summation-order noise of its tensor (|g| < ~1e-4 of the tensor's scale: 1-2 % of the elements of a
+    random-init network) moves by +-lr on the sign of that noise, here as on any other backend.  The update is therefore
+    compared as a whole -- relative L2 over all parameters (measured 2.3e-2, the size of that sign population; a wrong
+    gradient scale, a dropped term or a stale moment is O(1)) -- and the losses, moments and running statistics
+    element by element."""
+    g = golden("round4.npz")
+    model = NestedResUNet(3, 2, 8)
+    model.load_state_dict(g.state_dict("sd0."))
+    model = model.cuda()
+    crit = HybridLogisticDiceLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+    losses = []
+    for b in _adam_batches(g):
+        model.train()
+        ld = crit(model(b["X"]), b["y"])
+        opt.zero_grad()
+        ld["loss"].backward()
+        opt.step()
+        model.eval()
+        losses.append([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()])
+    np.testing.assert_allclose(np.asarray(losses), g["adam_losses"], rtol=0, atol=1e-4)
+    rel, worst_buf = _adam_update_error(model, g)
+    print(f"adam eager: update rel-L2 {rel:.3e}, worst running-stat error {worst_buf:.3e}")
+    assert rel <= 5e-2 and worst_buf <= 1e-4
+    names = [str(k) for k in g["param_names"]]
+    ea = np.asarray([opt.state[p]["exp_avg"].double().norm().item() for p in model.parameters()])
+    es = np.asarray([opt.state[p]["exp_avg_sq"].double().norm().item() for p in model.parameters()])
+    assert names == [k for k, _ in model.named_parameters()]
+    np.testing.assert_allclose(ea, g["exp_avg_norms"], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(es, g["exp_avg_sq_norms"], rtol=4e-3, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_adam_through_graphed_train_step(golden, mode):
+    """GraphedTrainStep needs Adam(capturable=True) (the step counter lives on the device): the replayed trajectory is
+    bit-identical to the eager loop with the same optimiser, and (fp32) follows the reference trajectory."""
+    import copy
+    import segmentation_pipeline_amd as sp
+    from segmentation_pipeline_amd.trainer import GraphedTrainStep
+    g = golden("round4.npz")
+    m_e = NestedResUNet(3, 2, 8)
+    m_e.load_state_dict(g.state_dict("sd0."))
+    m_e = m_e.cuda()
+    m_g = copy.deepcopy(m_e)
+    crit = HybridLogisticDiceLoss()
+    batches = _adam_batches(g)
+    with sp.precision(mode):
+        opt_e = torch.optim.Adam(m_e.parameters(), lr=2e-4, capturable=True)
+        opt_g = torch.optim.Adam(m_g.parameters(), lr=2e-4, capturable=True)
+        step = GraphedTrainStep(m_g, crit, opt_g, warmup=1)
+        le, lg = [], []
+        for b in batches:
+            m_e.train()
+            opt_e.zero_grad(set_to_none=True)
+            ld = crit(m_e(b["X"]), b["y"])
+            ld["loss"].backward()
+            opt_e.step()
+            le.append(ld["loss"].detach().clone())
+            lg.append(step(b)["loss"])
+    assert torch.equal(torch.stack(le), torch.stack(lg))
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    if mode == "fp32":
+        np.testing.assert_allclose(torch.stack(lg).cpu().numpy(), g["adam_losses"][:, 0], rtol=0, atol=1e-4)
+        rel, worst_buf = _adam_update_error(m_g, g)
+        assert rel <= 5e-2 and worst_buf <= 1e-4
+
+
 def test_cfg2_architecture_reduced_patch(golden):
     """The real 5-level [32,64,128,256,320] GN/ConvT network (18.08 M params) on a 32^3 patch;
     weights re-created from seed 0 exactly as the fixture generator did."""

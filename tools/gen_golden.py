@@ -243,13 +243,59 @@ def gen_round3(M, C):
     print(f"round3.npz: ensemble seed {seed}, min top-2 gap {gap:.3e}; cascade params {int(out['cascade.n_params'])}")
 
 
+def gen_round4(M, C):
+    """10. (round 4) -> round4.npz: the reference's OWN optimiser configuration end to end
+    (research/dmri_hippo/configs/main_config.py:123-128: NestedResUNet + torch.optim.Adam(lr=2e-4) +
+    HybridLogisticDiceLoss, loop order of segmentation_trainer.py:162-180): a 4-step Adam trajectory of
+    NestedResUNet(3, 2, 8) (dropout off: the trajectory must be deterministic) on a batch that changes every step --
+    per-step loss dicts, the state_dict after the last step (weights AND BatchNorm running statistics) and Adam's
+    exp_avg / exp_avg_sq norms.  The GPU tests run it eagerly, through GraphedTrainStep (capturable=True) and through
+    PatchParallel's bucket-view gradients."""
+    out = {}
+    torch.manual_seed(0)
+    model = M.NestedResUNet(3, 2, 8)
+    out.update(sd_np(model, "sd0."))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+    crit = C.HybridLogisticDiceLoss()
+    losses = []
+    for step in range(4):
+        x, lab, y = synth((2, 3, 16, 16, 16), 2, 900 + step)
+        out[f"x{step}"], out[f"y{step}"] = x.numpy(), y.numpy()
+        model.train()
+        p = model(x)
+        ld = crit(p, y)
+        opt.zero_grad()
+        ld["loss"].backward()
+        opt.step()
+        model.eval()
+        losses.append([ld["loss"].item(), ld["dice_loss"].item(), ld["logistic_loss"].item()])
+    out["adam_losses"] = np.asarray(losses, dtype=np.float32)
+    out.update(sd_np(model, "sd_final."))
+    names = [k for k, _ in model.named_parameters()]
+    out["param_names"] = np.asarray(names)
+    out["exp_avg_norms"] = np.asarray([opt.state[p_]["exp_avg"].double().norm().item() for p_ in model.parameters()])
+    out["exp_avg_sq_norms"] = np.asarray([opt.state[p_]["exp_avg_sq"].double().norm().item() for p_ in model.parameters()])
+    np.savez_compressed(os.path.join(OUT, "round4.npz"), **out)
+    print("round4.npz: Adam losses", losses)
+
+
+def write_manifest():
+    with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
+        f.write("Generated by tools/gen_golden.py from the reference modules at /root/reference\n")
+        f.write(f"torch {torch.__version__}\n")
+        for name in sorted(os.listdir(OUT)):
+            if name.endswith(".npz"):
+                f.write(f"{name} {os.path.getsize(os.path.join(OUT, name))} bytes\n")
+
+
 def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     M, C = load_reference()
     torch.set_num_threads(8)
     if only:
         for name in only:
-            {"ensembles_ws": gen_ensembles_ws, "round3": gen_round3}[name](M, C)
+            {"ensembles_ws": gen_ensembles_ws, "round3": gen_round3, "round4": gen_round4}[name](M, C)
+        write_manifest()
         return
     meta = {"torch": torch.__version__}
 
@@ -426,13 +472,8 @@ def main(only=()):
     np.savez_compressed(os.path.join(OUT, "cfg2_arch_32cube.npz"), **out)
     gen_ensembles_ws(M, C)
     gen_round3(M, C)
-
-    with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
-        f.write("Generated by tools/gen_golden.py from the reference modules at /root/reference\n")
-        f.write(f"torch {meta['torch']}\n")
-        for name in sorted(os.listdir(OUT)):
-            if name.endswith(".npz"):
-                f.write(f"{name} {os.path.getsize(os.path.join(OUT, name))} bytes\n")
+    gen_round4(M, C)
+    write_manifest()
     print("golden fixtures written to", os.path.abspath(OUT))
 
 
