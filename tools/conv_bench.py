@@ -43,6 +43,13 @@ def main():
         x = torch.randn(1, ci, sp, sp, sp, device="cuda")
         w = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
         dy = torch.randn(1, co, sp, sp, sp, device="cuda")
+        # operand statistics (power probe: the MFMA clock depends on how many operand bits toggle)
+        if "--zeros" in sys.argv:
+            x, w, dy = torch.zeros_like(x), torch.zeros_like(w), torch.zeros_like(dy)
+        elif "--relu" in sys.argv:       # what the convs of the network actually read: post-ReLU activations
+            x = torch.relu(x)
+        elif "--const" in sys.argv:
+            x, w, dy = torch.ones_like(x), torch.full_like(w, 0.05), torch.ones_like(dy)
         flops = 2.0 * 27 * ci * co * sp ** 3
         row = f"{name:8s} {ci:4d} {co:4d} {sp:4d} "
         if compute:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
