@@ -41,7 +41,6 @@ static Tuning read_tuning() {
   t.fuse_softmax = env_int("M355_FUSE_SOFTMAX", 1);
   t.convt_wgs = env_int("M355_CONVT_WGS", 0);
   t.h16_stagger = env_int("M355_H16_STAGGER", 2);
-  t.h16r = env_int("M355_H16R", 0);
   return t;
 }
 static Tuning g_tuning = read_tuning();

@@ -74,8 +74,6 @@ struct Tuning {
   int fuse_softmax = 1;
   int convt_wgs = 0;     // c8 conv-transpose kernels: workgroups per CU of the persistent grids (0 = built-in)
   int h16_stagger = 2;   // 16-bit conv kernel: start offset of the odd workgroup of a CU, in units of 1024 cycles
-  int h16r = 0;          // register-resident-weights 16-bit conv kernel (conv3d_h16r.hip; measured equal to the default kernel, kept as the
-                         // diagnostic vehicle -- see its header): 0 never, 1 wherever a launch of it fills the chip, 2 wherever it runs
 };
 const Tuning& tuning();
 

@@ -2375,26 +2375,6 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
   return M355_OK;
 }
 
-bool m355::plan_h16r(const FwdPlan& p, int N, int kin, int D, int H, int W, FwdPlan* r) {
-  const int mode = tuning().h16r;
-  if (!mode || !p.mfma || p.gx != 32 || p.ksplit != 1 || D < 8 || H < 4) return false;
-  if (kin <= 4 && !tuning().no_small) return false;          // conv3_c4_h16_kernel owns the <= 4-channel edge layers
-  const int64_t items = ceil_div(D, 8) * ceil_div(H, 4) * (int64_t)p.tx_tiles * p.otiles * N;
-  const int64_t cus = num_cus();
-  // one workgroup per CU, equal items: the launch takes ceil(items / CUs) item times -- it must fill the chip, and
-  // its last round should not be mostly empty (mode 2: wherever the geometry allows, for tests / sweeps)
-  if (mode == 1 && (items < cus || items * 5 < ceil_div(items, cus) * cus * 4)) return false;
-  if (r) {
-    *r = p;
-    r->ntw = 4;
-    r->nw = 8;
-    r->oneshot = 0;
-    r->tz_tiles = (int)ceil_div(D, 8);
-    r->ty_tiles = (int)ceil_div(H, 4);
-  }
-  return true;
-}
-
 // Per (sample, output channel): how many (sum, sum of squares) partials the forward kernel writes
 // when statistics are fused (4 waves x spatial tiles); 0 = this descriptor has no fused statistics
 // (not 3x3x3 s1 p1, small-Cout kernel, bf16 operand mode, or a split-K plan).
@@ -2412,8 +2392,6 @@ static int64_t conv_stats_slots_c8(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
   FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return splitk_c8_slots((int64_t)d->D * d->H * d->W);
-  FwdPlan r;
-  if (plan_h16r(p, d->N, d->Cin, d->D, d->H, d->W, &r)) p = r;
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots_c8(const m355_conv3d_desc* d) { return d ? conv_stats_slots_c8(d) : 0; }
@@ -2857,13 +2835,27 @@ int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int6
   return M355_OK;
 }
 
+// fp32 NCDHW operands in a 16-bit compute mode (the plain entry point; the model path hands over c8 tensors through
+// m355_conv3d_bwd_weight_h16 / _c8): both operands are rounded into c8 copies and the c8 kernel runs (round 1 had a kernel
+// of its own for this case, conv3_mfma_bww_h16_kernel, three dx-shifted LDS copies at a third of the c8 kernel's rate)
+static bool bww_c8_ok(const m355_conv3d_desc* d);
+static bool bww_plain_h16(const m355_conv3d_desc* d) {
+  return d->compute != M355_COMPUTE_F32 && is_k3s1p1(d) && !small_bww(d) && bww_c8_ok(d) && d->N <= 65535;
+}
+
 extern "C" size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d) {
   if (!d) return 0;
   const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
             OW = out_dim(d->W, d->k, d->stride, d->pad);
   const size_t db = dbias_ws_bytes(d->Cout, (int64_t)OD * OH * OW);
   if (!is_k3s1p1(d)) return db;
-  return plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes + db;
+  const size_t f32 = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes + db;
+  if (bww_plain_h16(d)) {   // 16-bit operand mode: both operands are rounded into c8 copies behind the c8 kernel's own workspace
+    const int64_t S = (int64_t)d->D * d->H * d->W;
+    return std::max(f32, m355_conv3d_bwd_weight_h16_workspace(d) + (size_t)round_up(d->N * c8_blocks(d->Cin) * S * 16, 256) +
+                             (size_t)round_up(d->N * c8_blocks(d->Cout) * S * 16, 256));
+  }
+  return f32;
 }
 
 extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x, const float* dy,
@@ -2885,18 +2877,19 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     M355_REQUIRE((int64_t)d->Cin * d->D * d->H * d->W < (1ll << 31) &&
                      (int64_t)d->Cout * d->D * d->H * d->W < (1ll << 31),
                  M355_EUNSUPPORTED, "conv3d_bwd_weight: tensor exceeds 2^31 elements per sample");
-    const bool bf16_ok = d->compute != M355_COMPUTE_F32 && d->W % 32 == 0 && (xbs % 4 == 0) && (ybs % 4 == 0) &&
-                         (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !small_bww(d);
-    if (bf16_ok) {
-      // tile 2x2x32; the slab layout / split count of the fp32 plan are reused
-      const int tz2 = (int)ceil_div(d->D, 2), ty2 = (int)ceil_div(d->H, 2), tx2 = d->W / 32;
-      const int nsplit = (int)std::min<int64_t>(p.nsplit, (int64_t)d->N * tz2 * ty2 * tx2);
-      if (int rc = launch_bww_h16(d->compute, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, tz2, ty2, tx2, nsplit,
-                                  p.ctiles, p.otiles, xbs, ybs, st))
-        return rc;
-      const int64_t total = (int64_t)d->Cout * d->Cin * 27;
-      const int blocks = (int)std::min<int64_t>(ceil_div(total, 64), 4096);
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, total, nsplit);
+    if (bww_plain_h16(d)) {
+      const int64_t S = (int64_t)d->D * d->H * d->W;
+      const size_t hws = m355_conv3d_bwd_weight_h16_workspace(d);
+      const size_t xb = (size_t)round_up(d->N * c8_blocks(d->Cin) * S * 16, 256), yb = (size_t)round_up(d->N * c8_blocks(d->Cout) * S * 16, 256);
+      M355_REQUIRE(workspace && workspace_bytes >= hws + xb + yb, M355_EWORKSPACE,
+                   "conv3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes, hws + xb + yb);
+      char* x16 = (char*)workspace + hws;
+      char* dy16 = x16 + xb;
+      if (int rc = launch_pack_act16(x, x16, d->N, d->Cin, S, xbs, c8_blocks(d->Cin) * S * 8, d->compute, st)) return rc;
+      if (int rc = launch_pack_act16(dy, dy16, d->N, d->Cout, S, ybs, c8_blocks(d->Cout) * S * 8, d->compute, st)) return rc;
+      m355_conv3d_desc dd = *d;
+      dd.y_batch_stride = ybs;
+      return m355_conv3d_bwd_weight_h16(&dd, x16, 0, dy16, 0, dbias ? dy : nullptr, dw, dbias, workspace, hws, stream);
     } else if (small_bww(d)) {
       // narrow side (<= 4 channels) shares the lane index with the taps
       const int swap = d->Cin <= 4 ? 0 : 1;

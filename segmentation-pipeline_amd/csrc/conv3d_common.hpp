@@ -152,11 +152,6 @@ int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_b
                  int Cout_w, int Cin_w, const float* bias, const float* add, float* out, int N, int kin, int mout,
                  int D, int H, int W, int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st, float* stat,
                  const void* prepacked = nullptr, bool out16 = false, bool softmax = false);
-// Register-resident-weights kernel (conv3d_h16r.hip) for the c8-output forms (forward, data gradient) of a 16-bit plan:
-// plan_h16r -> true and the tile counts (8 x 4 x 32 voxels, 8 statistics slots per tile) when that kernel runs the layer.
-bool plan_h16r(const FwdPlan& p, int N, int kin, int D, int H, int W, FwdPlan* r);
-int launch_h16r(const FwdPlan& r, int compute, const void* x16, int64_t xbs16, const void* wp, const float* bias, void* y16,
-                int N, int kin, int mout, int D, int H, int W, int64_t ybs16, hipStream_t st, float* stat);
 void launch_pack_w3_h16(const FwdPlan& p, int compute, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose,
                         hipStream_t st);
 
@@ -198,11 +193,6 @@ __device__ __forceinline__ void pack_w3_body(const float* __restrict__ w, float*
     wp[i] = v;
   }
 }
-// weight gradient on the 16-bit MFMA (fp32 NCDHW operands rounded while staged; W % 32 == 0)
-int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
-                   int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
-                   hipStream_t st);
-
 // blocks along the voxel axis of splitk_reduce_c8_kernel == statistics slots it emits per sample
 inline int64_t splitk_c8_slots(int64_t S) { return std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256), 2048)); }
 

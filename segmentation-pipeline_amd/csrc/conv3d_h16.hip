@@ -925,11 +925,6 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
   if (!prepacked) pack_w3_h16_t<HT>(p, w, wpb, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
-  // wide levels, c8 output: register-resident weights, two planes per wave (conv3d_h16r.hip)
-  FwdPlan pr;
-  if (out16 && !ka && !softmax && plan_h16r(p, N, kin, D, H, W, &pr))
-    return launch_h16r(pr, std::is_same<HT, __bf16>::value ? M355_COMPUTE_BF16 : M355_COMPUTE_F16, in16, in16_bs, wpb, kb,
-                       out, N, kin, mout, D, H, W, out_bs, st, stat);
   // edge layers with <= 4 K-channels and a c8 output: four taps per k-step (conv3_c4_h16_kernel)
   if (kin <= 4 && out16 && p.ksplit == 1 && p.gx == 32 && p.nw == 4 && !softmax && !tuning().no_small &&
       launch_c4_h16<HT>(p, in16, in16_bs, wpb, kb, (HT*)out, N, mout, D, H, W, out_bs, st, stat))
@@ -972,190 +967,6 @@ int run_h16_conv(const FwdPlan& p, int compute, const void* in16, int64_t in16_b
                                   kin, mout, D, H, W, out_bs, ws, ws_bytes, st, stat, prepacked, out16, softmax);
 }
 
-// ------------------------------------------------ bwd-weight, bf16 compute mode (W % 32 == 0)
-// dW[o,c,tap] = sum_v dy[o,v] * x[c,v+off(tap)] on v_mfma_f32_32x32x16_bf16: i = o, j = c,
-// k = 16 x-adjacent voxels (lane half h carries voxels 8h..8h+7 as ONE 16-byte fragment).
-// A tap's dx shift would misalign those 16-byte reads by 2 bytes, so the input tile is kept in
-// LDS three times, pre-shifted by dx = -1/0/+1 (built while staging with one lane shuffle each
-// way); dz/dy shifts are whole rows and stay aligned.  Tile = 2x2x32 voxels:
-//   dys[32 o][128 + 8]            (row stride 17 x 16 B: conflict-free b128 reads)
-//   xs3[3 dx][32 c][16 rows x 32 + 8]   (channel stride 65 x 16 B)
-// Memory-bound at this MFMA rate; the next tile is prefetched into registers during the MFMAs.
-template <typename HT>
-__global__ __launch_bounds__(256, 1) void conv3_mfma_bww_h16_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N,
-    int Cin, int Cout, int D, int H, int W, int tz_tiles, int ty_tiles, int tx_tiles, int nsplit,
-    int64_t xbs, int64_t ybs) {
-  using hx8 = typename H16<HT>::x8;
-  constexpr int TZ = 2, TY = 2, TX = 32, NV = TZ * TY * TX;     // 128
-  constexpr int ROWS = (TZ + 2) * (TY + 2);                      // 16 halo rows per channel
-  constexpr int DROW = NV + 8;                                   // bf16 elements per dy row
-  constexpr int XCH = ROWS * TX + 8;                             // bf16 elements per channel per copy
-  constexpr int XCPY = 32 * XCH;                                 // bf16 elements per shifted copy
-  constexpr int XITEMS = 32 * ROWS * 8;                          // (c, row, q) float4 items
-  constexpr int XPER = XITEMS / 256;                             // 16
-  __shared__ __attribute__((aligned(16))) HT dys[32 * DROW];
-  __shared__ __attribute__((aligned(16))) HT xs3[3 * XCPY];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l32 = lane & 31;
-  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32, split = blockIdx.z;
-  const int iHW = H * W, iDHW = D * H * W;
-
-  // this wave's taps: element offsets of (dx copy, dz/dy row shift) inside xs3
-  int toff[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = min(wave * 7 + t, 26);
-    toff[t] = (tap % 3) * XCPY + ((tap / 9) * (TY + 2) + (tap / 3) % 3) * TX;
-  }
-  f32x16 acc[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // staging roles
-  const int q = tid & 7;                 // float4 column of an x item
-  const int so = tid >> 3, sseg = tid & 7;  // dy: output channel, 16-voxel segment
-  const int sz = sseg >> 2, sy = (sseg >> 1) & 1, sxh = sseg & 1;
-
-  const int tiles_per_n = tz_tiles * ty_tiles * tx_tiles;
-  const int ntiles = N * tiles_per_n;
-
-  f32x4 xr[XPER];
-  float xh[XPER];
-  f32x4 dr[4];
-  unsigned mrow, mhalo, mdy;  // validity bits applied at commit
-  auto fetch = [&](int tile) {
-    int t = tile;
-    const int n = t / tiles_per_n;
-    t -= n * tiles_per_n;
-    const int txt = t % tx_tiles;
-    t /= tx_tiles;
-    const int tyt = t % ty_tiles;
-    const int tzt = t / ty_tiles;
-    const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
-    const float* xn = x + (int64_t)n * xbs;
-    const float* dn = dy + (int64_t)n * ybs;
-    mrow = 0u;
-    mhalo = 0u;
-    const int hx = q == 0 ? x0 - 1 : x0 + TX;       // only lanes q == 0 / q == 7 use their halo value
-    const bool hx_ok = (q == 0 || q == 7) && hx >= 0 && hx < W;
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-      const int rowi = (tid >> 3) + 32 * k;          // (c, halo row) index, 512 in all
-      const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      const int zz = rr / (TY + 2), yy = rr - zz * (TY + 2);
-      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gc = c0 + c;
-      const bool rok = gc < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
-      const int base = gc * iDHW + gz * iHW + gy * W;
-      xr[k] = *reinterpret_cast<const f32x4*>(xn + (rok ? base + x0 + 4 * q : 0));
-      xh[k] = xn[(rok && hx_ok) ? base + hx : 0];
-      mrow |= rok ? (1u << k) : 0u;
-      mhalo |= (rok && hx_ok) ? (1u << k) : 0u;
-    }
-    const int gz = z0 + sz, gy = y0 + sy;
-    const bool dok = o0 + so < Cout && gz < D && gy < H;
-    const int dbase = dok ? (o0 + so) * iDHW + gz * iHW + gy * W + x0 + 16 * sxh : 0;
-    mdy = dok ? 1u : 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dr[u] = *reinterpret_cast<const f32x4*>(dn + dbase + 4 * u);
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) {
-      const bool rok = (mrow >> k) & 1u;
-      f32x4 v = xr[k];
-      if (!rok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float hv = ((mhalo >> k) & 1u) ? xh[k] : 0.f;
-      // neighbours inside the 8-lane row group
-      float left = __shfl_up(v[3], 1, 64), right = __shfl_down(v[0], 1, 64);
-      if (q == 0) left = hv;
-      if (q == 7) right = hv;
-      const int rowi = (tid >> 3) + 32 * k;
-      const int c = rowi / ROWS, rr = rowi - c * ROWS;
-      HT* dst = xs3 + c * XCH + rr * TX + 4 * q;
-      using bf16x4 = typename H16<HT>::x4;
-      bf16x4 m1, m0, p1;
-      m1[0] = (HT)left; m1[1] = (HT)v[0]; m1[2] = (HT)v[1]; m1[3] = (HT)v[2];   // x - 1
-      m0[0] = (HT)v[0]; m0[1] = (HT)v[1]; m0[2] = (HT)v[2]; m0[3] = (HT)v[3];   // x
-      p1[0] = (HT)v[1]; p1[1] = (HT)v[2]; p1[2] = (HT)v[3]; p1[3] = (HT)right;  // x + 1
-      *reinterpret_cast<bf16x4*>(dst) = m1;
-      *reinterpret_cast<bf16x4*>(dst + XCPY) = m0;
-      *reinterpret_cast<bf16x4*>(dst + 2 * XCPY) = p1;
-    }
-    hx8 d0, d1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      d0[u] = (HT)(mdy ? dr[0][u] : 0.f);
-      d0[4 + u] = (HT)(mdy ? dr[1][u] : 0.f);
-      d1[u] = (HT)(mdy ? dr[2][u] : 0.f);
-      d1[4 + u] = (HT)(mdy ? dr[3][u] : 0.f);
-    }
-    HT* dd = dys + so * DROW + sseg * 16;
-    *reinterpret_cast<hx8*>(dd) = d0;
-    *reinterpret_cast<hx8*>(dd + 8) = d1;
-  };
-
-  if (split < ntiles) {
-    fetch(split);
-    commit();
-  }
-  __syncthreads();
-  const HT* ab = dys + l32 * DROW + 8 * half;
-  const HT* bb = xs3 + l32 * XCH + 8 * half;
-  for (int tile = split; tile < ntiles; tile += nsplit) {
-    const bool more = tile + nsplit < ntiles;
-    if (more) fetch(tile + nsplit);
-#pragma unroll
-    for (int zy = 0; zy < TZ * TY; ++zy) {
-      const int z = zy / TY, yy = zy % TY;
-#pragma unroll
-      for (int xk = 0; xk < 2; ++xk) {
-        const hx8 a = *reinterpret_cast<const hx8*>(ab + zy * TX + 16 * xk);
-        const HT* brow = bb + (z * (TY + 2) + yy) * TX + 16 * xk;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-          const hx8 b = *reinterpret_cast<const hx8*>(brow + toff[t]);
-          acc[t] = H16<HT>::mfma(a, b, acc[t]);
-        }
-      }
-    }
-    __syncthreads();
-    if (more) commit();
-    __syncthreads();
-  }
-  float* sl = slab + (int64_t)split * Cout * Cin * 27;
-  const int c = c0 + l32;
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = wave * 7 + t;
-    if (tap < 27 && c < Cin) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sl[((int64_t)o * Cin + c) * 27 + tap] = acc[t][r];
-      }
-    }
-  }
-}
-
-
-int launch_bww_h16(int compute, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
-                   int W, int tz2, int ty2, int tx2, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs,
-                   hipStream_t st) {
-  dim3 gb((unsigned)ctiles, (unsigned)otiles, (unsigned)nsplit);
-  if (compute == M355_COMPUTE_BF16)
-    hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<__bf16>, gb, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, tz2,
-                       ty2, tx2, nsplit, xbs, ybs);
-  else
-    hipLaunchKernelGGL(conv3_mfma_bww_h16_kernel<_Float16>, gb, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W,
-                       tz2, ty2, tx2, nsplit, xbs, ybs);
-  return check_launch("conv3_mfma_bww_h16");
-}
 
 // ------------------------------------------------ weight gradient from c8 operands (16-bit training flow)
 // dW[o,c,tap] = sum_v dy[o,v] * x[c,v+off(tap)] with BOTH operands handed over in the c8 layout (h16.hpp) -- the

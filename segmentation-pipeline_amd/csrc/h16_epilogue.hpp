@@ -1,5 +1,4 @@
-// Epilogue of the 16-bit convolution kernels that write their output tile in the c8 layout (conv3d_h16.hip,
-// conv3d_h16r.hip).
+// Epilogue of the 16-bit convolution kernels that write their output tile in the c8 layout (conv3d_h16.hip).
 #pragma once
 #include "conv3d_common.hpp"
 

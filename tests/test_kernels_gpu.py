@@ -1056,46 +1056,6 @@ def test_act16_pack_unpack_scaled(hip, compute):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
-def test_conv3d_h16r_register_resident_weights_kernel(hip, oracle, compute, tuning):
-    """conv3_h16r_kernel (csrc/conv3d_h16r.hip; the wide levels' c8 -> c8 forward and data gradient: two planes per wave,
-    weights in registers, halo tile double-buffered), forced onto small volumes with M355_H16R=2: == the fp32-output
-    kernel within one rounding (the same exact products, another fp32 summation order) and == the oracle on the rounded
-    operands; fused statistics; padded channels exactly zero; ragged D / H / W (tiles that overhang on every axis), odd
-    numbers of channel blocks, 1 .. 9 chunks, several channel tiles, N = 2, more items than workgroups; bit-reproducible."""
-    dt, ulp = _dt(compute), _ulp(compute)
-    shapes = [(2, 16, 40, 9, 10, 62), (1, 40, 72, 8, 6, 64), (1, 24, 32, 17, 5, 32), (1, 136, 32, 8, 8, 32), (1, 8, 8, 40, 44, 96)]
-    for (N, ci, co, D, H, W) in shapes:
-        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
-        x16 = hip.act16_pack(x, compute)
-        tuning(M355_H16R=0)
-        y32 = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute).cpu()
-        y16_old, _ = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
-        tuning(M355_H16R=2)
-        y16, part = hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute, with_stats=True)
-        assert part.shape[1] == -(-D // 8) * -(-H // 4) * -(-W // 32) * 8, "not the register-weights plan"
-        got = _c8_to_ncdhw(y16, co, (D, H, W))
-        tol = 2e-5 * y32.abs().max().item()
-        assert ((got - y32).abs() <= ulp * y32.abs() * 1.01 + tol).all(), (N, ci, co, D, H, W)
-        ref = oracle.conv3d_fwd(x.to(dt).float(), w.to(dt).float(), b)
-        assert ((got - ref).abs() <= ulp * ref.abs() * 1.01 + tol).all()
-        if co % 8:
-            assert (y16[:, -1, :, co % 8:].float() == 0).all()
-        s1, s2 = part[..., 0].sum(dim=1).cpu().double(), part[..., 1].sum(dim=1).cpu().double()
-        torch.testing.assert_close(s1, y32.double().sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
-        torch.testing.assert_close(s2, (y32.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3)
-        assert torch.equal(y16, hip.conv3d_fwd_h16_c8(x16, ci, (D, H, W), w, b, compute=compute)), "reproducible, with / without stats"
-        # data gradient: the same kernel on dy with the transposed filter
-        dy = rnd(N, co, D, H, W, seed=4)
-        dy16 = hip.act16_pack(dy, compute)
-        dx16 = hip.conv3d_bwd_data_h16_c8(dy16, co, w, (N, ci, D, H, W), compute)
-        tuning(M355_H16R=0)
-        dx32 = hip.conv3d_bwd_data_h16(dy16, co, w, (N, ci, D, H, W), compute).cpu()
-        _rounded_close(_c8_to_ncdhw(dx16, ci, (D, H, W)), dx32, compute, 2e-5 * dx32.abs().max().item(), "dx (register-weights kernel)")
-        if ci % 8:
-            assert (dx16[:, -1, :, ci % 8:].float() == 0).all()
-
-
-@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("env", [{}, {"M355_CONV_KSPLIT": "2"}])
 def test_conv3d_bwd_data_c8_output_and_weight_gradient_c8(hip, oracle, compute, env, tuning):
     """m355_conv3d_bwd_data_h16_c8 == m355_conv3d_bwd_data_h16 rounded once; m355_conv3d_bwd_weight_c8: dw bit-identical to

@@ -49,16 +49,15 @@ for N, ci, co, D, H, W, env in CASES:
                     sys.exit(1)
     print(f"ok {iters} x {(N, ci, co, D, H, W)} {env}", flush=True)
 # the c8 kernels of the 16-bit training flow: one-shot / queue-driven forward with fused statistics, data gradient, the
-# ring-buffered + software-pipelined weight gradient, and the opt-in register-weights kernel (double-buffered halo, one
-# barrier per chunk)
+# ring-buffered + software-pipelined weight gradient
 C8_CASES = [  # (N, Cin, Cout, D, H, W, env)
     (1, 32, 32, 32, 32, 64, {}),
     (1, 96, 32, 16, 20, 64, {"M355_BWW_NSPLIT": "7"}),
     (2, 24, 72, 9, 13, 33, {"M355_H16_ONESHOT": "3", "M355_CONV_SLOTS": "11"}),
-    (1, 40, 64, 17, 12, 64, {"M355_H16R": "2"}),
-    (1, 64, 32, 8, 8, 96, {"M355_H16R": "2", "M355_BWW_NSPLIT": "3"}),
+    (1, 40, 64, 17, 12, 64, {}),
+    (1, 64, 32, 8, 8, 96, {"M355_BWW_NSPLIT": "3"}),
 ]
-KN = ("M355_CONV_SLOTS", "M355_CONV_KSPLIT", "M355_CONV_PERSISTENT", "M355_BWW_NSPLIT", "M355_H16_ONESHOT", "M355_H16R")
+KN = ("M355_CONV_SLOTS", "M355_CONV_KSPLIT", "M355_CONV_PERSISTENT", "M355_BWW_NSPLIT", "M355_H16_ONESHOT")
 for N, ci, co, D, H, W, env in C8_CASES:
     for k in KN:
         os.environ.pop(k, None)
