@@ -86,6 +86,13 @@ void m355_reload_tuning(void);
  * on different streams, and launch sequences captured into different hipGraphs, never share one. */
 size_t m355_queue_pool_bytes(void);
 int m355_queue_pool_set(void* zeroed_device_buffer, size_t bytes, int32_t device);
+/* fp16 training flow (loss-scaled activation gradients, "grad_scale" below): `device_word` = a zeroed 4-byte device word
+ * owned by the caller (NULL: off).  From then on, on that device, every kernel that rounds a loss-scaled gradient to fp16
+ * ORs bit 0 into it when it had to clamp a value to +-65504 (the gradient was clipped: the scale is too large), and every
+ * epilogue that removes the loss scale from a parameter gradient (grad_unscale != 1) ORs bit 1 when its result is not
+ * finite.  The host reads and clears the word after a backward pass and, when it is non-zero, skips the optimizer step and
+ * lowers the scale (segmentation_pipeline_amd.ops.fp16_overflow(); the reference has no reduced-precision path). */
+int m355_overflow_flag_set(void* device_word, int32_t device);
 
 /* ------------------------------------------------------------------ conv3d
  * Replaces nn.Conv3d as used by Block3d (models/components.py:36,42,51) and the

@@ -56,6 +56,7 @@ SIGNATURES = {
     "m355_reload_tuning": (None, []),
     "m355_queue_pool_bytes": (_sz, []),
     "m355_queue_pool_set": (C.c_int, [_P, _sz, _i32]),
+    "m355_overflow_flag_set": (C.c_int, [_P, _i32]),
     "m355_conv3d_fuses_softmax": (_i32, [_CD]),
     "m355_conv3d_packed_bytes": (_sz, [_CD, _i32]),
     "m355_conv3d_pack": (C.c_int, [_CD, _i32, _P, _P, _P]),

@@ -85,6 +85,16 @@ int* g_queue_pool[64] = {nullptr};
 bool g_queue_pool_owned[64] = {false};
 }  // namespace
 
+static int* g_overflow_flag[64] = {nullptr};
+int* overflow_flag() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return g_overflow_flag[dev];
+}
+
 int queue_pool_set(void* buf, size_t bytes, int dev) {
   if (dev < 0 || dev >= 64 || !buf || bytes < (size_t)QUEUE_SLOTS * 64 || ((uintptr_t)buf & 63)) return M355_EINVALID_ARG;
   std::lock_guard<std::mutex> lock(g_queue_mu);
@@ -139,6 +149,14 @@ extern "C" int m355_queue_pool_set(void* zeroed_device_buffer, size_t bytes, int
   else if (rc != M355_OK)
     m355::set_error("queue_pool_set: device %d already has a work-queue pool in use", (int)device);
   return rc;
+}
+extern "C" int m355_overflow_flag_set(void* device_word, int32_t device) {
+  if (device < 0 || device >= 64 || ((uintptr_t)device_word & 3)) {
+    m355::set_error("overflow_flag_set: need a 4-byte aligned device word (or NULL) and a device index in [0, 64)");
+    return M355_EINVALID_ARG;
+  }
+  m355::g_overflow_flag[device] = (int*)device_word;
+  return M355_OK;
 }
 extern "C" int m355_version(void) { return M355_ABI_VERSION; }
 extern "C" const char* m355_last_error(void) { return m355::g_err; }

@@ -85,5 +85,9 @@ int num_cus();
 
 // zero-initialised, self-resetting work-queue state (16 ints) of this (device, stream): abi.cpp
 int* queue_state(hipStream_t st);
+// fp16 training flow: the caller's overflow word of the current device (m355_overflow_flag_set), or null.  Kernels that
+// round a loss-scaled gradient to fp16 OR bit 0 into it when a value had to be clamped to +-65504 (to_h16_sat), the
+// epilogues that remove the loss scale from a parameter gradient OR bit 1 when the result is not finite.
+int* overflow_flag();
 
 }  // namespace m355

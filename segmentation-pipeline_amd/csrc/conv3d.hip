@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww2c_kernel(
 // dW[o][c][27] = sum over splits of slab[split][27][o][c] (fixed order): one block per (o, 32 input
 // channels); coalesced reads along c, transposed through LDS, one contiguous 864-float write.
 __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                            int Cin, int Cout, BwwClasses k, float scale = 1.f) {
+                                                            int Cin, int Cout, BwwClasses k, float scale, int* __restrict__ oflag) {
   __shared__ float tr[32 * 27 + 32];
   const int o = blockIdx.x, c0 = blockIdx.y * 32;
   const int nsplit = k.ns[(o >= k.of * 32 ? 2 : 0) + ((int)blockIdx.y >= k.cf ? 1 : 0)];  // splits of this pair's class
@@ -1556,6 +1556,7 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
       for (; s < nsplit; ++s) v += p[(int64_t)s * split_stride];
     }
     tr[cl * 27 + tap] = v * scale;   // (scale != 1 only in the fp16 training flow: the loss scale leaves here)
+    report_nonfinite(v * scale, oflag);
   }
   __syncthreads();
   float* dst = out + ((int64_t)o * Cin + c0) * 27;
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(256) void slab_reduce_t_kernel(const float* __restr
 // 22 us on 32 of 256 CUs): one block per (o, c-tile, tap); its 256 threads are 32 channels x 8 split lanes, lane j sums
 // the splits s = j, j + 8, ... and the eight partial sums are added in lane order -- fixed order, bit-reproducible.
 __global__ __launch_bounds__(256) void slab_reduce_tap_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                              int Cin, int Cout, BwwClasses k, float scale) {
+                                                              int Cin, int Cout, BwwClasses k, float scale, int* __restrict__ oflag) {
   __shared__ float part[8][32];
   const int o = blockIdx.x, ct = blockIdx.y, tap = blockIdx.z;
   const int nsplit = k.ns[(o >= k.of * 32 ? 2 : 0) + (ct >= k.cf ? 1 : 0)];
@@ -1591,6 +1592,7 @@ __global__ __launch_bounds__(256) void slab_reduce_tap_kernel(const float* __res
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += part[q][cl];
     out[((int64_t)o * Cin + c) * 27 + tap] = t * scale;
+    report_nonfinite(t * scale, oflag);
   }
 }
 
@@ -1601,10 +1603,10 @@ static void launch_slab_reduce_t(const float* slab, float* dw, int Cin, int Cout
   for (int c = 0; c < 4; ++c) max_ns = std::max(max_ns, k.ns[c]);
   if ((int64_t)Cout * ctiles < 2 * (int64_t)num_cus() && max_ns >= 16)
     hipLaunchKernelGGL(slab_reduce_tap_kernel, dim3((unsigned)Cout, (unsigned)ctiles, 27u), dim3(256), 0, st, slab, dw, Cin,
-                       Cout, k, scale);
+                       Cout, k, scale, scale != 1.f ? overflow_flag() : nullptr);
   else
     hipLaunchKernelGGL(slab_reduce_t_kernel, dim3((unsigned)Cout, (unsigned)ctiles), dim3(256), 0, st, slab, dw, Cin, Cout,
-                       k, scale);
+                       k, scale, scale != 1.f ? overflow_flag() : nullptr);
 }
 
 // ------------------------------------------- bwd-weight, tiny channel count on one side

@@ -933,7 +933,8 @@ __global__ __launch_bounds__(256) void convt_k2s2_bww_c8_kernel(
 // positions; its 4 waves take the splits s = wave, wave + 4, ... (coalesced 256-byte reads), then the four partial
 // sums are added in wave order
 __global__ __launch_bounds__(256) void convt_slab_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                  int Cin, int Cout, int nsplit, float unscale) {
+                                                                  int Cin, int Cout, int nsplit, float unscale,
+                                                                  int* __restrict__ oflag) {
   __shared__ double part[4][64];
   const int64_t plane = (int64_t)Cin * Cout * 8, cc = (int64_t)Cin * Cout;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -953,7 +954,9 @@ __global__ __launch_bounds__(256) void convt_slab_reduce_t_kernel(const float* _
   if (wv == 0 && j < plane) {
     const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     const int t = (int)(j / cc);
-    dw[(j - (int64_t)t * cc) * 8 + t] = (float)(tot * (double)unscale);
+    const float r = (float)(tot * (double)unscale);
+    dw[(j - (int64_t)t * cc) * 8 + t] = r;
+    report_nonfinite(r, oflag);
   }
 }
 
@@ -1455,7 +1458,7 @@ extern "C" int m355_conv_transpose3d_bwd_weight_h16(const m355_conv3d_desc* d, c
 #undef M355_CTBW
   const int64_t total = (int64_t)d->Cin * d->Cout * 8;
   hipLaunchKernelGGL(convt_slab_reduce_t_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, st, slab, dw, d->Cin,
-                     d->Cout, nsplit, grad_unscale);
+                     d->Cout, nsplit, grad_unscale, grad_unscale != 1.f ? overflow_flag() : nullptr);
   if (dbias) {
     const size_t slab_b = (size_t)round_up((int64_t)nsplit * 8 * d->Cin * d->Cout * 4, 256);
     if (int rc = launch_dbias_c8(dy16, ybs, dbias, d->N, d->Cout, S * 8, compute, grad_unscale, (char*)workspace + slab_b, st))

@@ -470,8 +470,10 @@ __global__ __launch_bounds__(256) void trilinear2_fwd_c8_kernel(const HT* __rest
 // (saturating for fp16, whose gradients carry the loss scale).
 template <typename HT>
 __global__ __launch_bounds__(256) void trilinear2_bwd_c8_kernel(const HT* __restrict__ dy16, HT* __restrict__ dx16, int N,
-                                                                int CB, int D, int H, int W, int64_t dybs, int64_t dxbs) {
+                                                                int CB, int D, int H, int W, int64_t dybs, int64_t dxbs,
+                                                                int* __restrict__ oflag) {
   using hx8 = typename H16<HT>::x8;
+  bool sat = false;
   const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
   const int64_t S = (int64_t)D * H * W, OS = S * 8;
   const int64_t total = (int64_t)N * CB * S;
@@ -515,18 +517,20 @@ __global__ __launch_bounds__(256) void trilinear2_bwd_c8_kernel(const HT* __rest
     }
     hx8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = to_h16_sat<HT>(acc[j]);
+    for (int j = 0; j < 8; ++j) o[j] = to_h16_sat<HT>(acc[j], sat);
     (reinterpret_cast<hx8*>(dx16 + (int64_t)n * dxbs) + (int64_t)cb * S)[((int64_t)iz * H + iy) * W + ix] = o;
   }
+  report_saturation(sat, oflag);
 }
 
 // y16[n][c][s] = x16[n][c][s] * scale[n * C + c]   (nn.Dropout3d on a c8 activation, and its backward)
 template <typename HT>
 __global__ __launch_bounds__(256) void channel_scale_c8_kernel(const HT* __restrict__ x16, const float* __restrict__ scale,
                                                                HT* __restrict__ y16, int N, int C, int CB, int64_t S,
-                                                               int64_t xbs, int64_t ybs) {
+                                                               int64_t xbs, int64_t ybs, int* __restrict__ oflag) {
   using hx8 = typename H16<HT>::x8;
   const int64_t total = (int64_t)N * CB * S;
+  bool sat = false;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
     const int64_t s = i % S;
     const int64_t r = i / S;
@@ -537,10 +541,11 @@ __global__ __launch_bounds__(256) void channel_scale_c8_kernel(const HT* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = cb * 8 + j;
-      o[j] = to_h16_sat<HT>(c < C ? (float)v[j] * scale[(int64_t)n * C + c] : 0.f);
+      o[j] = to_h16_sat<HT>(c < C ? (float)v[j] * scale[(int64_t)n * C + c] : 0.f, sat);
     }
     (reinterpret_cast<hx8*>(y16 + (int64_t)n * ybs) + (int64_t)cb * S)[s] = o;
   }
+  report_saturation(sat, oflag);
 }
 
 // space-to-depth / depth-to-space by 2 on c8 activations (the Blur convolutions of the msseg2 family in the 16-bit
@@ -770,10 +775,11 @@ extern "C" int m355_upsample_trilinear2x_bwd_h16(const void* dy16, void* dx16, i
   const int64_t total = (int64_t)N * CB * S;
   if (compute == M355_COMPUTE_BF16)
     hipLaunchKernelGGL(trilinear2_bwd_c8_kernel<__bf16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
-                       (hipStream_t)stream, (const __bf16*)dy16, (__bf16*)dx16, N, CB, D, H, W, dybs, dxbs);
+                       (hipStream_t)stream, (const __bf16*)dy16, (__bf16*)dx16, N, CB, D, H, W, dybs, dxbs, overflow_flag());
   else
     hipLaunchKernelGGL(trilinear2_bwd_c8_kernel<_Float16>, dim3(grid_for(total, 256, 65536)), dim3(256), 0,
-                       (hipStream_t)stream, (const _Float16*)dy16, (_Float16*)dx16, N, CB, D, H, W, dybs, dxbs);
+                       (hipStream_t)stream, (const _Float16*)dy16, (_Float16*)dx16, N, CB, D, H, W, dybs, dxbs,
+                       overflow_flag());
   return check_launch("upsample_trilinear2x_bwd_h16");
 }
 
@@ -787,10 +793,10 @@ extern "C" int m355_act16_channel_scale(const void* x16, const float* scale, voi
   const int64_t total = (int64_t)N * CB * S;
   if (compute == M355_COMPUTE_BF16)
     hipLaunchKernelGGL(channel_scale_c8_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x16, scale, (__bf16*)y16, N, C, CB, S, xbs, ybs);
+                       (const __bf16*)x16, scale, (__bf16*)y16, N, C, CB, S, xbs, ybs, overflow_flag());
   else
     hipLaunchKernelGGL(channel_scale_c8_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)x16, scale, (_Float16*)y16, N, C, CB, S, xbs, ybs);
+                       (const _Float16*)x16, scale, (_Float16*)y16, N, C, CB, S, xbs, ybs, overflow_flag());
   return check_launch("act16_channel_scale");
 }
 

@@ -45,6 +45,23 @@ __device__ __forceinline__ _Float16 to_h16_sat<_Float16>(float v) {
   return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
 }
 
+// the same, remembering in `sat` that a value was clamped (the kernel ORs bit 0 into the overflow word at its end)
+template <typename HT>
+__device__ __forceinline__ HT to_h16_sat(float v, bool& sat);
+template <>
+__device__ __forceinline__ __bf16 to_h16_sat<__bf16>(float v, bool&) { return (__bf16)v; }
+template <>
+__device__ __forceinline__ _Float16 to_h16_sat<_Float16>(float v, bool& sat) {
+  sat = sat || fabsf(v) > 65504.f;
+  return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+}
+__device__ __forceinline__ void report_saturation(bool sat, int* __restrict__ oflag) {
+  if (sat && oflag) atomicOr(oflag, 1);
+}
+__device__ __forceinline__ void report_nonfinite(float v, int* __restrict__ oflag) {
+  if (oflag && !(fabsf(v) <= 3.4028235e38f)) atomicOr(oflag, 2);   // inf or NaN
+}
+
 static inline int64_t c8_blocks(int64_t C) { return (C + 7) / 8; }
 
 // fp32 NCDHW -> c8 (round to nearest even) and back; implemented in conv3d_h16.hip

@@ -354,7 +354,8 @@ __global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __res
                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ stat_m, int N,
                                                               int C, int groups, int nblk, int64_t count, int training,
-                                                              const double* __restrict__ count_ptr, float grad_unscale) {
+                                                              const double* __restrict__ count_ptr, float grad_unscale,
+                                                              int* __restrict__ oflag) {
   // synchronised batch norm: divide by the element count over all ranks; the SUM all-reduce of stat_m is then the mean
   if (count_ptr) count = (int64_t)count_ptr[0];
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
@@ -411,6 +412,8 @@ __global__ __launch_bounds__(64) void norm_bwd_reduce_kernel(const double* __res
       // two (loss scaling); the parameter gradients leave in true units
       if (dbeta) dbeta[c] = (float)(a * (double)grad_unscale);
       if (dgamma) dgamma[c] = (float)(bb * (double)grad_unscale);
+      report_nonfinite((float)(a * (double)grad_unscale), oflag);
+      report_nonfinite((float)(bb * (double)grad_unscale), oflag);
     }
   }
 }
@@ -610,7 +613,7 @@ static int norm_act_bwd_reduce_impl(const m355_norm_desc* d, const float* x, con
                        d->act_slope, xbs, ybs, nblk_c);
   const int64_t nthreads = std::max<int64_t>(g.nstats, d->C);
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)nthreads), dim3(64), 0, st, partial, gamma, dgamma, dbeta,
-                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training, count_ptr, 1.f);
+                     stat_m, d->N, d->C, d->groups, nblk_c, g.count, training, count_ptr, 1.f, nullptr);
   return check_launch(who);
 }
 
@@ -621,7 +624,8 @@ int m355::launch_norm_bwd_reduce(const double* partial, const float* gamma, floa
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
   const int64_t count = groups == 0 ? (int64_t)N * S : (int64_t)(C / groups) * S;
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)std::max<int64_t>(nstats, C)), dim3(64), 0, st, partial, gamma,
-                     dgamma, dbeta, stat_m, N, C, groups, nblk_c, count, training, nullptr, grad_unscale);
+                     dgamma, dbeta, stat_m, N, C, groups, nblk_c, count, training, nullptr, grad_unscale,
+                     grad_unscale != 1.f ? overflow_flag() : nullptr);
   return check_launch("norm_bwd_reduce");
 }
 

@@ -32,18 +32,20 @@ __device__ __forceinline__ float act16_grad_t(float pre, int act, float slope) {
 // ---------------------------------------------------------------- scaled layout conversion
 template <typename HT>
 __global__ __launch_bounds__(256) void pack_act16_scaled_kernel(const float* __restrict__ x, HT* __restrict__ x16, int C,
-                                                                int64_t S, int64_t xbs, int64_t x16bs, float scale) {
+                                                                int64_t S, int64_t xbs, int64_t x16bs, float scale, int* __restrict__ oflag) {
   using hx8 = typename H16<HT>::x8;
   const int cb = blockIdx.y, n = blockIdx.z;
   const float* xn = x + (int64_t)n * xbs + (int64_t)cb * 8 * S;
   hx8* dst = reinterpret_cast<hx8*>(x16 + (int64_t)n * x16bs) + (int64_t)cb * S;
   const int nc = min(8, C - cb * 8);
+  bool sat = false;
   for (int64_t s = blockIdx.x * 256ll + threadIdx.x; s < S; s += gridDim.x * 256ll) {
     hx8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = j < nc ? to_h16_sat<HT>(xn[(int64_t)j * S + s] * scale) : (HT)0.f;
+    for (int j = 0; j < 8; ++j) v[j] = j < nc ? to_h16_sat<HT>(xn[(int64_t)j * S + s] * scale, sat) : (HT)0.f;
     dst[s] = v;
   }
+  report_saturation(sat, oflag);
 }
 
 template <typename HT>
@@ -204,9 +206,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_c8c8_kernel(
     const HT* __restrict__ x16, const HT* __restrict__ dy16, const HT* __restrict__ dp16, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stat_m, HT* __restrict__ dx16, int C, int64_t S, int groups, int act, float slope,
-    int64_t xbs16, int64_t ybs16, int64_t pbs16, int64_t dxbs16, int H, int W) {
+    int64_t xbs16, int64_t ybs16, int64_t pbs16, int64_t dxbs16, int H, int W, int* __restrict__ oflag) {
   using hx8 = typename H16<HT>::x8;
   constexpr int U = 2;
+  bool sat = false;
   const int cb = blockIdx.y, n = blockIdx.z;
   const int c0 = cb * 8, nc = min(8, C - c0);
   float m[8], r[8], gm[8], sc[8], sh[8], m1[8], m2[8];
@@ -255,21 +258,24 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_c8c8_kernel(
         const float pre = fmaf(xf, sc[j], sh[j]);
         const float gg = g[u][j] * act16_grad_t(pre, act, slope) * gm[j];
         const float v = r[j] * (gg - m1[j] - xh * m2[j]);
-        o[j] = j < nc ? to_h16_sat<HT>(v) : (HT)0.f;
+        o[j] = j < nc ? to_h16_sat<HT>(v, sat) : (HT)0.f;
       }
       dst[i] = o;
     }
   }
+  report_saturation(sat, oflag);
 }
 
 // ---------------------------------------------------------------- AvgPool3d(2, 2) backward (+ skip gradient), c8 -> c8
 template <typename HT>
 __global__ __launch_bounds__(256) void avgpool2_bwd_c8_kernel(const HT* __restrict__ dp16, const HT* __restrict__ dskip16,
                                                               HT* __restrict__ dx16, int CB, int D, int H, int W,
-                                                              int64_t pbs16, int64_t sbs16, int64_t xbs16, int N) {
+                                                              int64_t pbs16, int64_t sbs16, int64_t xbs16, int N,
+                                                              int* __restrict__ oflag) {
   using hx8 = typename H16<HT>::x8;
   const int64_t S = (int64_t)D * H * W;
   const int64_t total = (int64_t)N * CB * S;
+  bool sat = false;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
     const int64_t v = i % S;
     const int64_t q = i / S;
@@ -283,21 +289,27 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_c8_kernel(const HT* __restri
     src.load(v, g);
     hx8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = to_h16_sat<HT>(g[j]);
+    for (int j = 0; j < 8; ++j) o[j] = to_h16_sat<HT>(g[j], sat);
     (reinterpret_cast<hx8*>(dx16 + (int64_t)n * xbs16) + (int64_t)cb * S)[v] = o;
   }
+  report_saturation(sat, oflag);
 }
 
 // ---------------------------------------------------------------- bias gradient from a c8 gradient
 // dbias[c] = unscale * sum_{n, slot} part[n][slot][c][0] (the per-channel sums of m355_act16_channel_partials)
 __global__ __launch_bounds__(64) void dbias_from_partials_kernel(const float* __restrict__ part, float* __restrict__ dbias,
-                                                                 int N, int C, int slots, float unscale) {
+                                                                 int N, int C, int slots, float unscale,
+                                                                 int* __restrict__ oflag) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0;
   const int64_t items = (int64_t)N * slots;
   for (int64_t i = lane; i < items; i += 64) a += (double)part[(i * C + c) * 2];
   a = wave_sum(a);
-  if (lane == 0) dbias[c] = (float)(a * (double)unscale);
+  if (lane == 0) {
+    const float r = (float)(a * (double)unscale);
+    dbias[c] = r;
+    report_nonfinite(r, oflag);
+  }
 }
 
 int launch_dbias_c8(const void* dy16, int64_t dybs16, float* dbias, int N, int C, int64_t S, int compute, float unscale,
@@ -305,7 +317,8 @@ int launch_dbias_c8(const void* dy16, int64_t dybs16, float* dbias, int N, int C
   const int slots = (int)m355_act16_partials_slots(S);
   float* part = (float*)ws;
   if (int rc = m355_act16_channel_partials(dy16, dybs16, N, C, S, compute, part, st)) return rc;
-  hipLaunchKernelGGL(dbias_from_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, part, dbias, N, C, slots, unscale);
+  hipLaunchKernelGGL(dbias_from_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, part, dbias, N, C, slots, unscale,
+                     overflow_flag());
   return check_launch("dbias_c8");
 }
 
@@ -333,10 +346,10 @@ extern "C" int m355_act16_pack_scaled(const float* x, void* x16, int32_t N, int3
   dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(S, 256 * 4), 4096)), (unsigned)c8_blocks(C), (unsigned)N);
   if (compute == M355_COMPUTE_BF16)
     hipLaunchKernelGGL(pack_act16_scaled_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x16, C, S, xbs,
-                       x16bs, scale);
+                       x16bs, scale, overflow_flag());
   else
     hipLaunchKernelGGL(pack_act16_scaled_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, (_Float16*)x16, C, S,
-                       xbs, x16bs, scale);
+                       xbs, x16bs, scale, overflow_flag());
   return check_launch("act16_pack_scaled");
 }
 
@@ -394,7 +407,7 @@ extern "C" int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, in
 #define M355_NB2(HT, POOL)                                                                                                 \
   hipLaunchKernelGGL((norm_bwd_apply_c8c8_kernel<HT, POOL>), g2, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16,        \
                      (const HT*)dpool16, mean, rstd, gamma, beta, stat_m, (HT*)dx16, d->C, d->S, d->groups, d->act,         \
-                     d->act_slope, xbs, ybs, pbs, dxbs, H, W)
+                     d->act_slope, xbs, ybs, pbs, dxbs, H, W, overflow_flag())
   if (compute == M355_COMPUTE_BF16) { if (dpool16) M355_NB1(__bf16, true); else M355_NB1(__bf16, false); }
   else { if (dpool16) M355_NB1(_Float16, true); else M355_NB1(_Float16, false); }
   if (int rc = launch_norm_bwd_reduce(partial, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, d->S, training,
@@ -424,9 +437,10 @@ extern "C" int m355_avgpool3d_2x_bwd_h16(const void* dpool16, const void* dskip1
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), 16384));
   if (compute == M355_COMPUTE_BF16)
     hipLaunchKernelGGL(avgpool2_bwd_c8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dpool16,
-                       (const __bf16*)dskip16, (__bf16*)dx16, CB, D, H, W, pbs, sbs, xbs, N);
+                       (const __bf16*)dskip16, (__bf16*)dx16, CB, D, H, W, pbs, sbs, xbs, N, overflow_flag());
   else
     hipLaunchKernelGGL(avgpool2_bwd_c8_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)dpool16, (const _Float16*)dskip16, (_Float16*)dx16, CB, D, H, W, pbs, sbs, xbs, N);
+                       (const _Float16*)dpool16, (const _Float16*)dskip16, (_Float16*)dx16, CB, D, H, W, pbs, sbs, xbs, N,
+                       overflow_flag());
   return check_launch("avgpool3d_2x_bwd_h16");
 }

@@ -147,6 +147,11 @@ class ModularUNet(nn.Module):
                     f"block_class {type(blk).__name__} has no HIP execution path (use models.Block3d)")
 
     def forward(self, x):
+        # one forward pass = one loss-scale cell of the fp16 training flow (ops.GradScale; a no-op in every other mode)
+        with ops.grad_scale_scope():
+            return self._forward(x)
+
+    def _forward(self, x):
         f = self._filters
         N, spatial = x.shape[0], tuple(x.shape[2:])
         # 16-bit precision mode under no_grad: activations live only in the c8 layout the conv kernels read

@@ -93,6 +93,10 @@ class NestedResUNet(nn.Module):
         self.hypothesis = hypothesis_class(**hypothesis_params)
 
     def forward(self, x):
+        with ops.grad_scale_scope():   # (one loss-scale cell per forward pass of the fp16 training flow)
+            return self._forward(x)
+
+    def _forward(self, x):
         F = self._filters
         N = x.shape[0]
         sp = [tuple(s >> lvl for s in x.shape[2:]) for lvl in range(4)]

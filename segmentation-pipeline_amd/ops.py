@@ -298,26 +298,142 @@ H16_TRAIN_C8 = True
 H16_TRAIN_C8ONLY = os.environ.get("M355_TRAIN_C8ONLY", "1") != "0"
 _bn_sync_group = None      # (defined properly with batch_norm_sync below)
 
-# fp16 carries activation gradients multiplied by a power of two (include/m355seg.h, "grad_scale"): "auto" derives it
-# from the size of the prediction at the output convolution -- the gradient of a mean-type loss is ~1/(N * voxels) --
-# as 2^(floor(log2(N * voxels)) + 3): the gradient of the logits is then O(1..10) x class weight, three decimal orders
-# below the fp16 maximum (normalisation backward multiplies by rstd, which can be large for a nearly constant group)
-# and four above its normal minimum; a number fixes it.  bf16 has fp32's exponent range: always 1.
+# fp16 carries activation gradients multiplied by a power of two (include/m355seg.h, "grad_scale"); bf16 has fp32's exponent
+# range: always 1.  The scale belongs to ONE backward pass: every node of the c8 training flow holds the `GradScale` cell of
+# the forward pass that created it (`grad_scale_scope`, opened by the models' forward), the node where the gradient ENTERS
+# the flow (the output convolution's backward, `_UnpackFn`) resolves the value, every other node of that pass reads it --
+# two models forwarded before either backward, or an ensemble member of another size, never see each other's scale
+# (round 3 kept one process-wide number, set as a side effect of the softmax out conv's forward).
+# FP16_GRAD_SCALE = "auto": the value is CALIBRATED on the gradient that enters: 2^round(log2(target / max|dL/dlogits|)),
+# measured once per (head, shape) -- one host read -- and again after an overflow; so a mean-reduced loss (gradient
+# ~1 / (N * voxels)), a sum-reduced one (~1) and a StochasticMatrix head all travel at max|g| ~ `target` = 16, three decimal
+# orders below the fp16 maximum (normalisation backward multiplies by rstd) and four above its normal minimum.  While a
+# hipGraph is being captured nothing can be read: the cached calibration is used, or the size-derived estimate
+# 2^(floor(log2(N * voxels)) + 3) of a mean-type loss.  A number fixes the scale.
+# Overflow: the kernels OR into a device word (m355_overflow_flag_set) when a scaled gradient had to be clamped or a
+# parameter gradient came out non-finite; `fp16_overflow()` reads and clears it -- trainer.train_step then skips the
+# optimizer step, and the next backward re-calibrates with a 4x lower target.
 FP16_GRAD_SCALE = "auto"
-_fp16_scale = 2.0 ** 16
+FP16_CHECK_OVERFLOW = True          # trainer.train_step: read the overflow word after every fp16 backward (one host sync)
+_FP16_TARGET_MAX = 16.0
+_fp16_target = _FP16_TARGET_MAX     # max|g| * scale aimed at by the calibration (lowered after an overflow)
+_fp16_clean_checks = 0
+_fp16_calibration = {}              # (head id, gradient shape) -> scale
+_last_scale = 2.0 ** 16             # the most recently resolved fp16 scale (ops.grad_scale: tests, reporting)
+
+
+class GradScale:
+    """the loss scale of one forward / backward pass of the c8 training flow"""
+    __slots__ = ("value", "auto")
+
+    def __init__(self):
+        self.value = None     # resolved where the gradient enters the flow
+        self.auto = None      # size-derived estimate, recorded by the head's forward
+
+    def get(self, compute) -> float:
+        if compute != _lib.COMPUTE_F16:
+            return 1.0
+        if self.value is not None:
+            return self.value
+        return self.auto if self.auto is not None else _last_scale
+
+    def resolve(self, compute, grad: torch.Tensor, key) -> float:
+        """called by an entry node with the fp32 gradient that is about to be packed"""
+        global _last_scale
+        if compute != _lib.COMPUTE_F16:
+            return 1.0
+        if self.value is None:
+            if FP16_GRAD_SCALE != "auto":
+                self.value = float(FP16_GRAD_SCALE)
+            else:
+                cal = _fp16_calibration.get(key)
+                if cal is None and not torch.cuda.is_current_stream_capturing():
+                    import math
+                    amax = float(grad.detach().abs().max())
+                    if math.isfinite(amax) and amax > 0.0:
+                        cal = 2.0 ** min(24, max(-8, round(math.log2(_fp16_target / amax))))
+                        _fp16_calibration[key] = cal
+                if cal is None:
+                    cal = self.auto if self.auto is not None else _last_scale
+                self.value = cal
+            _last_scale = self.value
+        return self.value
+
+
+_gs_default = GradScale()
+_gs_current = None
+
+
+def _gs() -> GradScale:
+    """the cell of the forward pass being recorded (outside a `grad_scale_scope`: one process-wide cell, as in round 3)"""
+    return _gs_current if _gs_current is not None else _gs_default
+
+
+class grad_scale_scope:
+    """`with grad_scale_scope():` around ONE forward pass (ModularUNet / NestedResUNet open it themselves): the c8 nodes
+    created inside share a fresh GradScale cell.  Nested scopes (a model called by an ensemble that is itself inside a
+    scope) keep the outer cell -- one loss, one scale."""
+
+    def __enter__(self):
+        global _gs_current
+        self.prev = _gs_current
+        if _gs_current is None:
+            _gs_current = GradScale()
+        return _gs_current
+
+    def __exit__(self, *exc):
+        global _gs_current
+        _gs_current = self.prev
 
 
 def grad_scale(compute) -> float:
-    return _fp16_scale if compute == _lib.COMPUTE_F16 else 1.0
+    """the fp16 loss scale most recently resolved (1.0 for bf16)"""
+    return _last_scale if compute == _lib.COMPUTE_F16 else 1.0
 
 
-def _set_auto_grad_scale(n_elements):
-    global _fp16_scale
-    if FP16_GRAD_SCALE == "auto":
-        import math
-        _fp16_scale = 2.0 ** min(24, max(0, int(math.floor(math.log2(max(1, n_elements)))) + 3))
+def _auto_grad_scale(n_elements) -> float:
+    import math
+    return 2.0 ** min(24, max(0, int(math.floor(math.log2(max(1, n_elements)))) + 3))
+
+
+_overflow_words = {}   # device index -> int32 device word handed to the library (m355_overflow_flag_set)
+
+
+def _overflow_word(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _overflow_words.get(idx)
+    if w is None and not torch.cuda.is_current_stream_capturing():
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        check(_lib.lib().m355_overflow_flag_set(_p(w), idx), "overflow_flag_set")
+        _overflow_words[idx] = w
+    return w
+
+
+def fp16_overflow(device=None) -> int:
+    """Read and clear the overflow word of the fp16 training flow (one host synchronisation): non-zero when, since the last
+    call, a loss-scaled gradient was clamped to the fp16 range (bit 0) or a parameter gradient came out non-finite (bit 1).  The caller
+    skips its optimizer step; the next backward re-calibrates the scale with a 4x lower target (raised again, 2x per 200
+    clean checks)."""
+    global _fp16_target, _fp16_clean_checks
+    hit = 0
+    for idx, w in _overflow_words.items():
+        if device is not None and device.index not in (None, idx):
+            continue
+        v = int(w.item())
+        if v:
+            w.zero_()
+            hit |= v
+    if hit:
+        _fp16_calibration.clear()
+        _fp16_target = max(_fp16_target / 4.0, 2.0 ** -6)
+        _fp16_clean_checks = 0
     else:
-        _fp16_scale = float(FP16_GRAD_SCALE)
+        _fp16_clean_checks += 1
+        if _fp16_clean_checks >= 200 and _fp16_target < _FP16_TARGET_MAX:
+            _fp16_target = min(_FP16_TARGET_MAX, _fp16_target * 2.0)
+            _fp16_calibration.clear()
+            _fp16_clean_checks = 0
+    return hit
 # an encoder block's last norm + activation pass also emits the AvgPool3d(2, 2) the next level consumes
 FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"
 
@@ -538,12 +654,13 @@ class _PackFn(torch.autograd.Function):
         check(_lib.lib().m355_act16_pack(_p(xd), out.ptr(), N, Cc, out.S, xbs, out.batch_stride(), out.compute, _stream()),
               "act16_pack")
         ctx.info = (Cc, out.spatial, out.compute)
+        ctx.gs = _gs()
         return out.alias()
 
     @staticmethod
     def backward(ctx, dy16):
         Cc, spatial, compute = ctx.info
-        return _unpack_scaled(dy16, Cc, spatial, compute, 1.0 / grad_scale(compute)), None
+        return _unpack_scaled(dy16, Cc, spatial, compute, 1.0 / ctx.gs.get(compute)), None
 
 
 class _UnpackFn(torch.autograd.Function):
@@ -557,11 +674,16 @@ class _UnpackFn(torch.autograd.Function):
         check(_lib.lib().m355_act16_unpack(a.ptr(), _p(x), N, a.C, a.S, a.batch_stride(), 0, a.compute, _stream()),
               "act16_unpack")
         ctx.compute = a.compute
+        ctx.gs = _gs()
+        if a.compute == _lib.COMPUTE_F16:
+            _overflow_word(a.device)
         return x
 
     @staticmethod
     def backward(ctx, dy):
-        return _pack_scaled(dy, ctx.compute, grad_scale(ctx.compute)), None
+        # (a gradient ENTERS the c8 flow here: this node may be the one that fixes the scale of the pass)
+        scale = ctx.gs.resolve(ctx.compute, dy, ("unpack", tuple(dy.shape)))
+        return _pack_scaled(dy, ctx.compute, scale), None
 
 
 @dataclass
@@ -613,8 +735,9 @@ class _Conv3dC8Fn(torch.autograd.Function):
             if meta.softmax and not fuse_sm:
                 logits, y = y, torch.empty_like(y)
                 check(L.m355_softmax_fwd(_p(logits), _p(y), N, Cout, 1, D * H * W, 0.0, _stream()), "softmax_fwd")
-            if meta.softmax:
-                _set_auto_grad_scale(N * D * H * W)
+            if x16.compute == _lib.COMPUTE_F16:     # the head of an fp16 pass: size-derived estimate (capture fallback)
+                _gs().auto = _auto_grad_scale(N * D * H * W)
+                _overflow_word(x16.device)
             out = y
         else:
             y16 = meta.out16
@@ -626,6 +749,7 @@ class _Conv3dC8Fn(torch.autograd.Function):
             prof.append(("conv3d_fwd", 2.0 * 27 * Cin * Cout * N * D * H * W, e0, e1, plan,
                          _conv_bytes(N, Cin, Cout, D * H * W, 27, 2, 4 if meta.f32_out else 2)))
         ctx.meta, ctx.desc = meta, d
+        ctx.gs = _gs()
         ctx.has_bias = bias is not None
         ctx.x_info = (x16.C, x16.spatial, x16.compute)
         xa = x16.alias()
@@ -640,7 +764,6 @@ class _Conv3dC8Fn(torch.autograd.Function):
         L = _lib.lib()
         meta, d = ctx.meta, ctx.desc
         compute = d.compute
-        scale = grad_scale(compute)
         if meta.softmax:
             xa, weight, y = ctx.saved_tensors
             dy = dy.contiguous()
@@ -651,9 +774,11 @@ class _Conv3dC8Fn(torch.autograd.Function):
         else:
             xa, weight = ctx.saved_tensors
         dadd = dy if (meta.has_add and ctx.needs_input_grad[2]) else None
-        if meta.f32_out:        # the gradient enters the c8 flow here
+        if meta.f32_out:        # the gradient enters the c8 flow here: this node fixes the scale of the pass
+            scale = ctx.gs.resolve(compute, dy, (id(weight), tuple(dy.shape)))
             dy16 = _pack_scaled(dy, compute, scale)
         else:
+            scale = ctx.gs.get(compute)
             dy16 = dy
         dy16, dybs = _c8t(dy16)
         xa, xbs = _c8t(xa)
@@ -755,6 +880,7 @@ class _NormActC8Fn(torch.autograd.Function):
                                      out16.ptr(), out16.batch_stride(), x.compute, _stream()), "norm_act_fwd_c8")
         ctx.desc, ctx.batch_stats, ctx.has_add, ctx.has_affine = d, use_batch, a16 is not None, gamma is not None
         ctx.compute, ctx.spatial = x.compute, spatial
+        ctx.gs = _gs()
         ctx.save_for_backward(x.alias(), mean, rstd, gamma, beta)
         if not meta.pool:
             return out16.alias()
@@ -783,7 +909,7 @@ class _NormActC8Fn(torch.autograd.Function):
         D, H, W = ctx.spatial
         check(L.m355_norm_act_bwd_c8(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean), _p(rstd),
                                      _p(gamma), _p(beta), _p(dx16), 0, _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0,
-                                     1.0 / grad_scale(compute), compute, _p(ws), ws.numel(), _stream()), "norm_act_bwd_c8")
+                                     1.0 / ctx.gs.get(compute), compute, _p(ws), ws.numel(), _stream()), "norm_act_bwd_c8")
         dadd = dy16 if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return dx16, dgamma, dbeta, dadd, None
 
@@ -858,6 +984,7 @@ class _ConvTC8Fn(torch.autograd.Function):
         check(L.m355_conv_transpose3d_fwd_h16(C.byref(d), x.ptr(), x.batch_stride(), _p(weight), _p(bias), y16.ptr(),
                                               y16.batch_stride(), x.compute, _stream()), "conv_transpose3d_fwd_h16")
         ctx.desc, ctx.compute, ctx.has_bias = d, x.compute, bias is not None
+        ctx.gs = _gs()
         ctx.save_for_backward(x.alias(), weight)
         return y16.alias()
 
@@ -866,7 +993,7 @@ class _ConvTC8Fn(torch.autograd.Function):
         L = _lib.lib()
         xa, weight = ctx.saved_tensors
         d, compute = ctx.desc, ctx.compute
-        scale = grad_scale(compute)
+        scale = ctx.gs.get(compute)
         dy16, dybs = _c8t(dy16)
         xa, xbs = _c8t(xa)
         S = d.D * d.H * d.W

@@ -11,6 +11,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import distributed as D
+from . import ops
 
 # Cooperative stop flag (segmentation_trainer.py:18-30): the reference installs SIGINT / SIGTERM /
 # SIGUSR2 handlers at import time; here installation is explicit (install_signal_handlers()).
@@ -75,7 +76,20 @@ def train_step(model, criterion, optimizer, predictor, batch, device, timer: Opt
     loss_dict["loss"].backward()
     if isinstance(model, D.PatchParallel):
         model.finish_gradient_sync()
-    optimizer.step()
+    # fp16 mode: a clamped activation gradient or a non-finite parameter gradient (ops.fp16_overflow: the kernels OR into a
+    # device word) means this step's gradients are not to be trusted -- skip the update, as torch's GradScaler does; the
+    # next backward re-calibrates the loss scale.  Under data parallelism every rank must take the same decision.
+    skip = False
+    if ops.get_precision() == "fp16" and ops.FP16_CHECK_OVERFLOW:
+        skip = bool(ops.fp16_overflow())
+        if D.is_distributed():
+            flag = torch.tensor([1.0 if skip else 0.0], device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            skip = bool(flag.item() > 0)
+    if skip:
+        loss_dict = dict(loss_dict, skipped_step=True)
+    else:
+        optimizer.step()
     model.eval()
     if timer:
         timer.stamp("model_backward")

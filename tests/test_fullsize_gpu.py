@@ -188,7 +188,9 @@ def _composed_16bit_training_check(case, mode, prob_tol_fp32, prob_tol_rounded, 
     ref32 = _fp32_oracle_grads(case)
     model, p, ld = _forward(case, mode, train=True)
     assert ops.h16_flow.__doc__ and ops.H16_TRAIN_C8ONLY
+    ops.fp16_overflow()
     ld["loss"].backward()
+    assert ops.fp16_overflow() == 0      # nothing was clamped, every parameter gradient is finite: the step would be taken
     got = {k: v.grad.detach().cpu() for k, v in model.named_parameters()}
     model.zero_grad(set_to_none=True)
     scale = ops.grad_scale(_lib.COMPUTE_F16 if mode == "fp16" else _lib.COMPUTE_BF16)

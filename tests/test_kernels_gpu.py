@@ -979,10 +979,12 @@ def test_bf16_precision_mode_end_to_end(golden):
 
 
 @pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("case", [(1, 32, 32, 8, 16, 64), (2, 40, 33, 5, 6, 32), (1, 96, 64, 4, 4, 32)])
+@pytest.mark.parametrize("case", [(1, 32, 32, 8, 16, 64), (2, 40, 33, 5, 6, 32), (1, 96, 64, 4, 4, 32), (1, 16, 16, 8, 8, 16),
+                                  (2, 24, 9, 3, 7, 21)])
 def test_conv3d_bwd_weight_bf16_mode(hip, oracle, case, compute):
-    """W % 32 == 0 and both channel counts > 4: bf16 weight-gradient kernel (three pre-shifted LDS
-    copies); checked against the oracle with bf16-rounded operands."""
+    """The plain entry point (fp32 NCDHW operands) in a 16-bit compute mode, both channel counts > 4: the operands are
+    rounded into c8 copies and the c8 weight-gradient kernel runs (any W since round 4: the round-1 kernel of this entry
+    needed W % 32 == 0); checked against the oracle with equally rounded operands."""
     N, Ci, Co, D, H, W = case
     x, dy = rnd(N, Ci, D, H, W, seed=1), rnd(N, Co, D, H, W, seed=5)
     dw_h, db_h = hip.conv3d_bwd_weight(x, dy, 3, compute=compute)
@@ -1014,8 +1016,8 @@ def test_conv3d_bwd_weight_from_c8_operands(hip, oracle, compute, env, tuning):
 
 
 def test_conv3d_bwd_weight_bf16_mode_falls_back_to_exact_fp32(hip, oracle):
-    """Geometries the bf16 kernel does not cover (W % 32 != 0, tiny channel counts) stay exact fp32."""
-    for (N, Ci, Co, D, H, W) in [(1, 16, 16, 8, 8, 16), (1, 4, 32, 8, 8, 32)]:
+    """The edge layers (<= 4 channels on one side) of the plain entry point stay exact fp32."""
+    for (N, Ci, Co, D, H, W) in [(1, 32, 3, 8, 8, 16), (1, 4, 32, 8, 8, 32)]:
         x, dy = rnd(N, Ci, D, H, W, seed=1), rnd(N, Co, D, H, W, seed=5)
         dw_h, _ = hip.conv3d_bwd_weight(x, dy, 3, compute=1)
         dw_o, _ = oracle.conv3d_bwd_weight(x, dy, 3, compute=0)
