@@ -87,12 +87,15 @@ class PatchParallel(nn.Module):
                  broadcast_parameters: bool = True, force_collectives: bool = False, sync_batch_norm: bool = False,
                  tail_bucket_bytes: int = 4 << 20, bucket_dtype: torch.dtype = torch.float32):
         super().__init__()
-        if bucket_dtype not in (torch.float32, torch.bfloat16, torch.float16):
-            raise ValueError(f"bucket_dtype must be float32, bfloat16 or float16, not {bucket_dtype}")
+        if bucket_dtype not in (torch.float32, torch.bfloat16):
+            # float16 is refused: the loss scale of the fp16 mode is already removed where a parameter gradient is formed,
+            # so the wire would carry TRUE gradients of a mean-type loss (1e-4 .. 1e-8): fp16 subnormals and zeros
+            raise ValueError(f"bucket_dtype must be float32 or bfloat16 (same exponent range as the fp32 master "
+                             f"gradients), not {bucket_dtype}")
         self.module = module
         self.tail_bucket_bytes = tail_bucket_bytes
         # bucket_dtype: the WIRE type of the gradient all-reduce.  float32 (default): the fp32 buckets themselves are
-        # reduced.  bfloat16 / float16 (the 16-bit precision modes, SURVEY section 5: 36.2 MB instead of 72.3 MB per cfg2
+        # reduced.  bfloat16 (the 16-bit precision modes, SURVEY section 5: 36.2 MB instead of 72.3 MB per cfg2
         # step): each bucket is cast into a 16-bit wire buffer by the packing copy, reduced on the wire type and
         # cast back into the fp32 bucket the optimizer reads -- master gradients and weights stay fp32.
         self.bucket_dtype = bucket_dtype
@@ -197,6 +200,11 @@ class PatchParallel(nn.Module):
                 wviews.append(wire[off:off + self.params[i].numel()].view_as(self.params[i]))
             if idxs:
                 torch._foreach_copy_(wviews, [self.params[i].grad for i in idxs])
+            if len(idxs) < len(self.members[b]):     # members without a gradient this step: their wire slice must not
+                for i in self.members[b]:            # keep last step's reduced value
+                    if self.params[i].grad is None:
+                        _, off = self.bucket_of[i]
+                        wire[off:off + self.params[i].numel()].zero_()
         else:
             src = [(v, self.params[i].grad) for v, i in zip(views, idxs) if self.params[i].grad.data_ptr() != v.data_ptr()]
             if src:
@@ -292,6 +300,11 @@ def gather_tiles(local_out: Optional[torch.Tensor], n_tiles: int, tile_shape, dt
     world = dist.get_world_size(group) if (sharded and is_distributed()) else 1
     rank = dist.get_rank(group) if (sharded and is_distributed()) else 0
     per = (n_tiles + world - 1) // world
+    # the tile buffer itself is returned / sent only when it already has the requested dtype: a model whose tile output
+    # is not `dtype` (a 16-bit head) is cast first, so that every rank contributes the same element type and size --
+    # ranks with a ragged share always send a `dtype` staging buffer
+    if local_out is not None and local_out.dtype != dtype:
+        local_out = local_out.to(dtype)
     if world == 1:      # nothing to exchange: the local tiles ARE the result (no staging copy)
         return local_out if local_out is not None else torch.zeros((0,) + tuple(tile_shape), dtype=dtype, device=device)
     n_local = len(shard_indices(n_tiles, rank, world))

@@ -239,6 +239,57 @@ def test_gather_tiles_restores_global_order():
         assert out[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
 
 
+def _gather_bf16_worker(rank, world):
+    """a model double whose tile outputs are bf16, ragged shares (5 tiles over 2 ranks: 3 + 2), fp32 requested"""
+    n_tiles = 5
+    mine = D.shard_indices(n_tiles, rank, world)
+    local = torch.stack([torch.full((2, 3), float(i) + 0.5) for i in mine]).to(torch.bfloat16)
+    every = D.gather_tiles(local, n_tiles, (2, 3), torch.float32, torch.device("cpu"))
+    one = D.gather_tiles(torch.full((4, 2, 3), 7.0, dtype=torch.bfloat16), 4, (2, 3), torch.float32, torch.device("cpu"),
+                         sharded=False)
+    to0 = D.gather_tiles(local, n_tiles, (2, 3), torch.float32, torch.device("cpu"), dst=0)
+    return every, one, to0
+
+
+def test_gather_tiles_casts_a_16bit_tile_output_before_the_collective():
+    """the tile buffer itself was returned / sent whatever its dtype -- the rank with a full share sent bf16
+    tiles, the rank with a ragged share an fp32 staging buffer, into the same all_gather."""
+    outs = spawn(_gather_bf16_worker)
+    for rank, (every, one, to0) in enumerate(outs):
+        assert every.dtype == torch.float32 and every[:, 0, 0].tolist() == [0.5, 1.5, 2.5, 3.5, 4.5]
+        assert one.dtype == torch.float32 and one.shape == (4, 2, 3)
+        assert (to0 is None) == (rank != 0)
+    assert outs[0][2].dtype == torch.float32 and outs[0][2][:, 1, 2].tolist() == [0.5, 1.5, 2.5, 3.5, 4.5]
+
+
+def test_float16_wire_is_refused():
+    """the loss scale is gone where a parameter gradient is formed: an fp16 wire would flush true gradients to zero"""
+    with pytest.raises(ValueError, match="bfloat16"):
+        D.PatchParallel(Net(), bucket_dtype=torch.float16)
+
+
+def _wire_unused_worker(rank, world):
+    """a member that has a gradient in step 1 only: its wire slice must not carry step 1's reduced value into step 2"""
+    torch.manual_seed(3)
+    model = Net()
+    ddp = D.PatchParallel(model, bucket_bytes=1 << 20, bucket_dtype=torch.bfloat16)
+    x, y = _data(rank)
+    ddp.zero_grad()
+    (R.hybrid_logistic_dice_loss(ddp(x), y)["loss"] + model.unused.sum()).backward()
+    ddp.finish_gradient_sync()
+    assert model.unused.grad is not None and torch.allclose(model.unused.grad, torch.ones(5))
+    ddp.zero_grad()
+    R.hybrid_logistic_dice_loss(ddp(x), y)["loss"].backward()
+    ddp.finish_gradient_sync()
+    b, off = ddp.bucket_of[[i for i, p in enumerate(ddp.params) if p is model.unused][0]]
+    return model.unused.grad is None, ddp.buckets[b][off:off + 5].clone()
+
+
+def test_wire_slice_of_a_member_without_gradient_is_zeroed():
+    for no_grad, sl in spawn(_wire_unused_worker):
+        assert no_grad and torch.equal(sl, torch.zeros(5))
+
+
 def test_grid_locations_and_validation():
     assert grid_locations((256,) * 3, (160,) * 3, (20,) * 3) == R.grid_locations((256,) * 3, (160,) * 3, (20,) * 3)
     assert len(grid_locations((256,) * 3, (160,) * 3, (20,) * 3)) == 8
