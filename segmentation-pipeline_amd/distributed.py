@@ -108,6 +108,7 @@ class PatchParallel(nn.Module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self._build_buckets(bucket_bytes)
         self._pending: List = []
+        self.hooks_enabled = True      # (trainer.SegmentedGraphTrainStep captures the backward with the hooks off)
         self._ready = [0] * len(self.buckets)
         self._used = [set() for _ in self.buckets]
         self._hooks = []
@@ -179,6 +180,8 @@ class PatchParallel(nn.Module):
         b, _ = self.bucket_of[idx]
 
         def hook(param):
+            if not self.hooks_enabled:
+                return
             # autograd has just stored this parameter's gradient (.grad was None, so it was not added
             # into anything: no kernel); count it, and ship the bucket when its last member arrives
             self._used[b].add(idx)

@@ -329,3 +329,60 @@ def test_adam_trajectory_through_patch_parallel_two_ranks():
         elif v.is_floating_point():   # running statistics after four updates of weights that moved by ~lr each
             assert (v.double() - reff.double()).abs().max().item() <= 1e-4, f"buffer {k}"
     assert (num / den) ** 0.5 <= 5e-2, (num / den) ** 0.5   # (see test_adam_trajectory_matches_reference: the sign population)
+
+
+def _segmented_worker(rank, world, port, precision, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        from segmentation_pipeline_amd import distributed as D, ops
+        from segmentation_pipeline_amd.criterions import HybridLogisticDiceLoss
+        from segmentation_pipeline_amd.trainer import SegmentedGraphTrainStep
+        torch.cuda.set_device(0)
+        ops.set_precision(precision)
+        m_e = _build("unet_gn")
+        m_g = copy.deepcopy(m_e)
+        g = torch.Generator().manual_seed(77 + rank)          # every rank trains on its own patches
+        batches = []
+        for _ in range(6):
+            x = torch.randn((2, 3, 16, 16, 16), generator=g)
+            lab = torch.randint(0, 2, (2, 16, 16, 16), generator=g)
+            batches.append({"X": x.cuda(), "y": torch.nn.functional.one_hot(lab, 2).permute(0, 4, 1, 2, 3).float().contiguous().cuda()})
+        crit = HybridLogisticDiceLoss()
+        ddp_e = D.PatchParallel(m_e, bucket_bytes=16 << 10)
+        ddp_g = D.PatchParallel(m_g, bucket_bytes=16 << 10)
+        opt_e = torch.optim.SGD(m_e.parameters(), lr=1e-2, momentum=0.9)
+        opt_g = torch.optim.SGD(m_g.parameters(), lr=1e-2, momentum=0.9)
+        step = SegmentedGraphTrainStep(ddp_g, crit, opt_g, warmup=2)
+        le, lg = [], []
+        for b in batches:
+            m_e.train()
+            ddp_e.zero_grad()
+            ld = crit(ddp_e(b["X"]), b["y"])
+            ld["loss"].backward()
+            ddp_e.finish_gradient_sync()
+            opt_e.step()
+            le.append(float(ld["loss"]))
+            lg.append(float(step(b)["loss"]))
+        same = all(torch.equal(a, b) for a, b in zip(m_e.state_dict().values(), m_g.state_dict().values()))
+        captured = next(iter(step._graphs.values()))["g1"] is not None
+        ret[rank] = (le, lg, same, captured, {k: v.detach().cpu() for k, v in m_g.state_dict().items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_segmented_graph_train_step_over_patch_parallel_two_ranks(precision):
+    """the train step of a PatchParallel-wrapped model replayed from two hipGraphs with the gradient
+    all-reduces issued eagerly between them == the eager wrapper, bit for bit (losses, weights, on both ranks; each rank
+    on its own patches), and both ranks end with identical weights."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_segmented_worker, args=(2, _free_port(), precision, ret), nprocs=2, join=True)
+    for rank in range(2):
+        le, lg, same, captured, _ = ret[rank]
+        assert captured and le == lg and same, (rank, le, lg, same)
+    for k, v in ret[0][4].items():
+        assert torch.equal(v, ret[1][4][k]), k
+    assert ret[0][0] != ret[1][0]          # the ranks really saw different data
