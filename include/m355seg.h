@@ -393,6 +393,23 @@ int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_b
                          const float* beta, void* dx16, int64_t dx16_batch_stride, float* dgamma, float* dbeta,
                          int training, float grad_unscale, int32_t compute, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* The same backward as its two halves around an exchange (synchronised BatchNorm on the c8 flow -- the reference's
+ * dmri_hippo model is BatchNorm, models/nested_residual_unet.py:19-23, and a batch sharded over ranks must normalise
+ * with the statistics of the whole batch): _reduce = first pass + per-statistic sums divided by `total_count[0]` (a
+ * device double: the element count per statistic over ALL ranks) -> stat_m[2 * num_stats] (this rank's share of the
+ * two gradient means) and the local dgamma / dbeta; the host all-reduces stat_m (SUM); _apply = second pass with the
+ * reduced stat_m.  With total_count = this rank's own count the pair equals m355_norm_act_bwd_c8 bit for bit. */
+int m355_norm_act_bwd_c8_reduce(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                                int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride, int32_t D,
+                                int32_t H, int32_t W, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, float* dgamma, float* dbeta, int training, const double* total_count,
+                                float grad_unscale, float* stat_m, int32_t compute, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int m355_norm_act_bwd_c8_apply(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                               int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride, int32_t D,
+                               int32_t H, int32_t W, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* stat_m, void* dx16, int64_t dx16_batch_stride,
+                               int32_t compute, void* stream);
 /* nn.AvgPool3d(2, 2) backward c8 -> c8, optionally adding the gradient of the un-pooled tensor's other consumer
  * (dskip16, may be NULL): dx16[v] = dskip16[v] + dpool16[v / 2] / 8.  D, H, W: the UN-pooled size (even). */
 int m355_avgpool3d_2x_bwd_h16(const void* dpool16, const void* dskip16, void* dx16, int32_t N, int32_t C, int32_t D,

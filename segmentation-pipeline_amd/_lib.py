@@ -87,6 +87,10 @@ SIGNATURES = {
     "m355_conv3d_bwd_weight_c8": (C.c_int, [_CD, _P, _i64, _P, _i64, _P, _P, _f32, _P, _sz, _P]),
     "m355_norm_act_bwd_c8": (C.c_int, [_ND, _P, _i64, _P, _i64, _P, _i64, _i32, _i32, _i32, _P, _P, _P, _P, _P, _i64, _P, _P,
                                        C.c_int, _f32, _i32, _P, _sz, _P]),
+    "m355_norm_act_bwd_c8_reduce": (C.c_int, [_ND, _P, _i64, _P, _i64, _P, _i64, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P,
+                                              C.c_int, _P, _f32, _P, _i32, _P, _sz, _P]),
+    "m355_norm_act_bwd_c8_apply": (C.c_int, [_ND, _P, _i64, _P, _i64, _P, _i64, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P, _i64,
+                                             _i32, _P]),
     "m355_avgpool3d_2x_bwd_h16": (C.c_int, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _P]),
     "m355_upsample_trilinear2x_fwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),
     "m355_upsample_trilinear2x_bwd_h16": (C.c_int, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _P]),

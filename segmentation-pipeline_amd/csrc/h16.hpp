@@ -79,7 +79,8 @@ int launch_norm_bwd_apply_c8(const float* x, const float* dy, const float* mean,
 // c8-only training flow (train16.hip / norm.hip): finalize stage of the normalisation backward shared by the fp32 and c8
 // first passes; bias gradient of a conv from its c8 output gradient
 int launch_norm_bwd_reduce(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* stat_m, int N,
-                           int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st);
+                           int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st,
+                           const double* count_ptr = nullptr);
 size_t dbias_c8_ws_bytes(int N, int C, int64_t S);
 int launch_dbias_c8(const void* dy16, int64_t dybs16, float* dbias, int N, int C, int64_t S, int compute, float unscale,
                     void* ws, hipStream_t st);

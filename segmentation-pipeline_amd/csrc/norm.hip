@@ -619,12 +619,13 @@ static int norm_act_bwd_reduce_impl(const m355_norm_desc* d, const float* x, con
 
 // the finalize stage for the c8 backward (train16.hip), whose first pass writes the same partial layout
 int m355::launch_norm_bwd_reduce(const double* partial, const float* gamma, float* dgamma, float* dbeta, float* stat_m, int N,
-                           int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st) {
+                           int C, int groups, int64_t S, int training, float grad_unscale, hipStream_t st,
+                           const double* count_ptr) {
   const int nblk_c = (int)ceil_div(S, NORM_CHUNK_C8);
   const int64_t nstats = groups == 0 ? C : (int64_t)N * groups;
   const int64_t count = groups == 0 ? (int64_t)N * S : (int64_t)(C / groups) * S;
   hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)std::max<int64_t>(nstats, C)), dim3(64), 0, st, partial, gamma,
-                     dgamma, dbeta, stat_m, N, C, groups, nblk_c, count, training, nullptr, grad_unscale,
+                     dgamma, dbeta, stat_m, N, C, groups, nblk_c, count, training, count_ptr, grad_unscale,
                      grad_unscale != 1.f ? overflow_flag() : nullptr);
   return check_launch("norm_bwd_reduce");
 }

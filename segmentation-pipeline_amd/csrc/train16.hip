@@ -370,54 +370,127 @@ extern "C" int m355_act16_unpack_scaled(const void* x16, float* x, int32_t N, in
   return check_launch("act16_unpack_scaled");
 }
 
+// The two halves of the c8 normalisation backward.  Fused (m355_norm_act_bwd_c8): pass 1 -> reduce -> pass 2 in one call.
+// Split (synchronised BatchNorm on the c8 flow, round 4): ..._c8_reduce = pass 1 + the finalize stage dividing by the
+// element count over ALL ranks (stat_m = this rank's share of the two gradient means), the host all-reduces stat_m (SUM),
+// ..._c8_apply = pass 2 -- as m355_norm_act_bwd_reduce / _apply do for fp32 tensors.
+static int norm_bwd_c8_check(const char* who, const m355_norm_desc* d, const void* x16, const void* dy16, const void* dpool16,
+                             const void* dx16_or_ws, int32_t D, int32_t H, int32_t W, int32_t compute) {
+  if (int rc = check_h16(who, compute)) return rc;
+  M355_REQUIRE(d && x16 && (dy16 || dpool16) && dx16_or_ws, M355_EINVALID_ARG, "%s: null pointer", who);
+  M355_REQUIRE(d->N > 0 && d->C > 0 && d->S > 0 && d->N <= 65535 && c8_blocks(d->C) <= 65535, M355_EINVALID_ARG, "%s: bad shape", who);
+  M355_REQUIRE(d->groups >= 0 && (d->groups == 0 || d->C % d->groups == 0), M355_EINVALID_ARG,
+               "%s: C=%d not divisible by groups=%d", who, d->C, d->groups);
+  M355_REQUIRE(d->act >= M355_ACT_NONE && d->act <= M355_ACT_LEAKY_RELU, M355_EINVALID_ARG, "%s: bad activation", who);
+  M355_REQUIRE(!dpool16 || (D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && (int64_t)D * H * W == d->S),
+               M355_EINVALID_ARG, "%s: a pooled gradient needs even D, H, W with D*H*W == S", who);
+  return M355_OK;
+}
+
+struct NormBwdC8Geom {
+  int64_t xbs, ybs, dxbs, pbs;
+  int nblk;
+  double* partial;
+  float* stat_m;
+};
+
+static int norm_bwd_c8_geom(const char* who, const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                            int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride, const void* dx16,
+                            int64_t dx16_batch_stride, void* workspace, NormBwdC8Geom* g) {
+  const int64_t dense = c8_blocks(d->C) * d->S * 8;
+  g->xbs = dense_or(x16_batch_stride, dense);
+  g->ybs = dense_or(dy16_batch_stride, dense);
+  g->dxbs = dense_or(dx16_batch_stride, dense);
+  g->pbs = dpool16 ? dense_or(dpool16_batch_stride, c8_blocks(d->C) * (d->S / 8) * 8) : 0;   // (pooled: S / 8 voxels)
+  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)dpool16 | (uintptr_t)dx16) & 15) == 0 && g->xbs % 8 == 0 &&
+                   g->ybs % 8 == 0 && g->dxbs % 8 == 0 && g->pbs % 8 == 0, M355_EINVALID_ARG, "%s: c8 tensor not 16B aligned", who);
+  g->nblk = (int)ceil_div(d->S, NORM_CHUNK_C8);
+  g->partial = (double*)workspace;
+  g->stat_m = workspace ? (float*)((char*)workspace + round_up((int64_t)d->N * d->C * g->nblk * 2 * sizeof(double), 256)) : nullptr;
+  return M355_OK;
+}
+
+static void norm_bwd_c8_pass1(const m355_norm_desc* d, const NormBwdC8Geom& g, const void* x16, const void* dy16, const void* dpool16,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, int H, int W,
+                              int32_t compute, hipStream_t st) {
+  const dim3 g1((unsigned)g.nblk, (unsigned)c8_blocks(d->C), (unsigned)d->N);
+#define M355_NB1(HT, POOL)                                                                                                 \
+  hipLaunchKernelGGL((norm_bwd_partial_c8_kernel<HT, POOL>), g1, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16,        \
+                     (const HT*)dpool16, mean, rstd, gamma, beta, g.partial, d->C, d->S, d->groups, d->act, d->act_slope, g.xbs, \
+                     g.ybs, g.pbs, H, W, g.nblk)
+  if (compute == M355_COMPUTE_BF16) { if (dpool16) M355_NB1(__bf16, true); else M355_NB1(__bf16, false); }
+  else { if (dpool16) M355_NB1(_Float16, true); else M355_NB1(_Float16, false); }
+#undef M355_NB1
+}
+
+static void norm_bwd_c8_pass2(const m355_norm_desc* d, const NormBwdC8Geom& g, const void* x16, const void* dy16, const void* dpool16,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, const float* stat_m,
+                              void* dx16, int H, int W, int32_t compute, hipStream_t st) {
+  const dim3 g2((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * 2), 1024)), (unsigned)c8_blocks(d->C),
+                (unsigned)d->N);
+#define M355_NB2(HT, POOL)                                                                                                 \
+  hipLaunchKernelGGL((norm_bwd_apply_c8c8_kernel<HT, POOL>), g2, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16,        \
+                     (const HT*)dpool16, mean, rstd, gamma, beta, stat_m, (HT*)dx16, d->C, d->S, d->groups, d->act,         \
+                     d->act_slope, g.xbs, g.ybs, g.pbs, g.dxbs, H, W, overflow_flag())
+  if (compute == M355_COMPUTE_BF16) { if (dpool16) M355_NB2(__bf16, true); else M355_NB2(__bf16, false); }
+  else { if (dpool16) M355_NB2(_Float16, true); else M355_NB2(_Float16, false); }
+#undef M355_NB2
+}
+
 extern "C" int m355_norm_act_bwd_c8(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
                                     int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride,
                                     int32_t D, int32_t H, int32_t W, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, void* dx16, int64_t dx16_batch_stride,
                                     float* dgamma, float* dbeta, int training, float grad_unscale, int32_t compute,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-  if (int rc = check_h16("norm_act_bwd_c8", compute)) return rc;
-  M355_REQUIRE(d && x16 && (dy16 || dpool16) && mean && rstd && dx16 && workspace, M355_EINVALID_ARG,
-               "norm_act_bwd_c8: null pointer");
-  M355_REQUIRE(d->N > 0 && d->C > 0 && d->S > 0 && d->N <= 65535 && c8_blocks(d->C) <= 65535, M355_EINVALID_ARG,
-               "norm_act_bwd_c8: bad shape");
-  M355_REQUIRE(d->groups >= 0 && (d->groups == 0 || d->C % d->groups == 0), M355_EINVALID_ARG,
-               "norm_act_bwd_c8: C=%d not divisible by groups=%d", d->C, d->groups);
-  M355_REQUIRE(d->act >= M355_ACT_NONE && d->act <= M355_ACT_LEAKY_RELU, M355_EINVALID_ARG, "norm_act_bwd_c8: bad activation");
-  M355_REQUIRE(!dpool16 || (D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && (int64_t)D * H * W == d->S),
-               M355_EINVALID_ARG, "norm_act_bwd_c8: a pooled gradient needs even D, H, W with D*H*W == S");
+  if (int rc = norm_bwd_c8_check("norm_act_bwd_c8", d, x16, dy16, dpool16, dx16, D, H, W, compute)) return rc;
+  M355_REQUIRE(mean && rstd && workspace, M355_EINVALID_ARG, "norm_act_bwd_c8: null pointer");
   M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE, "norm_act_bwd_c8: workspace too small");
-  const int64_t dense = c8_blocks(d->C) * d->S * 8;
-  const int64_t xbs = dense_or(x16_batch_stride, dense), ybs = dense_or(dy16_batch_stride, dense);
-  const int64_t dxbs = dense_or(dx16_batch_stride, dense);
-  const int64_t pbs = dpool16 ? dense_or(dpool16_batch_stride, c8_blocks(d->C) * (d->S / 8) * 8) : 0;   // (pooled: S / 8 voxels)
-  M355_REQUIRE((((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)dpool16 | (uintptr_t)dx16) & 15) == 0 && xbs % 8 == 0 &&
-                   ybs % 8 == 0 && dxbs % 8 == 0 && pbs % 8 == 0, M355_EINVALID_ARG, "norm_act_bwd_c8: c8 tensor not 16B aligned");
+  NormBwdC8Geom g;
+  if (int rc = norm_bwd_c8_geom("norm_act_bwd_c8", d, x16, x16_batch_stride, dy16, dy16_batch_stride, dpool16,
+                                dpool16_batch_stride, dx16, dx16_batch_stride, workspace, &g))
+    return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)ceil_div(d->S, NORM_CHUNK_C8);
-  double* partial = (double*)workspace;
-  float* stat_m = (float*)((char*)workspace + round_up((int64_t)d->N * d->C * nblk * 2 * sizeof(double), 256));
-  const dim3 g1((unsigned)nblk, (unsigned)c8_blocks(d->C), (unsigned)d->N);
-  const dim3 g2((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(d->S, 256 * 2), 1024)), (unsigned)c8_blocks(d->C),
-                (unsigned)d->N);
-#define M355_NB1(HT, POOL)                                                                                                 \
-  hipLaunchKernelGGL((norm_bwd_partial_c8_kernel<HT, POOL>), g1, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16,        \
-                     (const HT*)dpool16, mean, rstd, gamma, beta, partial, d->C, d->S, d->groups, d->act, d->act_slope, xbs, \
-                     ybs, pbs, H, W, nblk)
-#define M355_NB2(HT, POOL)                                                                                                 \
-  hipLaunchKernelGGL((norm_bwd_apply_c8c8_kernel<HT, POOL>), g2, dim3(256), 0, st, (const HT*)x16, (const HT*)dy16,        \
-                     (const HT*)dpool16, mean, rstd, gamma, beta, stat_m, (HT*)dx16, d->C, d->S, d->groups, d->act,         \
-                     d->act_slope, xbs, ybs, pbs, dxbs, H, W, overflow_flag())
-  if (compute == M355_COMPUTE_BF16) { if (dpool16) M355_NB1(__bf16, true); else M355_NB1(__bf16, false); }
-  else { if (dpool16) M355_NB1(_Float16, true); else M355_NB1(_Float16, false); }
-  if (int rc = launch_norm_bwd_reduce(partial, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, d->S, training,
+  norm_bwd_c8_pass1(d, g, x16, dy16, dpool16, mean, rstd, gamma, beta, H, W, compute, st);
+  if (int rc = launch_norm_bwd_reduce(g.partial, gamma, dgamma, dbeta, g.stat_m, d->N, d->C, d->groups, d->S, training,
                                       grad_unscale, st))
     return rc;
-  if (compute == M355_COMPUTE_BF16) { if (dpool16) M355_NB2(__bf16, true); else M355_NB2(__bf16, false); }
-  else { if (dpool16) M355_NB2(_Float16, true); else M355_NB2(_Float16, false); }
-#undef M355_NB1
-#undef M355_NB2
+  norm_bwd_c8_pass2(d, g, x16, dy16, dpool16, mean, rstd, gamma, beta, g.stat_m, dx16, H, W, compute, st);
   return check_launch("norm_act_bwd_c8");
+}
+
+extern "C" int m355_norm_act_bwd_c8_reduce(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                                           int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride,
+                                           int32_t D, int32_t H, int32_t W, const float* mean, const float* rstd,
+                                           const float* gamma, const float* beta, float* dgamma, float* dbeta, int training,
+                                           const double* total_count, float grad_unscale, float* stat_m, int32_t compute,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = norm_bwd_c8_check("norm_act_bwd_c8_reduce", d, x16, dy16, dpool16, workspace, D, H, W, compute)) return rc;
+  M355_REQUIRE(mean && rstd && stat_m, M355_EINVALID_ARG, "norm_act_bwd_c8_reduce: null pointer");
+  M355_REQUIRE(workspace_bytes >= m355_norm_workspace(d), M355_EWORKSPACE, "norm_act_bwd_c8_reduce: workspace too small");
+  NormBwdC8Geom g;
+  if (int rc = norm_bwd_c8_geom("norm_act_bwd_c8_reduce", d, x16, x16_batch_stride, dy16, dy16_batch_stride, dpool16,
+                                dpool16_batch_stride, nullptr, 0, workspace, &g))
+    return rc;
+  hipStream_t st = (hipStream_t)stream;
+  norm_bwd_c8_pass1(d, g, x16, dy16, dpool16, mean, rstd, gamma, beta, H, W, compute, st);
+  return launch_norm_bwd_reduce(g.partial, gamma, dgamma, dbeta, stat_m, d->N, d->C, d->groups, d->S, training, grad_unscale, st,
+                                total_count);
+}
+
+extern "C" int m355_norm_act_bwd_c8_apply(const m355_norm_desc* d, const void* x16, int64_t x16_batch_stride, const void* dy16,
+                                          int64_t dy16_batch_stride, const void* dpool16, int64_t dpool16_batch_stride,
+                                          int32_t D, int32_t H, int32_t W, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, const float* stat_m, void* dx16,
+                                          int64_t dx16_batch_stride, int32_t compute, void* stream) {
+  if (int rc = norm_bwd_c8_check("norm_act_bwd_c8_apply", d, x16, dy16, dpool16, dx16, D, H, W, compute)) return rc;
+  M355_REQUIRE(mean && rstd && stat_m, M355_EINVALID_ARG, "norm_act_bwd_c8_apply: null pointer");
+  NormBwdC8Geom g;
+  if (int rc = norm_bwd_c8_geom("norm_act_bwd_c8_apply", d, x16, x16_batch_stride, dy16, dy16_batch_stride, dpool16,
+                                dpool16_batch_stride, dx16, dx16_batch_stride, nullptr, &g))
+    return rc;
+  norm_bwd_c8_pass2(d, g, x16, dy16, dpool16, mean, rstd, gamma, beta, stat_m, dx16, H, W, compute, (hipStream_t)stream);
+  return check_launch("norm_act_bwd_c8_apply");
 }
 
 extern "C" int m355_avgpool3d_2x_bwd_h16(const void* dpool16, const void* dskip16, void* dx16, int32_t N, int32_t C, int32_t D,

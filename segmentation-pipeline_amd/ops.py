@@ -192,9 +192,9 @@ def h16_flow() -> int:
         return 0
     if not torch.is_grad_enabled():
         return c
-    # with autograd: the c8-only training flow (`_*C8Fn` below), except under synchronised batch norm, whose backward is
-    # split around an all-reduce (fp32 halves only)
-    return c if (H16_TRAIN_C8ONLY and _bn_sync_group is None) else 0
+    # with autograd: the c8-only training flow (`_*C8Fn` below) -- since round 4 under synchronised batch norm too
+    # (m355_norm_act_bwd_c8_reduce / _apply: the backward split around the all-reduce, on c8 tensors)
+    return c if H16_TRAIN_C8ONLY else 0
 
 
 class Act16:
@@ -881,6 +881,7 @@ class _NormActC8Fn(torch.autograd.Function):
         ctx.desc, ctx.batch_stats, ctx.has_add, ctx.has_affine = d, use_batch, a16 is not None, gamma is not None
         ctx.compute, ctx.spatial = x.compute, spatial
         ctx.gs = _gs()
+        ctx.sync = cfg.sync             # synchronised batch norm: (process group, element count over all ranks)
         ctx.save_for_backward(x.alias(), mean, rstd, gamma, beta)
         if not meta.pool:
             return out16.alias()
@@ -907,9 +908,23 @@ class _NormActC8Fn(torch.autograd.Function):
         dbeta = torch.empty(d.C, dtype=torch.float32, device=xa.device) if ctx.has_affine else None
         ws = _workspace(L.m355_norm_workspace(C.byref(d)), xa.device)
         D, H, W = ctx.spatial
-        check(L.m355_norm_act_bwd_c8(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean), _p(rstd),
-                                     _p(gamma), _p(beta), _p(dx16), 0, _p(dgamma), _p(dbeta), 1 if ctx.batch_stats else 0,
-                                     1.0 / ctx.gs.get(compute), compute, _p(ws), ws.numel(), _stream()), "norm_act_bwd_c8")
+        training, unscale = 1 if ctx.batch_stats else 0, 1.0 / ctx.gs.get(compute)
+        if ctx.sync is not None:        # the two halves around the all-reduce of the per-channel gradient means
+            import torch.distributed as dist
+            group, total = ctx.sync
+            stat_m = torch.empty(2 * d.C, dtype=torch.float32, device=xa.device)
+            check(L.m355_norm_act_bwd_c8_reduce(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean),
+                                                _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), training, _p(total),
+                                                unscale, _p(stat_m), compute, _p(ws), ws.numel(), _stream()),
+                  "norm_act_bwd_c8_reduce")
+            dist.all_reduce(stat_m, group=group)
+            check(L.m355_norm_act_bwd_c8_apply(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean),
+                                               _p(rstd), _p(gamma), _p(beta), _p(stat_m), _p(dx16), 0, compute, _stream()),
+                  "norm_act_bwd_c8_apply")
+        else:
+            check(L.m355_norm_act_bwd_c8(C.byref(d), _p(xa), xbs, _p(dy16), dyb, _p(dpool16), dpb, D, H, W, _p(mean), _p(rstd),
+                                         _p(gamma), _p(beta), _p(dx16), 0, _p(dgamma), _p(dbeta), training, unscale, compute,
+                                         _p(ws), ws.numel(), _stream()), "norm_act_bwd_c8")
         dadd = dy16 if (ctx.has_add and ctx.needs_input_grad[3]) else None
         return dx16, dgamma, dbeta, dadd, None
 

@@ -65,6 +65,8 @@ def _worker(rank, world, port, which, precision, ret):
         ops.set_precision(precision)
         model = _build(which)
         ddp = D.PatchParallel(model, sync_batch_norm=which != "unet_gn", bucket_bytes=16 << 10)   # several buckets
+        if precision != "fp32" and which != "unet_gn":
+            assert ops.H16_TRAIN_C8ONLY      # (and h16_flow() no longer looks at the sync group)
         x, w = _inputs()
         per = SHAPE[0] // world
         xs, ws = x[rank * per:(rank + 1) * per].cuda(), w[rank * per:(rank + 1) * per].cuda()
@@ -80,21 +82,19 @@ def _close(a, b, tol, what):
 
 
 @pytest.mark.parametrize("which,precision,tol", [("unet_bn", "fp32", 1.0), ("nested", "fp32", 1.0),
-                                                 ("unet_bn", "bf16", 100.0), ("unet_gn", "fp32", 1.0)])
+                                                 ("unet_bn", "bf16", 100.0), ("nested", "bf16", 100.0),
+                                                 ("unet_bn", "fp16", 30.0), ("unet_gn", "fp32", 1.0)])
 def test_sync_batch_norm_two_ranks_match_one_process(which, precision, tol):
-    """bf16: the same operand roundings in both runs, only the fp32 statistics are summed in another order; the
-    16-bit training flow takes the split backward with the c8 gradient twin (m355_norm_act_bwd_apply, dx16)."""
+    """16-bit modes: since round 4 a model under synchronised batch norm stays on the c8-only training flow (round 3 fell
+    back to the twin flow: 10.1 instead of 7.4 ms per cfg2 step): the backward of every normalisation runs as
+    m355_norm_act_bwd_c8_reduce -> all-reduce -> m355_norm_act_bwd_c8_apply.  The single-process reference is the fused c8
+    flow on the whole batch: the same operand roundings, only the fp32 statistics are summed in another order."""
     from segmentation_pipeline_amd import ops
     ops.set_precision(precision)
     model = _build(which)
     x, w = _inputs()
-    # under synchronised batch norm the 16-bit modes train in the twin flow (the split backward exists for fp32 tensors
-    # with c8 twins only): the single-process reference takes the same flow, so both sides round at the same points
-    ops.H16_TRAIN_C8ONLY = False
-    try:
-        ref_out, ref_loss, ref_grads, ref_bufs = _step(model, x.cuda(), w.cuda(), SHAPE[0])
-    finally:
-        ops.H16_TRAIN_C8ONLY = True
+    assert ops.H16_TRAIN_C8ONLY
+    ref_out, ref_loss, ref_grads, ref_bufs = _step(model, x.cuda(), w.cuda(), SHAPE[0])
 
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -129,12 +129,14 @@ def test_per_rank_statistics_differ_without_sync():
     assert (whole[:2] - half).abs().max().item() > 1e-4
 
 
-def test_sync_halves_bit_identical_at_world_one():
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_sync_halves_bit_identical_at_world_one(precision):
     """One rank: the split statistics / split backward (m355_norm_sums -> m355_norm_stats_from_sums,
-    m355_norm_act_bwd_reduce -> m355_norm_act_bwd_apply) sum in the same order as the fused entry points, so every
-    result is bit-identical -- from x and from the conv epilogue partials."""
+    m355_norm_act_bwd_reduce -> m355_norm_act_bwd_apply; on the c8 flow of the 16-bit modes m355_norm_act_bwd_c8_reduce ->
+    m355_norm_act_bwd_c8_apply) sum in the same order as the fused entry points, so every result is bit-identical -- from x
+    and from the conv epilogue partials."""
     from segmentation_pipeline_amd import ops
-    ops.set_precision("fp32")
+    ops.set_precision(precision)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
@@ -155,6 +157,7 @@ def test_sync_halves_bit_identical_at_world_one():
         for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
             assert torch.equal(a, b)
     finally:
+        ops.set_precision("fp32")
         dist.destroy_process_group()
 
 
