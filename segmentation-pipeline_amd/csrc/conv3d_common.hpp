@@ -112,7 +112,10 @@ __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float*
       a[r] = s1[r];
       a[16 + r] = s2[r];
     }
-    const int l32 = threadIdx.x & 31;
+    // (opaque: the lane-derived values of this once-per-item tail are RECOMPUTED here -- hoisted out of the persistent
+    // kernels' item loop they sat in registers through every MFMA chunk, and conv3_mfma_fwd_p_kernel<4, 32> at the
+    // 256-register limit spilled them to scratch: 5 VGPR spills, 16 B of scratch, round-3 review)
+    const int l32 = opaque((int)threadIdx.x) & 31;
 #pragma unroll
     for (int h = 16; h >= 1; h >>= 1) {
       const bool up = (l32 & h) != 0;
@@ -124,7 +127,7 @@ __device__ __forceinline__ void store_conv_tile(const f32x16 (&acc)[NTW], float*
       }
     }
     const int r = l32 & 15, q = l32 >> 4;
-    const int o = ob + (r & 3) + 8 * (r >> 2);
+    const int o = o0 + 4 * (opaque((int)threadIdx.x >> 5) & 1) + (r & 3) + 8 * (r >> 2);
     if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
   }
 }

@@ -70,7 +70,7 @@ __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT*
       a[r] = s1[r];
       a[16 + r] = s2[r];
     }
-    const int l32 = threadIdx.x & 31;
+    const int l32 = opaque((int)threadIdx.x) & 31;   // (recomputed, not hoisted out of a persistent item loop: conv3d_common.hpp)
 #pragma unroll
     for (int h = 16; h >= 1; h >>= 1) {
       const bool up = (l32 & h) != 0;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT*
       }
     }
     const int r = l32 & 15, q = l32 >> 4;
-    const int o = ob + (r & 3) + 8 * (r >> 2);
+    const int o = o0 + 4 * (opaque((int)threadIdx.x >> 5) & 1) + (r & 3) + 8 * (r >> 2);
     if (o < Cout) stat[(int64_t)o * 2 + q] = a[0];
   }
 }
