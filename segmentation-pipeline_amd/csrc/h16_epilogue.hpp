@@ -11,38 +11,46 @@ namespace m355 {
 // lanes: block q, upper lanes: block q+1) and stores it with a single 16-byte instruction: 8 store
 // instructions per lane and tile (NTW = 4) instead of the 64 dword stores of the fp32 NCDHW epilogue, which
 // was the largest fixed cost of a short-K item (store-issue bound, ~9k cycles of a ~24k-cycle item).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int NTW, int GY, typename HT>
 __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT* __restrict__ dst16,
                                                    const float* __restrict__ bias, int o0, int Cout, int z, int y0,
                                                    int xg, int ly, int half, int H, int W, int64_t S, bool lane_ok,
                                                    float* __restrict__ stat) {
+  // Round 4: this tail is pure vector-ALU work (a wave64 instruction costs 4 cycles, and the edge-layer kernel -- 28 MFMAs
+  // per tile -- spent most of its time here): bias add, statistics and the out-of-volume mask run on register PAIRS
+  // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: half the instructions, the same roundings), the mask is a multiply by
+  // 1 / 0 instead of 16 selects per group.
   using hx4 = typename H16<HT>::x4;
   const int iHW = H * W;
   const int ob = o0 + 4 * half;
-  float bb[16];
+  f32x2 bb[8];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int o = ob + (r & 3) + 8 * (r >> 2);
-    bb[r] = (bias && o < Cout) ? bias[o] : 0.f;     // padded channels of the last block stay exactly zero
+    bb[r >> 1][r & 1] = (bias && o < Cout) ? bias[o] : 0.f;     // padded channels of the last block stay exactly zero
   }
-  float s1[16], s2[16];
+  f32x2 s1[8], s2[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+  for (int r = 0; r < 8; ++r) s1[r] = s2[r] = f32x2{0.f, 0.f};
   const int CBout = (Cout + 7) >> 3;
   uint4* base = reinterpret_cast<uint4*>(dst16);
 #pragma unroll
   for (int g = 0; g < NTW; ++g) {
     const int yg = y0 + g * GY + ly;
     const bool ok = lane_ok && yg < H;
-    float v[16];
+    f32x2 v[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bb[r];
+    for (int r = 0; r < 8; ++r) v[r] = f32x2{acc[g][2 * r], acc[g][2 * r + 1]} + bb[r];
     if (stat) {
+      const float okf = ok ? 1.f : 0.f;
+      const f32x2 mk = f32x2{okf, okf};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float t = ok ? v[r] : 0.f;
+      for (int r = 0; r < 8; ++r) {
+        const f32x2 t = v[r] * mk;          // (finite values: x * 1 = x, x * 0 = 0 -- as the select it replaces)
         s1[r] += t;
-        s2[r] = fmaf(t, t, s2[r]);
+        s2[r] = __builtin_elementwise_fma(t, t, s2[r]);
       }
     }
     const int64_t vox = (int64_t)z * iHW + (int64_t)yg * W + xg;
@@ -51,8 +59,8 @@ __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT*
       hx4 lo, hi;                     // this lane's 4 channels of block 2qp and of block 2qp + 1
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        lo[j] = (HT)v[8 * qp + j];
-        hi[j] = (HT)v[8 * qp + 4 + j];
+        lo[j] = (HT)v[(8 * qp + j) >> 1][(8 * qp + j) & 1];
+        hi[j] = (HT)v[(8 * qp + 4 + j) >> 1][(8 * qp + 4 + j) & 1];
       }
       uint2 X = __builtin_bit_cast(uint2, lo), Y = __builtin_bit_cast(uint2, hi);
       auto r0 = __builtin_amdgcn_permlane32_swap(X.x, Y.x, false, false);
@@ -67,8 +75,8 @@ __device__ __forceinline__ void store_conv_tile_c8(const f32x16 (&acc)[NTW], HT*
     float a[32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      a[r] = s1[r];
-      a[16 + r] = s2[r];
+      a[r] = s1[r >> 1][r & 1];
+      a[16 + r] = s2[r >> 1][r & 1];
     }
     const int l32 = opaque((int)threadIdx.x) & 31;   // (recomputed, not hoisted out of a persistent item loop: conv3d_common.hpp)
 #pragma unroll
