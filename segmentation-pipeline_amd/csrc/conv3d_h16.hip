@@ -839,6 +839,169 @@ static bool launch_c4_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const 
   return true;
 }
 
+// ---- M-channels <= 4: the output convolution of a network (Cout = 3: out conv + softmax of cfg2) ----
+// conv3_h16_kernel spends a 32-row MFMA tile on 3 useful rows: 27 taps x 2 k-halves = 54 MFMAs per 32 voxels and chunk, 0.10 ms
+// for 0.02 ms of bytes (round-3 review, item 3).  Here the tap row dy moves from the K side to the M side: row m = 8 dy + o
+// of the A fragment holds W[o][c][dz][dy][dx], so ONE MFMA per (dz, dx) and INPUT row j produces the partial sums of the
+// three output rows j - dy it contributes to,
+//     P_j[8 dy + o][x] = sum_c W[o, c, dz, dy, dx] * X[c, z + dz - 1, y0 - 1 + j, x + dx - 1]      j = 0 .. NTW + 1
+// and the output row g is an in-lane sum of three accumulator registers: out[o][g] = P_g[o] + P_{g+1}[8 + o] + P_{g+2}[16 + o]
+// (rows 0..3, 8..11, 16..19 all sit in the LOWER lane half of the 32x32 C/D layout: registers o, 4 + o, 8 + o).
+// 9 x (NTW + 2) = 54 MFMAs per chunk and wave instead of 108, 9 A fragments instead of 27, the halo tile and its
+// row-fragment reads exactly as in conv3_h16_kernel's REUSE loop.  fp32 NCDHW output with bias and (optionally)
+// nn.Softmax(dim=1) in registers (models/modular_unet.py:99-100).  One item per workgroup, two workgroups per CU.
+template <int NTW, typename HT>
+__global__ __launch_bounds__(256, 2) void conv3_cout4_h16_kernel(
+    const HT* __restrict__ x16, const HT* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int CB,
+    int Cout, int D, int H, int W, int cout_pad, int tz_tiles, int ty_tiles, int tx_tiles, int nchunks, int64_t xbs16,
+    int64_t ybs, int softmax) {
+  using T = FwdTile<NTW, 32>;
+  using hx8 = typename H16<HT>::x8;
+  constexpr int TZ = 4, TY = T::TY, RS = T::RS, PS = T::PS, HV = (TZ + 2) * PS;
+  constexpr int XI = 2 * HV, XPER = (XI + 255) / 256;      // (half, halo voxel) items of 16 bytes
+  constexpr int WI = 9 * 64, WPER = (WI + 255) / 256;      // ((dz, dx), lane) A-fragment items
+  __shared__ __attribute__((aligned(16))) hx8 xs[XI];
+  __shared__ __attribute__((aligned(16))) hx8 ws[WI];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int iHW = H * W, S = D * iHW;
+  int it = blockIdx.x;
+  const int sp_tiles = tz_tiles * ty_tiles * tx_tiles;
+  const int sp = it % sp_tiles, n = it / sp_tiles;
+  const int txt = sp % tx_tiles, tyt = (sp / tx_tiles) % ty_tiles, tzt = sp / (tx_tiles * ty_tiles);
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * 32;
+
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[XPER];
+#pragma unroll
+  for (int i = 0; i < XPER; ++i) {
+    const int e = tid + 256 * i;
+    const int h = e / HV, r = e - h * HV;
+    const int zz = r / PS, r2 = r - zz * PS;
+    const int yy = r2 / RS, xx = r2 - yy * RS;
+    const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+    const bool ok = e < XI && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    goff[i] = ok ? (unsigned)(h * S + gz * iHW + gy * W + gx) * 16u : OOB;
+  }
+  // this thread's A-fragment items: item (s = (dz, dx), lane' = (m, half')) <- packed weight item of tap (dz, dy = m >> 3, dx),
+  // output channel o = m & 7 (zero rows: o >= Cout or dy > 2)
+  int woff[WPER];
+#pragma unroll
+  for (int k = 0; k < WPER; ++k) {
+    const int idx = tid + 256 * k;
+    const int sidx = idx >> 6, ln = idx & 63, m = ln & 31, hh = ln >> 5;
+    const int o = m & 7, dy = m >> 3, dz = sidx / 3, dx = sidx - 3 * dz;
+    woff[k] = (idx < WI && o < Cout && dy < 3) ? ((dz * 9 + dy * 3 + dx) * 2 + hh) * cout_pad + o : -1;
+  }
+  f32x4 xr[XPER], wr[WPER];
+  auto fetch = [&](int ch, bool live) {
+    const int nb = min(2, CB - 2 * ch);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x16 + (int64_t)n * xbs16 + (int64_t)(2 * ch) * S * 8), 0,
+                                                                  live ? nb * S * 16 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, goff[i], 0, 0));
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp) + (int64_t)ch * 54 * cout_pad;
+#pragma unroll
+    for (int k = 0; k < WPER; ++k) wr[k] = (live && woff[k] >= 0) ? wsrc[woff[k]] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < XPER; ++i)
+      if (tid + 256 * i < XI) reinterpret_cast<f32x4*>(xs)[tid + 256 * i] = xr[i];
+#pragma unroll
+    for (int k = 0; k < WPER; ++k)
+      if (tid + 256 * k < WI) reinterpret_cast<f32x4*>(ws)[tid + 256 * k] = wr[k];
+  };
+  fetch(0, true);
+  commit();
+  __syncthreads();
+  f32x16 acc[NTW + 2];
+#pragma unroll
+  for (int j = 0; j < NTW + 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const hx8* xb = xs + half * HV + wave * PS + l32;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    fetch(ch + 1, ch + 1 < nchunks);          // (zero-sized descriptor after the last chunk: the loads move nothing)
+    // software-pipelined by one step, as conv3_h16_kernel's loop: the 1 + (NTW + 2) fragments of step s + 1 are requested
+    // between the MFMAs of step s (left alone, hipcc sinks every ds_read in front of its MFMA with lgkmcnt(0))
+    {
+      hx8 fa[2], fb[2][NTW + 2];
+      auto lds_step = [&](int st, int slot) {
+        const int dz = st / 3, dx = st % 3;
+        fa[slot] = ws[st * 64 + lane];
+        const hx8* xt = xb + dz * PS + dx;
+#pragma unroll
+        for (int j = 0; j < NTW + 2; ++j) fb[slot][j] = xt[j * RS];
+      };
+      lds_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < 9; ++st) {
+        if (st + 1 < 9) lds_step(st + 1, (st + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < NTW + 2; ++j) acc[j] = H16<HT>::mfma(fa[st & 1], fb[st & 1][j], acc[j]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                 // A + first B fragment of the next step
+#pragma unroll
+        for (int m = 1; m < NTW + 2; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               // one more B fragment
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (ch + 1 < nchunks) commit();
+    __syncthreads();
+  }
+  // ---- output rows: fold the three tap rows, bias, softmax over the <= 4 channels, fp32 NCDHW ----
+  if (half == 0) {
+    const int z = z0 + wave, xg = x0 + l32;
+    const int64_t DHW = (int64_t)S;
+    float bb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bb[c] = (bias && c < Cout) ? bias[c] : 0.f;
+    float* dst = y + (int64_t)n * ybs;
+#pragma unroll
+    for (int g = 0; g < NTW; ++g) {
+      const int yg = y0 + g;
+      if (!(z < D && xg < W && yg < H)) continue;
+      float v[4], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[c] = ((acc[g][c] + acc[g + 1][4 + c]) + acc[g + 2][8 + c]) + bb[c];
+        if (c < Cout) mx = fmaxf(mx, v[c]);
+      }
+      const int64_t base = (int64_t)z * iHW + (int64_t)yg * W + xg;
+      if (softmax) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < Cout) sum += expf(v[c] - mx);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < Cout) dst[base + (int64_t)c * DHW] = expf(v[c] - mx) * inv;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < Cout) dst[base + (int64_t)c * DHW] = v[c];
+      }
+    }
+  }
+}
+
+template <typename HT>
+static bool launch_cout4_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias, float* y, int N,
+                             int kin, int mout, int D, int H, int W, int64_t ybs, hipStream_t st, int softmax) {
+  const int64_t items = (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * N;
+  if (items <= 0 || items >= (1ll << 31) || p.ntw != 4) return false;
+  hipLaunchKernelGGL((conv3_cout4_h16_kernel<4, HT>), dim3((unsigned)items), dim3(256), 0, st, x16, wp, bias, y,
+                     (int)c8_blocks(kin), mout, D, H, W, p.mout_pad, p.tz_tiles, p.ty_tiles, p.tx_tiles, p.nchunks, xbs16, ybs,
+                     softmax);
+  return true;
+}
+
 template <int NTW, int GX, typename HT>
 static void launch_h16(const FwdPlan& p, const HT* x16, int64_t xbs16, const HT* wp, const float* bias,
                        const float* add, float* y, float* slab, int N, int kin, int mout, int D, int H, int W,
@@ -929,6 +1092,10 @@ static int run_h16_conv_t(const FwdPlan& p, const HT* in16, int64_t in16_bs, con
   if (kin <= 4 && out16 && p.ksplit == 1 && p.gx == 32 && p.nw == 4 && !softmax && !tuning().no_small &&
       launch_c4_h16<HT>(p, in16, in16_bs, wpb, kb, (HT*)out, N, mout, D, H, W, out_bs, st, stat))
     return check_launch("conv3_c4_h16");
+  // output convolution (<= 4 M-channels, fp32 result, optional softmax): tap rows folded onto the MFMA's M side
+  if (mout <= 4 && !out16 && !ka && !stat && p.ksplit == 1 && p.gx == 32 && p.nw == 4 && p.ntw == 4 && p.otiles == 1 &&
+      !tuning().no_small && launch_cout4_h16<HT>(p, in16, in16_bs, wpb, kb, out, N, kin, mout, D, H, W, out_bs, st, softmax ? 1 : 0))
+    return check_launch("conv3_cout4_h16");
 #define M355_H16_CASE(NTW, GX)                                                                               \
   if (p.ntw == NTW && p.gx == GX) {                                                                          \
     launch_h16<NTW, GX, HT>(p, in16, in16_bs, wpb, kb, ka, out, slab, N, kin, mout, D, H, W, out_bs, st,       \

@@ -287,6 +287,32 @@ def test_out_conv_softmax_fused_epilogue_16bit(hip, oracle, compute, tuning):
             assert (fused.sum(dim=1) - 1).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("compute", [1, 2], ids=["bf16", "fp16"])
+def test_out_conv_tap_rows_on_the_m_side_16bit(hip, oracle, compute, tuning):
+    """conv3_cout4_h16_kernel (round 4: <= 4 output channels, c8 input, fp32 output -- the out conv of cfg2 / cfg4): the tap
+    row dy sits on the MFMA's M side, an output row is the in-lane sum of three accumulator registers.  Against the oracle
+    on equally rounded operands (1..4 output channels, channel counts that are no multiples of 16, ragged D / H, N = 2,
+    bias, with and without the softmax epilogue) and against the generic 32-row kernel (M355_NO_SMALL=1)."""
+    from segmentation_pipeline_amd import _lib
+    for (N, ci, co, D, H, W) in [(1, 32, 3, 8, 16, 64), (2, 40, 1, 5, 7, 64), (1, 24, 4, 9, 10, 32), (1, 8, 2, 4, 4, 96)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(co, ci, 3, 3, 3, seed=2) * 0.2, rnd(co, seed=3)
+        x16 = hip.act16_pack(x, compute)
+        tuning(M355_NO_SMALL=0, M355_CONV_KSPLIT=1, M355_CONV_NTW=4)   # (the planner takes a lower tile for these small volumes)
+        plan = hip.conv_plan((N, ci, D, H, W), co, compute=compute)
+        assert plan[1] == 4 and plan[2] == 32, plan        # (the geometry the kernel is instantiated for)
+        y = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute)
+        ysm = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute, softmax=True)
+        ref = oracle.conv3d_fwd(x, w, b, compute=compute)
+        close(y, ref, 3e-5, 3e-5 * ref.abs().max().item(), f"logits {(N, ci, co)}")
+        assert torch.equal(ysm, hip.softmax_fwd(y))
+        close(ysm, oracle.softmax_fwd(ref), 1e-4, 1e-5, "softmax")
+        assert torch.equal(y, hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute))     # deterministic
+        tuning(M355_NO_SMALL=1, M355_CONV_KSPLIT=1, M355_CONV_NTW=4)
+        y_generic = hip.conv3d_fwd_h16(x16, ci, (D, H, W), w, b, compute=compute)
+        close(y, y_generic, 3e-5, 3e-5 * ref.abs().max().item(), "vs the 32-row kernel")
+    tuning(M355_NO_SMALL=0)
+
+
 def test_conv3d_deterministic(hip):
     x, w = rnd(1, 32, 8, 16, 32, seed=1), rnd(32, 32, 3, 3, 3, seed=2) * 0.05
     dy = rnd(1, 32, 8, 16, 32, seed=3)
