@@ -1853,8 +1853,11 @@ class _HybridLossFn(torch.autograd.Function):
                                      _stream()), "hybrid_loss_fwd")
         ctx.args = (N, Cc, S, float(dice_weight), 1 if square_dice else 0)
         ctx.save_for_backward(p, t, sums, class_weights)
-        # three independent 0-dim tensors (not views of one buffer) for autograd's sake
-        loss, dice, logistic = out3[0].clone(), out3[1].clone(), out3[2].clone()
+        # three independent 0-dim tensors for autograd's sake: not views of `out3` (a Function must not return views of one
+        # base) and not clones either (three 4-byte device copies of ~10 us each per step) -- fresh tensor objects over the
+        # same storage, as ops._alloc_out makes them for concat slots
+        st = out3.untyped_storage()
+        loss, dice, logistic = (torch.empty((), dtype=torch.float32, device=p.device).set_(st, i, ()) for i in range(3))
         ctx.mark_non_differentiable(dice, logistic)
         return loss, dice, logistic
 
