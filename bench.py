@@ -73,10 +73,10 @@ def source_hash():
 
 def pmc_traffic(kernel_substr, precision="fp32"):
     """HBM bytes per launch of a kernel from the PMC passes of this same command (tools/pmc_collect.sh ->
-    profiles/r03_pmc_traffic[_bf16|_fp16].json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).  PMC
+    profiles/r04_pmc_traffic[_bf16|_fp16].json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).  PMC
     counters cannot be read inside the run; the committed figure is only quoted when it was collected on
     exactly these kernel sources (source_hash), otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json" if precision == "fp32" else f"r03_pmc_traffic_{precision}.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json" if precision == "fp32" else f"r04_pmc_traffic_{precision}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
