@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-3 probe: the c8-only 16-bit TRAINING flow (ops.H16_TRAIN_C8ONLY) against the CPU oracle -- the reference's fp32
+"""Round-3 probe (round 4: the fp16-rounded oracle carries the loss scale; the twin flow has none, its fp16 rows show why): the c8-only 16-bit TRAINING flow (ops.H16_TRAIN_C8ONLY) against the CPU oracle -- the reference's fp32
 arithmetic and the rounding-matched variant (oracle.torch_ref.UNetSpec.rounding) -- and against the round-2 twin flow:
 probabilities, loss, per-parameter gradient cosine / norm ratio, step time.   usage: c8_train_probe.py [small|cfg2|cfg5] ..."""
 import os
@@ -28,12 +28,14 @@ def build(cin, cout, filters, depth):
                        upsample_class=nn.ConvTranspose3d, upsample_params={'kernel_size': 2, 'stride': 2})
 
 
-def oracle_run(sd0, spec, x, y):
+def oracle_run(sd0, spec, x, y, loss_scale=1.0):
+    """loss_scale: the backward pass starts from loss * scale and the parameter gradients are divided by it -- what the
+    fp16 mode's loss scaling does on the GPU (without it the fp16-rounded oracle's activation gradients underflow)"""
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
     p = R.unet_forward(sd, spec, x, training=True)
     ld = R.hybrid_logistic_dice_loss(p, y)
-    ld["loss"].backward()
-    return p.detach(), float(ld["loss"]), {k: v.grad for k, v in sd.items() if v.grad is not None}
+    (ld["loss"] * loss_scale).backward()
+    return p.detach(), float(ld["loss"]), {k: v.grad / loss_scale for k, v in sd.items() if v.grad is not None}
 
 
 def compare(tag, p, loss, grads, ref):
@@ -73,8 +75,10 @@ def main():
         for rounding in (None, "bf16", "fp16"):
             spec = R.UNetSpec(cin, cout, filters, depth, norm="group", groups=8, up="convT", rounding=rounding)
             t0 = time.time()
-            refs[rounding] = oracle_run(sd0, spec, x, y)
-            print(f"  oracle rounding={rounding}: {time.time() - t0:.1f} s, loss {refs[rounding][1]:.6f}", flush=True)
+            scale = ops._auto_grad_scale(shape[0] * shape[2] * shape[3] * shape[4]) if rounding == "fp16" else 1.0
+            refs[rounding] = oracle_run(sd0, spec, x, y, scale)
+            print(f"  oracle rounding={rounding}: {time.time() - t0:.1f} s, loss {refs[rounding][1]:.6f}" +
+                  (f" (loss scale 2^{int(scale).bit_length() - 1})" if scale != 1.0 else ""), flush=True)
         compare("oracle bf16-rounded vs fp32 oracle", refs["bf16"][0], refs["bf16"][1], refs["bf16"][2], refs[None])
         compare("oracle fp16-rounded vs fp32 oracle", refs["fp16"][0], refs["fp16"][1], refs["fp16"][2], refs[None])
         model = model.cuda().train()
