@@ -395,7 +395,9 @@ def run_train(args, rank, world, device, force_ddp, precision=None):
     cin, cout, filters, depth, patch = cfg
     model = build_model(cfg).to(device)
     crit = HybridLogisticDiceLoss()
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95)  # research/msseg2/msseg2.py:94
+    # research/msseg2/msseg2.py:94.  fp16: the FUSED flavour of the same optimizer, whose kernels take the overflow word of
+    # the loss scaling as `found_inf` on the device (trainer.train_step) -- the foreach flavour needs a host read per step
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.95, **({"fused": True} if precision == "fp16" else {}))
     ddp_kw = {"tail_bucket_bytes": int(os.environ["M355_DDP_TAIL"])} if "M355_DDP_TAIL" in os.environ else {}   # (A/B hook)
     if args.bucket_dtype == "bf16":
         ddp_kw["bucket_dtype"] = torch.bfloat16
@@ -513,7 +515,7 @@ def run_train(args, rank, world, device, force_ddp, precision=None):
                                f"{str(filters).replace(' ', '')},{depth},GroupNorm(8),ConvTranspose3d k2s2) on {args.batch}x{cin}x{'x'.join(map(str, patch))} per GPU",
                    "global_batch": world * args.batch, "params": n_params,
                    "parallelism": f"patch-parallel dp{world}" if world > 1 else "single GPU",
-                   "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95)"},
+                   "optimizer": "torch.optim.SGD(lr=1e-3, momentum=0.95" + (", fused=True)" if precision == "fp16" else ")")},
         "infer": infer, "phases_ms": phases, "conv_kernels": conv_summary, "roofline": roofline,
         "rccl": dict(rccl_info(world), gradient_bytes_per_step=(n_params * wire if (world > 1 or force_ddp) else 0),
                      bucket_dtype=args.bucket_dtype),

@@ -409,20 +409,21 @@ def _overflow_word(device):
     return w
 
 
-def fp16_overflow(device=None) -> int:
-    """Read and clear the overflow word of the fp16 training flow (one host synchronisation): non-zero when, since the last
-    call, a loss-scaled gradient was clamped to the fp16 range (bit 0) or a parameter gradient came out non-finite (bit 1).  The caller
-    skips its optimizer step; the next backward re-calibrates the scale with a 4x lower target (raised again, 2x per 200
-    clean checks)."""
+class _DeferredOverflow:
+    """the overflow word of the LAST step on its way to the host (pinned copy + event): read when it has arrived, never
+    waited for -- the scale adaptation may lag a step, the decision to skip does not (it is taken on the device)"""
+
+    def __init__(self):
+        self.host = None
+        self.event = None
+        self.armed = False
+
+
+_deferred = {}      # device index -> _DeferredOverflow
+
+
+def _adapt_after_overflow(hit: int):
     global _fp16_target, _fp16_clean_checks
-    hit = 0
-    for idx, w in _overflow_words.items():
-        if device is not None and device.index not in (None, idx):
-            continue
-        v = int(w.item())
-        if v:
-            w.zero_()
-            hit |= v
     if hit:
         _fp16_calibration.clear()
         _fp16_target = max(_fp16_target / 4.0, 2.0 ** -6)
@@ -433,6 +434,49 @@ def fp16_overflow(device=None) -> int:
             _fp16_target = min(_FP16_TARGET_MAX, _fp16_target * 2.0)
             _fp16_calibration.clear()
             _fp16_clean_checks = 0
+
+
+def fp16_found_inf(device) -> Optional[torch.Tensor]:
+    """The overflow word as the `found_inf` tensor of torch's fused optimizers (float32, 1.0 = skip this step), WITHOUT a
+    host synchronisation: torch.optim.SGD / Adam / AdamW built with fused=True take it (`optimizer.found_inf`, the protocol
+    torch.cuda.amp.GradScaler uses) and leave parameters and optimizer state untouched on the device when it is set.  The
+    word is cleared on the device; its value travels to the host asynchronously and lowers the loss-scale target when it
+    has arrived (usually before the next backward).  None when no fp16 pass has run on this device."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _overflow_words.get(idx)
+    if w is None:
+        return None
+    d = _deferred.get(idx)
+    if d is None:
+        d = _deferred[idx] = _DeferredOverflow()
+        d.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        d.event = torch.cuda.Event()
+    elif d.armed and d.event.query():          # last step's word has arrived
+        _adapt_after_overflow(int(d.host[0]))
+        d.armed = False
+    found = (w != 0).to(torch.float32).reshape(())       # 0-dim, as torch.cuda.amp.GradScaler hands it over
+    if not d.armed:
+        d.host.copy_(w, non_blocking=True)
+        d.event.record()
+        d.armed = True
+    w.zero_()
+    return found
+
+
+def fp16_overflow(device=None) -> int:
+    """Read and clear the overflow word of the fp16 training flow (one host synchronisation): non-zero when, since the last
+    call, a loss-scaled gradient was clamped to the fp16 range (bit 0) or a parameter gradient came out non-finite (bit 1).  The caller
+    skips its optimizer step; the next backward re-calibrates the scale with a 4x lower target (raised again, 2x per 200
+    clean checks)."""
+    hit = 0
+    for idx, w in _overflow_words.items():
+        if device is not None and device.index not in (None, idx):
+            continue
+        v = int(w.item())
+        if v:
+            w.zero_()
+            hit |= v
+    _adapt_after_overflow(hit)
     return hit
 # an encoder block's last norm + activation pass also emits the AvgPool3d(2, 2) the next level consumes
 FUSE_POOL = os.environ.get("M355_FUSE_POOL", "1") != "0"

@@ -79,15 +79,32 @@ def train_step(model, criterion, optimizer, predictor, batch, device, timer: Opt
     # fp16 mode: a clamped activation gradient or a non-finite parameter gradient (ops.fp16_overflow: the kernels OR into a
     # device word) means this step's gradients are not to be trusted -- skip the update, as torch's GradScaler does; the
     # next backward re-calibrates the loss scale.  Under data parallelism every rank must take the same decision.
+    # With a FUSED torch optimizer (SGD / Adam / AdamW, fused=True) the decision stays on the device: the word becomes the
+    # optimizer's `found_inf` tensor, the fused kernels skip the update themselves -- no host synchronisation (measured on
+    # cfg2: 7.1 ms/step instead of 8.4 with the host read).  Any other optimizer: the host reads the word (one sync).
     skip = False
+    found_inf = None
     if ops.get_precision() == "fp16" and ops.FP16_CHECK_OVERFLOW:
-        skip = bool(ops.fp16_overflow())
-        if D.is_distributed():
-            flag = torch.tensor([1.0 if skip else 0.0], device=device if torch.distributed.get_backend() == "nccl" else "cpu")
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            skip = bool(flag.item() > 0)
+        dev = device if isinstance(device, torch.device) else torch.device(device)
+        if getattr(optimizer, "_step_supports_amp_scaling", False) and dev.type == "cuda":
+            found_inf = ops.fp16_found_inf(dev)
+            if found_inf is not None and D.is_distributed():
+                torch.distributed.all_reduce(found_inf, op=torch.distributed.ReduceOp.MAX)
+        else:
+            skip = bool(ops.fp16_overflow())
+            if D.is_distributed():
+                flag = torch.tensor([1.0 if skip else 0.0], device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                skip = bool(flag.item() > 0)
     if skip:
         loss_dict = dict(loss_dict, skipped_step=True)
+    elif found_inf is not None:
+        optimizer.grad_scale, optimizer.found_inf = None, found_inf      # (the GradScaler protocol of fused optimizers)
+        try:
+            optimizer.step()
+        finally:
+            del optimizer.grad_scale, optimizer.found_inf
+        loss_dict = dict(loss_dict, found_inf=found_inf)
     else:
         optimizer.step()
     model.eval()

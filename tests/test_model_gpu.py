@@ -1143,3 +1143,27 @@ def test_fp16_overflow_is_detected_and_the_step_skipped(monkeypatch):
     with sp.precision("bf16"):
         ld, _ = train_step(model, crit, opt, pred, {"X": x, "y": y}, torch.device("cuda"))
     assert not ops.fp16_overflow()
+    # a FUSED optimizer takes the word as its `found_inf` tensor: the skip happens on the device, no host read in the step
+    for make in (lambda ps: torch.optim.SGD(ps, lr=1e-2, momentum=0.9, fused=True), lambda ps: torch.optim.Adam(ps, lr=1e-3, fused=True)):
+        model = _small_unet()
+        optf = make(model.parameters())
+        with sp.precision("fp16"):
+            ld, _ = train_step(model, crit, optf, pred, {"X": x, "y": y}, torch.device("cuda"))   # a clean step: state exists
+            assert float(ld["found_inf"]) == 0.0
+            before = {k: v.clone() for k, v in model.state_dict().items()}
+            state_before = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for st in optf.state.values()]
+            monkeypatch.setattr(ops, "FP16_GRAD_SCALE", 2.0 ** 40)
+            ld, _ = train_step(model, crit, optf, pred, {"X": x, "y": y}, torch.device("cuda"))
+            monkeypatch.setattr(ops, "FP16_GRAD_SCALE", "auto")
+            assert float(ld["found_inf"]) == 1.0
+            for k, v in model.state_dict().items():
+                assert torch.equal(v, before[k]), k
+            for st, st0 in zip(optf.state.values(), state_before):
+                for k, v in st.items():
+                    if torch.is_tensor(v) and k != "step":
+                        assert torch.equal(v, st0[k]), k
+            ld, _ = train_step(model, crit, optf, pred, {"X": x, "y": y}, torch.device("cuda"))
+            torch.cuda.synchronize()
+            assert float(ld["found_inf"]) == 0.0 and ops._fp16_target < 16.0     # (the host has learnt of the overflow by now)
+            assert any(not torch.equal(v, before[k]) for k, v in model.state_dict().items())
+        ops._fp16_target = 16.0
