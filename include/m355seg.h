@@ -61,6 +61,12 @@ enum { M355_F32 = 0 };
  *                     fp32 accumulation (BASELINE cfg3).
  *   M355_COMPUTE_F16  the same with IEEE fp16 operands, v_mfma_f32_32x32x16_f16 (BASELINE cfg5:
  *                     "mixed fp16 with MFMA channel-GEMM path"); values beyond +-65504 become inf.
+ *   M355_COMPUTE_F32X3 fp32 tensors in and out, fp32 accuracy, bf16 matrix pipe: every operand is split EXACTLY
+ *                     into three bf16 values (x = hi + mid + lo, 8 + 8 + 8 significant bits) and six of the nine plane
+ *                     products -- all but the three below 2^-24 of the product -- run on v_mfma_f32_32x32x16_bf16
+ *                     with fp32 accumulation (conv3d_f32x3.hip).  Measured against fp64 the error equals the fp32
+ *                     MFMA kernels' (it is the fp32 accumulation's in both).  Forward / data gradient of layers with
+ *                     Cin >= 8 and Cout > 4; every other descriptor and entry point treats it as M355_COMPUTE_F32.
  * Applies to conv3d fwd, bwd_data and (when W % 32 == 0 and both channel counts > 4) bwd_weight;
  * every other case of the weight gradient runs in exact fp32.
  * In the 16-bit modes the convolution kernels read their input in the "c8" layout
@@ -69,7 +75,7 @@ enum { M355_F32 = 0 };
  * The *_h16 entry points take such tensors directly (the normalisation / pooling passes of the model
  * path write them, m355_norm_act_fwd_h16 ...); the plain entry points accept fp32 NCDHW and convert
  * into their workspace first. */
-enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1, M355_COMPUTE_F16 = 2 };
+enum { M355_COMPUTE_F32 = 0, M355_COMPUTE_BF16 = 1, M355_COMPUTE_F16 = 2, M355_COMPUTE_F32X3 = 3 };
 
 /* activation fused into the normalise pass (components.py:26,54-55) */
 enum { M355_ACT_NONE = 0, M355_ACT_RELU = 1, M355_ACT_LEAKY_RELU = 2 };

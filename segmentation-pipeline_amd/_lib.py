@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(_HERE, "libm355seg.so
 
 M355_OK = 0
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32X3 = 0, 1, 2, 3
 CONV_W_PACKED, CONV_SOFTMAX = 1, 2
 
 

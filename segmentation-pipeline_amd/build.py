@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm355seg.so")
-SOURCES = ["abi.cpp", "conv3d.hip", "conv3d_h16.hip", "act16.hip", "train16.hip", "norm.hip", "elementwise.hip", "convt.hip", "loss_patch_eval.hip", "ensemble.hip",
+SOURCES = ["abi.cpp", "conv3d.hip", "conv3d_f32x3.hip", "conv3d_h16.hip", "act16.hip", "train16.hip", "norm.hip", "elementwise.hip", "convt.hip", "loss_patch_eval.hip", "ensemble.hip",
            "blur_weights.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.hpp", "h16.hpp", "conv3d_common.hpp", "h16_epilogue.hpp")] + \
     [os.path.join(HERE, "..", "include", "m355seg.h")]

@@ -1953,19 +1953,29 @@ int pick_gx(int W) {
   return best;
 }
 
+// M355_COMPUTE_F32X3 (conv3d_f32x3.hip): 8-channel chunks must carry real channels, a 32-row tile real rows, and the
+// 8-channel slab of a sample must fit the 31-bit byte offsets its loads add up
+static bool x3_layer(int kin, int mout, int D, int H, int W) {
+  return tuning().f32x3 && kin >= 8 && mout > 4 && (int64_t)D * H * W < (1ll << 26);
+}
+
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   FwdPlan p{};
   p.mfma = true;
   p.gx = pick_gx(W);
   const int gy = 32 / p.gx;
-  const bool h16 = compute != M355_COMPUTE_F32;  // bf16 / fp16 operand modes share one plan
-  const int cc = h16 ? 16 : 4;  // input channels per LDS chunk
+  const bool h16 = is16(compute);  // bf16 / fp16 operand modes share one plan
+  if (compute == M355_COMPUTE_F32 && tuning().f32x3 == 2) compute = M355_COMPUTE_F32X3;   // M355_F32X3=2: test hook
+  const bool x3 = compute == M355_COMPUTE_F32X3 && x3_layer(kin, mout, D, H, W);
+  if (!h16 && !x3) compute = M355_COMPUTE_F32;
+  p.x3 = x3 ? 1 : 0;
+  const int cc = h16 ? 16 : (x3 ? 8 : 4);  // input channels per LDS chunk
   p.kin_pad = (int)round_up(kin, cc);
   p.mout_pad = (int)round_up(mout, 32);
   p.otiles = p.mout_pad / 32;
   // fp32: a remainder of 1..16 channels runs as ONE 16-row tile on v_mfma_f32_16x16x4_f32 (half the MFMA time of a
   // padded 32-row tile): 40 channels = 32 + 16 rows instead of 64, 80 = 64 + 16 instead of 96
-  p.tile16 = (!h16 && tuning().tile16 && mout % 32 >= 1 && mout % 32 <= 16) ? 1 : 0;
+  p.tile16 = (!h16 && !x3 && tuning().tile16 && mout % 32 >= 1 && mout % 32 <= 16) ? 1 : 0;
   if (p.tile16) p.otiles -= 1;
   const int wtiles = p.otiles + p.tile16;   // workgroup items per spatial tile
   p.nchunks = p.kin_pad / cc;
@@ -2033,7 +2043,33 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     chosen_ks = (int)ks;
     if (nwg * ks * 4 >= 512 * 3) break;
   }
-  for (int i = 0; i < 4 && !h16; ++i) {
+  if (x3) {
+    // conv3_f32x3_kernel: one item per workgroup, two workgroups per CU, NTW <= 4.  A chunk (8 channels) is 14 x 6 x NTW
+    // MFMAs of 32 cycles per wave at the ~1.6 GHz the bf16 pipe holds; split-K as for the fp32 kernels
+    double best3 = 1e30;
+    for (int ntw : {4, 2, 1}) {
+      if (force_ntw && ntw != force_ntw && force_ntw != 8) continue;
+      const int ty = ntw * gy;
+      if (ty > H && ntw > 1 && !force_ntw) continue;
+      const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+      const double chunk_us = 14.0 * 6.0 * ntw * 32.0 / 1600.0 / (ntw >= 4 ? 1.0 : ntw == 2 ? 0.9 : 0.75);
+      for (int ks = 1; ks <= std::min(p.nchunks, 8); ++ks) {
+        if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;
+        if (ks > 1 && ks * out_bytes > (128ll << 20)) break;
+        const int64_t nwg = base_wg * ks;
+        const double rounds = (double)ceil_div(nwg, (int64_t)cus * 2);
+        const double share = nwg <= cus ? 1.0 / 0.8 : 2.0;
+        double cost = rounds * share * ((double)ceil_div(p.nchunks, ks) + 1.0) * chunk_us;
+        if (ks > 1) cost += (2.0 * ks + 1.0) * (double)out_bytes / 4.0e6 + 4.0;
+        if (cost < best3 * 0.98) {
+          best3 = cost;
+          chosen = ntw;
+          chosen_ks = ks;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < 4 && !h16 && !x3; ++i) {
     const int ntw = cands[i];
     if (p.tile16 && ntw == 8) continue;              // the 16-row kernel is instantiated for NTW <= 4
     if (force_ntw && ntw != force_ntw && !(p.tile16 && force_ntw == 8)) continue;
@@ -2099,13 +2135,14 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
     // ... and the queue only pays beyond two residencies of items: up to there the one-shot grid, whose workgroups
     // the hardware hands out as CUs free up, is 3-7 % faster (192->64 @64^3, 2.0 residencies: 1.237 -> 1.195 ms;
     // 128->384 @32^3, 1.5: 0.672 -> 0.628); from 3.4 residencies (40->40 @96^3) the queue wins by 7-9 %
-    p.persistent = compute == M355_COMPUTE_F32 && items < (1ll << 31) && tuning().conv_persistent &&
+    p.persistent = compute == M355_COMPUTE_F32 && !x3 && items < (1ll << 31) && tuning().conv_persistent &&
                    (tuning().conv_persistent > 1 ? items > slots
                                                  : (items > 2 * slots && ceil_div(p.nchunks, p.ksplit) > 1));
     (void)wtiles;
   }
   // packed weights + 256 B for the work counter of the persistent kernel
   p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (h16 ? 2 : 4), 256) + 256;
+  if (x3) p.wp_bytes = (size_t)p.otiles * p.nchunks * (14 * 3 * 1024) + 256;   // [tile][chunk][pair][plane][lane] x 16 B
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
 }
@@ -2121,7 +2158,7 @@ static int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 
 
 // Cout <= 4 forward in exact fp32: z-Toeplitz packed rows instead of a mostly-empty 32-row tile
 static bool small_cout_fwd(const m355_conv3d_desc* d) {
-  return d->Cout <= 4 && d->compute == M355_COMPUTE_F32 && d->W >= 32 && d->D >= 8 && d->Cin >= 8 &&
+  return d->Cout <= 4 && !is16(d->compute) && d->W >= 32 && d->D >= 8 && d->Cin >= 8 &&
          !tuning().no_small && (int64_t)std::max(d->Cin, d->Cout) * d->D * d->H * d->W < (1ll << 31);
 }
 static size_t small_cout_ws(const m355_conv3d_desc* d) {
@@ -2186,9 +2223,9 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
                          bool out16 = false, bool softmax = false) {
   // prepacked: weights already packed for this plan by m355_conv3d_pack (M355_CONV_W_PACKED); `w` is then unused
   const FwdPlan p = plan_mfma(N, kin, mout, D, H, W, compute);
-  M355_REQUIRE(!stat || p.ksplit == 1 || compute == M355_COMPUTE_F32 || out16, M355_EINVALID_ARG,
+  M355_REQUIRE(!stat || p.ksplit == 1 || !is16(compute) || out16, M355_EINVALID_ARG,
                "conv3d_fwd_stats: no fused statistics for this plan (m355_conv3d_stats_slots() == 0)");
-  if (compute != M355_COMPUTE_F32) {
+  if (is16(compute)) {
     if (!in16) {
       // fp32 NCDHW input: one conversion pass into the c8 layout (the model path hands over c8 tensors that its
       // normalisation / pooling passes wrote, m355_conv3d_fwd_h16)
@@ -2212,9 +2249,15 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
   float* slab = (float*)((char*)ws + p.wp_bytes);
   int* work_counter = queue_state(st);   // per (device, stream): concurrent launches over one model never share it
   M355_REQUIRE(work_counter, M355_ELAUNCH, "conv3d: could not allocate the work-queue state");
-  if (!prepacked) launch_pack_w3(p, w, wp, Cout_w, Cin_w, transpose, st);
   const float* kb = p.ksplit == 1 ? bias : nullptr;
   const float* ka = p.ksplit == 1 ? add : nullptr;
+  if (p.x3) {
+    if (!prepacked) launch_pack_w3_x3(p, w, wp, Cout_w, Cin_w, transpose, st);
+    if (int rc = launch_x3_conv(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, st,
+                                p.ksplit == 1 ? stat : nullptr))
+      return rc;
+  } else {
+  if (!prepacked) launch_pack_w3(p, w, wp, Cout_w, Cin_w, transpose, st);
 #define M355_FWD_CASE(NTW, GX)                                                              \
   if (p.ntw == NTW && p.gx == GX) {                                                         \
     launch_fwd<NTW, GX>(p, in, wp, kb, ka, out, slab, N, kin, mout, D, H, W, in_bs, out_bs, \
@@ -2236,6 +2279,7 @@ static int run_mfma_conv(const float* in, const float* w, bool transpose, int Co
     return M355_EUNSUPPORTED;
   }
 #undef M355_FWD_CASE
+  }
   if (p.ksplit > 1 && stat) {   // split plan + fused statistics: the reduction pass emits the partials
     const int64_t S = (int64_t)D * H * W;
     dim3 grid((unsigned)splitk_c8_slots(S), (unsigned)mout, (unsigned)N);
@@ -2362,7 +2406,7 @@ extern "C" size_t m355_conv3d_fwd_workspace(const m355_conv3d_desc* d) {
   if (small_cout_fwd(d)) return small_cout_ws(d);
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes +
-         (d->compute != M355_COMPUTE_F32 ? act16_staging_bytes(d->N, d->Cin, d->D, d->H, d->W) : 0);
+         (is16(d->compute) ? act16_staging_bytes(d->N, d->Cin, d->D, d->H, d->W) : 0);
 }
 
 static int validate_conv(const m355_conv3d_desc* d, const char* who) {
@@ -2371,7 +2415,8 @@ static int validate_conv(const m355_conv3d_desc* d, const char* who) {
                M355_EINVALID_ARG, "%s: non-positive dimension", who);
   M355_REQUIRE(d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->pad >= 0, M355_EINVALID_ARG,
                "%s: bad k/stride/pad (%d/%d/%d)", who, d->k, d->stride, d->pad);
-  M355_REQUIRE(d->compute == M355_COMPUTE_F32 || d->compute == M355_COMPUTE_BF16 || d->compute == M355_COMPUTE_F16,
+  M355_REQUIRE(d->compute == M355_COMPUTE_F32 || d->compute == M355_COMPUTE_BF16 || d->compute == M355_COMPUTE_F16 ||
+                   d->compute == M355_COMPUTE_F32X3,
                M355_EINVALID_ARG,
                "%s: unknown compute mode %d", who, d->compute);
   return M355_OK;
@@ -2384,14 +2429,14 @@ static int64_t conv_stats_slots(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || small_cout_fwd(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1)   // split-K: the fp32 reduction pass emits the partials (one slot per block of it); the 16-bit
-    return d->compute == M355_COMPUTE_F32 && d->N <= 65535 && d->Cout <= 65535   // kernels only with a c8 output
+    return !is16(d->compute) && d->N <= 65535 && d->Cout <= 65535   // kernels only with a c8 output
                ? splitk_c8_slots((int64_t)d->D * d->H * d->W) : 0;
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
 }
 extern "C" int64_t m355_conv3d_stats_slots(const m355_conv3d_desc* d) { return d ? conv_stats_slots(d) : 0; }
 // c8-output forward of the 16-bit modes: split-K plans emit the partials from their reduction pass
 static int64_t conv_stats_slots_c8(const m355_conv3d_desc* d) {
-  if (!is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
+  if (!is_k3s1p1(d) || !is16(d->compute)) return 0;
   FwdPlan p = plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute);
   if (p.ksplit != 1) return splitk_c8_slots((int64_t)d->D * d->H * d->W);
   return (int64_t)p.tz_tiles * p.ty_tiles * p.tx_tiles * p.nw;
@@ -2413,7 +2458,7 @@ static void launch_pack_smallcout(const m355_conv3d_desc* d, const float* w, flo
 // softmax over the output channels in the epilogue: the fp32 packed-FMA kernel for Cout <= 4
 static bool fuses_softmax(const m355_conv3d_desc* d) {
   if (!is_k3s1p1(d) || !tuning().fuse_softmax) return false;
-  if (d->compute != M355_COMPUTE_F32)   // 16-bit kernels (c8 input, m355_conv3d_fwd_h16): in-register epilogue, unsplit plans
+  if (is16(d->compute))   // 16-bit kernels (c8 input, m355_conv3d_fwd_h16): in-register epilogue, unsplit plans
     return d->Cout <= 4 && plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute).ksplit == 1;
   return small_cout_fwd(d) && tuning().smallcout_valu && (int64_t)d->D * d->H * d->W < (1ll << 27);
 }
@@ -2506,7 +2551,9 @@ extern "C" int m355_conv3d_pack(const m355_conv3d_desc* d, int32_t which, const 
   }
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  if (d->compute == M355_COMPUTE_F32)
+  if (p.x3)
+    launch_pack_w3_x3(p, w, packed, d->Cout, d->Cin, which == 1, st);
+  else if (!is16(d->compute))
     launch_pack_w3(p, w, (float*)packed, d->Cout, d->Cin, which == 1, st);
   else
     launch_pack_w3_h16(p, d->compute, w, packed, d->Cout, d->Cin, which == 1, st);
@@ -2532,7 +2579,11 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
     }
     const FwdPlan p = it.which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                     : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-    const int kind = d->compute == M355_COMPUTE_F32 ? 0 : (d->compute == M355_COMPUTE_BF16 ? 1 : 2);
+    if (p.x3) {   // split + fragment-ordered weights: launched on their own
+      launch_pack_w3_x3(p, it.w, it.packed, d->Cout, d->Cin, it.which == 1, st);
+      continue;
+    }
+    const int kind = !is16(d->compute) ? 0 : (d->compute == M355_COMPUTE_BF16 ? 1 : 2);
     if (nb && (kind == 0) != (b.e[0].kind == 0)) {   // a launch holds fp32 entries or 16-bit entries, not both
       launch_pack_batch(b, nb, st);
       nb = 0;
@@ -2543,7 +2594,7 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
     e.counter = (int*)((char*)it.packed + p.wp_bytes - 256);
     e.Cout = d->Cout;
     e.Cin = d->Cin;
-    e.kdim = d->compute == M355_COMPUTE_F32 ? p.kin_pad : p.nchunks;
+    e.kdim = !is16(d->compute) ? p.kin_pad : p.nchunks;
     e.mout_pad = p.mout_pad;
     e.transpose = it.which == 1;
     e.kind = kind;
@@ -2587,7 +2638,7 @@ extern "C" int m355_act16_unpack(const void* x16, float* x, int32_t N, int32_t C
 }
 
 extern "C" size_t m355_conv3d_h16_workspace(const m355_conv3d_desc* d, int32_t which) {
-  if (!d || !is_k3s1p1(d) || d->compute == M355_COMPUTE_F32) return 0;
+  if (!d || !is_k3s1p1(d) || !is16(d->compute)) return 0;
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes;
@@ -2595,7 +2646,7 @@ extern "C" size_t m355_conv3d_h16_workspace(const m355_conv3d_desc* d, int32_t w
 
 static int validate_h16(const m355_conv3d_desc* d, const char* who) {
   if (int rc = validate_conv(d, who)) return rc;
-  M355_REQUIRE(is_k3s1p1(d) && d->compute != M355_COMPUTE_F32, M355_EUNSUPPORTED,
+  M355_REQUIRE(is_k3s1p1(d) && is16(d->compute), M355_EUNSUPPORTED,
                "%s: c8 input is only defined for the 3x3x3 / stride 1 / pad 1 kernels in a 16-bit compute mode", who);
   return M355_OK;
 }
@@ -2678,7 +2729,7 @@ static int bww_c8_nsplit(const m355_conv3d_desc* d) {
 }
 
 static bool bww_c8_ok(const m355_conv3d_desc* d) {
-  return is_k3s1p1(d) && d->compute != M355_COMPUTE_F32 && (int64_t)d->D * d->H * d->W * 64 < (1ll << 31);
+  return is_k3s1p1(d) && is16(d->compute) && (int64_t)d->D * d->H * d->W * 64 < (1ll << 31);
 }
 
 extern "C" size_t m355_conv3d_bwd_weight_h16_workspace(const m355_conv3d_desc* d) {
@@ -2781,7 +2832,7 @@ extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-  out4[0] = d->compute != M355_COMPUTE_F32 ? (p.oneshot ? 6 : (p.nw == 8 ? 5 : 4)) : (p.persistent ? 3 : 1); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
+  out4[0] = is16(d->compute) ? (p.oneshot ? 6 : (p.nw == 8 ? 5 : 4)) : (p.x3 ? 7 : (p.persistent ? 3 : 1)); out4[1] = p.ntw; out4[2] = p.gx; out4[3] = p.ksplit;
   return M355_OK;
 }
 
@@ -2789,7 +2840,7 @@ extern "C" size_t m355_conv3d_bwd_data_workspace(const m355_conv3d_desc* d) {
   if (!d || !is_k3s1p1(d)) return 0;
   const FwdPlan p = plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
   return p.wp_bytes + p.slab_bytes +
-         (d->compute != M355_COMPUTE_F32 ? act16_staging_bytes(d->N, d->Cout, d->D, d->H, d->W) : 0);
+         (is16(d->compute) ? act16_staging_bytes(d->N, d->Cout, d->D, d->H, d->W) : 0);
 }
 
 extern "C" int m355_conv3d_bwd_data(const m355_conv3d_desc* d, const float* dy, const float* w,
@@ -2842,7 +2893,7 @@ int launch_dbias(const float* dy, float* dbias, int N, int Cout, int64_t S, int6
 // of its own for this case, conv3_mfma_bww_h16_kernel, three dx-shifted LDS copies at a third of the c8 kernel's rate)
 static bool bww_c8_ok(const m355_conv3d_desc* d);
 static bool bww_plain_h16(const m355_conv3d_desc* d) {
-  return d->compute != M355_COMPUTE_F32 && is_k3s1p1(d) && !small_bww(d) && bww_c8_ok(d) && d->N <= 65535;
+  return is16(d->compute) && is_k3s1p1(d) && !small_bww(d) && bww_c8_ok(d) && d->N <= 65535;
 }
 
 extern "C" size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d) {

@@ -143,10 +143,17 @@ struct FwdPlan {
   int tile16;       // + one 16-row remainder tile at channel 32 * otiles (fp32 path, mout % 32 in 1..16)
   int nw;           // waves per workgroup = z slices of a tile: 4, or 8 (16-bit kernels, double-buffered variant)
   int oneshot;      // 16-bit kernels: one item per workgroup instead of the work queue (items of 1-2 chunks)
+  int x3;           // M355_COMPUTE_F32X3 and the layer qualifies: conv3_f32x3_kernel (conv3d_f32x3.hip), 8-channel chunks
   size_t wp_bytes, slab_bytes;
 };
 
 int pick_gx(int W);
+inline bool is16(int compute) { return compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16; }
+// M355_COMPUTE_F32X3 (conv3d_f32x3.hip): split + fragment-ordered weights, and the kernel launch of a plan with x3 != 0
+void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose, hipStream_t st);
+int launch_x3_conv(const FwdPlan& p, const float* in, const void* wp, const float* bias, const float* add, float* out,
+                   float* slab, int N, int kin, int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, hipStream_t st,
+                   float* stat);
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32);
 
 // 16-bit operand convolution (conv3d_h16.hip).  in16: c8 layout (h16.hpp) with `in16_bs` ELEMENTS between

@@ -17,6 +17,10 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 
 # Arithmetic of the 3x3x3 convolutions: "fp32" = exact fp32 MFMA (default, the mode every 1e-4 parity
 # claim refers to), "bf16" / "fp16" = operands rounded to 16 bits, fp32 accumulate (BASELINE cfg3 / cfg5).
+# "fp32x3" = fp32 tensors and fp32 accuracy on the bf16 matrix pipe: every operand split exactly into three bf16
+# values, six plane products per fp32 product, fp32 accumulation (M355_COMPUTE_F32X3, csrc/conv3d_f32x3.hip) -- the
+# same tensors, layouts and flow as "fp32", only the conv kernels differ; results differ from "fp32" by summation-order
+# noise (both sit ~1e-6 of max|y| from an fp64 convolution).
 # In the 16-bit modes the forward / data-gradient / weight-gradient kernels of the 3x3x3 stride-1 convolutions with
 # more than 4 channels on both sides read the c8 activation layout (include/m355seg.h; `H16_TRAIN_C8` below); the
 # edge layers go through the fp32-tensor entry points, which round the operands while staging them (Cin <= 4
@@ -24,7 +28,7 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 # kernels always compute in fp32.
 # Under torch.no_grad() the activations between conv -> norm/act -> conv (-> pool) live ONLY in c8 (`Act16`):
 # no fp32 copy is written or read.
-_COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16}
+_COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16, "fp32x3": _lib.COMPUTE_F32X3}
 _DT16 = {_lib.COMPUTE_BF16: torch.bfloat16, _lib.COMPUTE_F16: torch.float16}
 _compute_mode = "fp32"
 
@@ -188,7 +192,7 @@ def h16_flow() -> int:
     """The 16-bit compute code when activations should flow in the c8 layout (a 16-bit precision mode; with autograd
     recording the c8-only training flow, H16_TRAIN_C8ONLY), else 0."""
     c = _COMPUTE[_compute_mode]
-    if c == _lib.COMPUTE_F32:
+    if c not in _DT16:
         return 0
     if not torch.is_grad_enabled():
         return c
@@ -1146,7 +1150,7 @@ class _Conv3dFn(torch.autograd.Function):
         # internally), consumed by the forward kernel and kept for the weight gradient (m355_conv3d_bwd_weight_h16
         # reads both operands as c8); the fp32 input is then not saved at all
         x16 = None
-        if (H16_TRAIN_C8 and d.compute != _lib.COMPUTE_F32 and k == 3 and meta.stride == 1 and meta.pad == 1
+        if (H16_TRAIN_C8 and d.compute in _DT16 and k == 3 and meta.stride == 1 and meta.pad == 1
                 and Cin > 4 and Cout > 4 and not meta.softmax and D * H * W * 64 < 2 ** 31
                 and ctx.needs_input_grad[0]):
             x16 = _c8_twin(x, d.compute)
@@ -1574,7 +1578,7 @@ class _NormActFn(torch.autograd.Function):
         compute = _COMPUTE[_compute_mode]
         ctx.dx_twin = cfg.dx_twin
         cfg.twin = None
-        if H16_TRAIN_C8 and compute != _lib.COMPUTE_F32 and cfg.out is None and ybs == Cc * S and Cc > 4:
+        if H16_TRAIN_C8 and compute in _DT16 and cfg.out is None and ybs == Cc * S and Cc > 4:
             cfg.twin = Act16.empty(N, Cc, tuple(x.shape[2:]), compute, x.device)
             check(L.m355_norm_act_fwd_h16(C.byref(d), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(add), _p(y),
                                           cfg.twin.ptr(), cfg.twin.batch_stride(), compute, _stream()), "norm_act_fwd_h16")

@@ -35,8 +35,14 @@ def timeit(fn, iters=5):
 def main():
     ops = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd", "bwd_data", "bwd_weight"]
     layers = QUICK if "--quick" in sys.argv else CFG2
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):   # --only=out,d0.c0
+            layers = [l for l in CFG2 if l[0] in a[7:].split(",")]
     hip = RawOps("hip")
     compute = 1 if "--bf16" in sys.argv else (2 if "--fp16" in sys.argv else 0)
+    h16 = compute != 0
+    if "--f32x3" in sys.argv:   # fp32 tensors, bf16 matrix pipe on an exact 3-way split (M355_COMPUTE_F32X3)
+        compute = 3
     tot = {o: [0.0, 0.0] for o in ops}
     print(f"{'layer':8s} {'Cin':>4s} {'Cout':>4s} {'S':>4s} " + " ".join(f"{o + ' ms':>14s} {'TF':>6s}" for o in ops))
     for name, ci, co, sp in layers:
@@ -52,15 +58,15 @@ def main():
             x, w, dy = torch.ones_like(x), torch.full_like(w, 0.05), torch.ones_like(dy)
         flops = 2.0 * 27 * ci * co * sp ** 3
         row = f"{name:8s} {ci:4d} {co:4d} {sp:4d} "
-        if compute:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
+        if h16:   # 16-bit modes: the model path hands over c8 tensors (packed outside the timing)
             x16, dy16 = hip.act16_pack(x, compute), hip.act16_pack(dy, compute)
         for o in ops:
-            if o == "fwd" and compute and ci > 4:   # c8 in, c8 out (the inference flow); --f32out: fp32 NCDHW output
+            if o == "fwd" and h16 and ci > 4:   # c8 in, c8 out (the inference flow); --f32out: fp32 NCDHW output
                 if "--f32out" in sys.argv:
                     ms = timeit(lambda: hip.conv3d_fwd_h16(x16, ci, (sp, sp, sp), w, compute=compute))
                 else:
                     ms = timeit(lambda: hip.conv3d_fwd_h16_c8(x16, ci, (sp, sp, sp), w, compute=compute))
-            elif o == "bwd_data" and compute and ci > 4:
+            elif o == "bwd_data" and h16 and ci > 4:
                 if "--f32out" in sys.argv:
                     ms = timeit(lambda: hip.conv3d_bwd_data_h16(dy16, co, w, x.shape, compute=compute))
                 else:   # c8 in, c8 out (the c8 training flow)
@@ -69,9 +75,9 @@ def main():
                 ms = timeit(lambda: hip.conv3d_fwd(x, w, compute=compute))
             elif o == "bwd_data":
                 ms = timeit(lambda: hip.conv3d_bwd_data(dy, w, x.shape, compute=compute))
-            elif compute and ci > 4 and co > 4 and "--f32in" not in sys.argv:   # c8 operands (the 16-bit training flow)
+            elif h16 and ci > 4 and co > 4 and "--f32in" not in sys.argv:   # c8 operands (the 16-bit training flow)
                 ms = timeit(lambda: hip.conv3d_bwd_weight_h16(x16, dy16, dy, ci, co, (sp, sp, sp), compute, with_bias=False))
-            elif compute and "--f32in" not in sys.argv:   # the edge layers of the c8 training flow (conv3_bww_c8_small_kernel)
+            elif h16 and "--f32in" not in sys.argv:   # the edge layers of the c8 training flow (conv3_bww_c8_small_kernel)
                 ms = timeit(lambda: hip.conv3d_bwd_weight_c8(x16, dy16, ci, co, (sp, sp, sp), compute, with_bias=False))
             else:
                 ms = timeit(lambda: hip.conv3d_bwd_weight(x, dy, 3, with_bias=False, compute=compute))
