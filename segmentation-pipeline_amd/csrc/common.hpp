@@ -73,6 +73,7 @@ struct Tuning {
   int conv_cube = 3, h16_order = 3;   // item order of the conv kernels: bit 0 = (y, z) tiles in 4x4 cubes, bit 1 = channel tile fastest
   int fuse_softmax = 1;
   int f32x3 = 1;         // M355_COMPUTE_F32X3 layers run conv3_f32x3_kernel (0: they run the fp32 MFMA kernels)
+  int f32x3_bww = 1;     // ... and conv3_bww_x3_kernel for the weight gradient
   int convt_wgs = 0;     // c8 conv-transpose kernels: workgroups per CU of the persistent grids (0 = built-in)
   int h16_stagger = 2;   // 16-bit conv kernel: start offset of the odd workgroup of a CU, in units of 1024 cycles
 };

@@ -2896,12 +2896,21 @@ static bool bww_plain_h16(const m355_conv3d_desc* d) {
   return is16(d->compute) && is_k3s1p1(d) && !small_bww(d) && bww_c8_ok(d) && d->N <= 65535;
 }
 
+// M355_COMPUTE_F32X3: the weight gradient on the split kernels too (conv3_bww_x3_kernel; M355_F32X3=2 forces every
+// fp32 layer there, M355_F32X3_BWW=0 keeps the weight gradient on the fp32 MFMA kernels)
+static bool bww_x3(const m355_conv3d_desc* d) {
+  const bool mode = d->compute == M355_COMPUTE_F32X3 || (d->compute == M355_COMPUTE_F32 && tuning().f32x3 == 2);
+  return mode && tuning().f32x3 && tuning().f32x3_bww && is_k3s1p1(d) && d->Cin > 4 && d->Cout > 4 &&
+         (int64_t)d->D * d->H * d->W < (1ll << 24);
+}
+
 extern "C" size_t m355_conv3d_bwd_weight_workspace(const m355_conv3d_desc* d) {
   if (!d) return 0;
   const int OD = out_dim(d->D, d->k, d->stride, d->pad), OH = out_dim(d->H, d->k, d->stride, d->pad),
             OW = out_dim(d->W, d->k, d->stride, d->pad);
   const size_t db = dbias_ws_bytes(d->Cout, (int64_t)OD * OH * OW);
   if (!is_k3s1p1(d)) return db;
+  if (bww_x3(d)) return plan_bww_x3(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes + db;
   const size_t f32 = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes + db;
   if (bww_plain_h16(d)) {   // 16-bit operand mode: both operands are rounded into c8 copies behind the c8 kernel's own workspace
     const int64_t S = (int64_t)d->D * d->H * d->W;
@@ -2921,8 +2930,23 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
             OW = out_dim(d->W, d->k, d->stride, d->pad);
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  if (is_k3s1p1(d)) {
+  size_t slab_used = 0;   // the bias gradient's scratch follows the slabs
+  if (bww_x3(d)) {
+    const BwwX3Plan p = plan_bww_x3(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+    M355_REQUIRE(workspace && workspace_bytes >= p.slab_bytes, M355_EWORKSPACE,
+                 "conv3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes, p.slab_bytes);
+    M355_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 3) == 0, M355_EINVALID_ARG, "conv3d_bwd_weight: misaligned tensor");
+    float* slab = (float*)workspace;
+    if (int rc = launch_bww_x3(p, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, st)) return rc;
+    BwwClasses kred{};
+    kred.of = p.otiles;
+    kred.cf = p.ctiles;
+    for (int c = 0; c < 4; ++c) kred.ns[c] = p.nsplit;
+    launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, p.ctiles, kred, 1.f, st);
+    slab_used = p.slab_bytes;
+  } else if (is_k3s1p1(d)) {
     const BwwPlan p = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+    slab_used = p.slab_bytes;
     M355_REQUIRE(workspace_bytes >= p.slab_bytes, M355_EWORKSPACE,
                  "conv3d_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                  p.slab_bytes);
@@ -3019,7 +3043,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
   }
   if (dbias) {
     const int64_t OS = (int64_t)OD * OH * OW;
-    const size_t slab_b = is_k3s1p1(d) ? plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W).slab_bytes : 0;
+    const size_t slab_b = slab_used;
     M355_REQUIRE(workspace && workspace_bytes >= slab_b + dbias_ws_bytes(d->Cout, OS), M355_EWORKSPACE,
                  "conv3d_bwd_weight: workspace too small for the bias gradient");
     launch_dbias(dy, dbias, d->N, d->Cout, OS, ybs, (char*)workspace + slab_b, st);

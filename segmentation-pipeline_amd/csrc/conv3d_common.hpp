@@ -154,6 +154,14 @@ void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, i
 int launch_x3_conv(const FwdPlan& p, const float* in, const void* wp, const float* bias, const float* add, float* out,
                    float* slab, int N, int kin, int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, hipStream_t st,
                    float* stat);
+// ... and its weight gradient (conv3_bww_x3_kernel): slab[nsplit][27][Cout][Cin] partials, reduced by the caller
+struct BwwX3Plan {
+  int tx, ty_tiles, tx_tiles, ctiles, otiles, nsplit;
+  size_t slab_bytes;
+};
+BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W);
+int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
+                  int W, int64_t xbs, int64_t ybs, hipStream_t st);
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32);
 
 // 16-bit operand convolution (conv3d_h16.hip).  in16: c8 layout (h16.hpp) with `in16_bs` ELEMENTS between

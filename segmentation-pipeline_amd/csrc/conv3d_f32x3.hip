@@ -304,4 +304,324 @@ int launch_x3_conv(const FwdPlan& p, const float* in, const void* wp, const floa
   return M355_EUNSUPPORTED;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[o, c, tap] = sum_v dy[o, v] * x[c, v + off(tap)] on the same three-way split (nn.Conv3d's weight gradient,
+// /root/reference/segmentation_pipeline/models/components.py:48-56 under autograd).  MFMA view as in conv3_bww_c8_kernel
+// (conv3d_h16.hip): rows = 32 output channels (A = dy), columns = 32 input channels (B = x), K = 16 x-adjacent voxels;
+// each wave owns 7 of the 27 taps.  Both operands are activations, so both are split while they are staged: fp32 NCDHW
+// -> registers (coalesced dwords along x, zero padding by the buffer descriptor) -> hi / mid / lo -> three voxel-major
+// LDS planes [voxel][32 channels] (64-byte rows).  The fragments come out of ds_read_b64_tr_b16 (k = 8 voxels of one
+// channel per lane); the three dy planes of a k-step are read once for the wave's 7 taps, the three x planes once per
+// tap, and feed six MFMAs: 0.57 fragment reads per MFMA where the 16-bit kernel needs 1.14.
+// Tile = ONE z plane of TY x TX = 64 voxels (4 k-steps).  A workgroup walks its tiles along z; the x halo planes sit in
+// a RING of four slots (plane p in slot (p + 1) & 3): tile z reads planes z - 1 .. z + 1 while plane z + 2 -- fetched
+// into registers before the MFMAs of tile z -- is split and committed to the fourth slot, so a tile costs ONE barrier and
+// one new halo plane ((TY + 2) x (TX + 2) voxels x 32 channels) + its dy tile (double-buffered) in global loads.
+// LDS: 4 x 3 x HP x 64 B + 2 x 3 x 4 KB = 126 KB at TX = 32: one workgroup per CU, latency is hidden by the software
+// pipeline (fragments of the next tap are requested between the MFMAs of this one), not by a second workgroup.
+typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
+typedef short x3_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 x3_tr_frag(const unsigned char* p) {   // two transposed 4-voxel blocks -> 8 k-values
+  typedef __attribute__((address_space(3))) x3_s16x4 lds_s16x4;
+  const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 256));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TX>
+__global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int Cin, int Cout, int D,
+    int H, int W, int ty_tiles, int tx_tiles, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs) {
+  constexpr int TY = 64 / TX, HR = TX + 2, HP = (TY + 2) * HR;   // tile rows; halo row / plane in voxels
+  constexpr int XI = HP * 4, XPER = (XI + 255) / 256;            // 8-channel items of a halo plane, per thread
+  constexpr int PLANE_B = HP * 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;
+  constexpr int KH = TX >= 16 ? 8 : HR;                          // voxels 8..15 of a k-step: 8 columns on, or the next row
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(4 * SLOT_B + 2 * DBUF_B <= 160 * 1024 && 2 * PLANE_B + 8 * HR * 64 + 512 < 65536, "LDS size / read offsets");
+  __shared__ __attribute__((aligned(16))) unsigned char xs[4 * SLOT_B];   // [slot][split plane][halo voxel][32 channels]
+  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * DBUF_B];   // [buffer][split plane][voxel][32 channels]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  int vid;  // XCD-aware placement, (c-tile, o-tile) pair fastest: see conv3_mfma_bww2_kernel
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pairs = ctiles * otiles;
+  const int pair = vid % pairs, split = vid / pairs;
+  const int ctile = pair % ctiles, otile = pair / ctiles;
+  const int iHW = H * W, S = D * iHW;
+  const unsigned cstride = (unsigned)S * 4u;   // S < 2^24 (host check): 32 channels stay below 2^31 bytes
+
+  // thread-invariant part of the staging: item e of a halo plane = (8-channel block e / HP, halo voxel e % HP)
+  int xrel[XPER], xdst[XPER];
+  unsigned xcode[XPER];
+#pragma unroll
+  for (int k = 0; k < XPER; ++k) {
+    const int e = tid + 256 * k;
+    const int cbl = e / HP, hv = e - cbl * HP;
+    const int yy = hv / HR, xx = hv - yy * HR;
+    xrel[k] = cbl * 8 * S + yy * W + xx;
+    xdst[k] = hv * 64 + cbl * 16;
+    xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
+  }
+  const int dv = tid & 63, dcb = tid >> 6;            // dy item: (voxel of the tile, 8-channel block)
+  const int dvy = dv / TX, dvx = dv - dvy * TX;
+  const int ddst = dv * 64 + dcb * 16;
+
+  // tiles: z fastest inside a (sample, y tile, x tile) column; split s owns a contiguous range
+  const int ntiles = N * ty_tiles * tx_tiles * D;
+  const int per = ntiles / nsplit, rem = ntiles - per * nsplit;
+  const int t_begin = split * per + min(split, rem), t_end = t_begin + per + (split < rem ? 1 : 0);
+
+  // staging state of the column that is fetched from
+  __amdgpu_buffer_rsrc_t rx, rd;
+  unsigned ymask = 0u;
+  int colbase = 0, xlim = 0, dbase = 0;
+  bool dok = false;
+  auto column_setup = [&](int col, bool live) __attribute__((always_inline)) {
+    const int txt = col % tx_tiles;
+    const int c2 = col / tx_tiles;
+    const int tyt = c2 % ty_tiles, n = c2 / ty_tiles;
+    const int y0 = tyt * TY, x0 = txt * TX;
+    const int nbx = min(32, Cin - 32 * ctile), nbd = min(32, Cout - 32 * otile);
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)(32 * ctile) * S), 0,
+                                           live ? nbx * S * 4 : 0, 0x00020000);
+    rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)(32 * otile) * S), 0,
+                                           live ? nbd * S * 4 : 0, 0x00020000);
+    ymask = 0u;
+    for (int yy = 0; yy < TY + 2; ++yy)
+      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ymask |= 1u << yy;
+    colbase = (y0 - 1) * W + x0 - 1;
+    xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
+    const int gy = y0 + dvy, gx = x0 + dvx;
+    dok = (gy < H) & (gx < W);
+    dbase = dcb * 8 * S + gy * W + gx;
+  };
+  auto fetch_plane = [&](float (&r)[XPER][8], int p, bool on) __attribute__((always_inline)) {   // halo plane p (absolute z, may lie outside) of the column
+    const bool pv = on && p >= 0 && p < D;
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+      const int xx = (int)(xcode[k] >> 16);
+      const bool ok = pv & (((xcode[k] & 0xffffu) & ~ymask) == 0u) & ((unsigned)(xlim + xx) < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(colbase + p * iHW + xrel[k]) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        r[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + j * cstride, 0, 0));
+    }
+  };
+  auto fetch_dy = [&](float (&r)[8], int z, bool on) __attribute__((always_inline)) {
+    const unsigned off = (on & dok) ? (unsigned)(dbase + z * iHW) * 4u : OOB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
+  };
+  auto commit8 = [&](const float (&v)[8], unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {   // split + three 16-byte items
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x3_split(v[c], h[c], m[c], l[c]);
+    *(u32x4*)(dst) = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+    *(u32x4*)(dst + plane_bytes) = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+    *(u32x4*)(dst + 2 * plane_bytes) = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+  };
+  auto commit_plane = [&](const float (&r)[XPER][8], int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < XPER; ++k)
+      if (tid + 256 * k < XI) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
+  };
+  auto commit_dy = [&](const float (&r)[8], int buf) __attribute__((always_inline)) { commit8(r, ds + buf * DBUF_B + ddst, 4096); };
+  // start of a column / of this split's range: the three planes of tile z, loaded here and now (once per D tiles)
+  auto cold = [&](int z) __attribute__((always_inline)) {
+    float r0[XPER][8], r1[XPER][8], r2[XPER][8];
+    fetch_plane(r0, z - 1, true);
+    fetch_plane(r1, z, true);
+    fetch_plane(r2, z + 1, true);
+    commit_plane(r0, z & 3);
+    commit_plane(r1, (z + 1) & 3);
+    commit_plane(r2, (z + 2) & 3);
+  };
+
+  // transposed-read lane bases: lane 4q + p of a 16-lane group addresses voxel row q, channels 4p .. 4p+3 of its
+  // group's 16-channel half; groups 2, 3 (the upper MFMA half) take the voxels 8 .. 15 of the k-step
+  const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int lbA = (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
+  const int lbB = (KH * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
+  int tdz[7], tyx[7];   // this wave's taps: plane offset dz, byte offset of (dy, dx) inside a plane
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(wave * 7 + t, 26);
+    tdz[t] = tap / 9;
+    tyx[t] = (((tap / 3) % 3) * HR + tap % 3) * 64 + lbB;
+  }
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int z = 0, col = 0;
+  if (t_begin < t_end) {
+    col = t_begin / D;
+    z = t_begin - col * D;
+    column_setup(col, true);
+    cold(z);
+    float d0[8];
+    fetch_dy(d0, z, true);
+    commit_dy(d0, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    // fragment bases of THIS tile: tap plane dz -> ring slot (z + dz) & 3
+    const unsigned char* xt[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) xt[t] = xs + tyx[t] + ((z + tdz[t]) & 3) * SLOT_B;
+    const unsigned char* da = ds + buf * DBUF_B + lbA;
+    const bool more = tile + 1 < t_end;
+    const bool newcol = z + 1 == D;
+    const int zn = newcol ? 0 : z + 1;
+    col += newcol ? 1 : 0;
+    column_setup(col, more);   // every tile (uniform scalar work): keeps the descriptors in scalar registers
+    float xr[XPER][8], dr[8];
+    fetch_plane(xr, zn + 1, more && !newcol);   // (a new column's planes are loaded after the barrier)
+    fetch_dy(dr, zn, more);
+    // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
+    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one
+    {
+      auto afrag = [&](int g, int pl) { return x3_tr_frag(da + pl * 4096 + g * 1024); };
+      auto bfrag = [&](int g, int t, int pl) {
+        const int goff = (TX == 32 ? (g >> 1) * HR + 16 * (g & 1) : (TX == 16 ? g * HR : 2 * g * HR)) * 64;
+        return x3_tr_frag(xt[t] + pl * PLANE_B + goff);
+      };
+      bf16x8 aq[2][3], bq[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) aq[0][pl] = afrag(0, pl);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bq[0][pl] = bfrag(0, 0, pl);
+#pragma unroll
+      for (int s = 0; s < 28; ++s) {
+        const int g = s / 7, t = s % 7;
+        const bool nb = s + 1 < 28, na = t == 0 && g + 1 < 4;
+        if (nb) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bq[(s + 1) & 1][pl] = bfrag((s + 1) / 7, (s + 1) % 7, pl);
+        }
+        if (na) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) aq[(g + 1) & 1][pl] = afrag(g + 1, pl);
+        }
+        const bf16x8 ah = aq[g & 1][0], am = aq[g & 1][1], al = aq[g & 1][2];
+        const bf16x8 bh = bq[s & 1][0], bm = bq[s & 1][1], bl = bq[s & 1][2];
+        // (the planes in the order their reads were issued; the small terms of a product group first)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        if (nb) {   // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+            if (na) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // fragment reads of the next step
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) {
+      if (!newcol) commit_plane(xr, (zn + 2) & 3);
+      commit_dy(dr, buf ^ 1);
+    }
+    __syncthreads();   // every wave is done reading this tile; the next one is in LDS
+    if (more && newcol) {   // (uniform)
+      cold(0);
+      __syncthreads();
+    }
+    z = zn;
+    buf ^= 1;
+  }
+
+  // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
+  const int c = ctile * 32 + l32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave * 7 + t;
+    if (tap < 27 && c < Cin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = otile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+      }
+    }
+  }
+}
+
+// tile width: the padded volume decides (ties: the wider tile, whose rows coalesce better)
+static int bww_x3_tx(int H, int W) {
+  int best = 32;
+  int64_t best_v = -1;
+  for (int tx : {32, 16, 8}) {
+    const int ty = 64 / tx;
+    const int64_t v = round_up(W, tx) * round_up(H, ty);
+    if (best_v < 0 || v < best_v) best = tx, best_v = v;
+  }
+  return best;
+}
+
+BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W) {
+  BwwX3Plan p{};
+  p.tx = bww_x3_tx(H, W);
+  p.ty_tiles = (int)ceil_div(H, 64 / p.tx);
+  p.tx_tiles = (int)ceil_div(W, p.tx);
+  p.ctiles = (int)ceil_div(Cin, 32);
+  p.otiles = (int)ceil_div(Cout, 32);
+  const int64_t ntiles = (int64_t)N * p.ty_tiles * p.tx_tiles * D, pairs = (int64_t)p.ctiles * p.otiles;
+  const int cus = num_cus();
+  // one workgroup per CU: time ~ residencies x (tiles per split x ~4 us + ~10 us of cold start and slab write) + the
+  // slab traffic (written here, read by the reduction)
+  const double slab_us = 2.0 * (double)Cout * Cin * 27 * 4 / 4.0e6;   // per split
+  int64_t cand[32];
+  int nc = 0;
+  for (int64_t ns = 1; ns < ntiles && nc < 20; ns *= 2) cand[nc++] = ns;
+  for (int r = 1; r <= 6; ++r) cand[nc++] = std::max<int64_t>(1, (int64_t)cus * r / pairs);
+  cand[nc++] = std::max<int64_t>(1, ntiles);
+  std::sort(cand, cand + nc);
+  double best = 1e30;
+  int64_t nsplit = 1;
+  for (int i = 0; i < nc; ++i) {
+    const int64_t ns = std::min<int64_t>(cand[i], std::max<int64_t>(1, ntiles));
+    if (ns * Cout * Cin * 27 * 4 > (256ll << 20) && ns > 1) continue;
+    const double rounds = (double)ceil_div(pairs * ns, cus);
+    const double cost = rounds * ((double)ceil_div(ntiles, ns) * 4.0 + 10.0) + (double)ns * slab_us;
+    if (cost < best * 0.97) {
+      best = cost;
+      nsplit = ns;
+    }
+  }
+  if (const int force = tuning().bww_nsplit) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
+  p.nsplit = (int)nsplit;
+  p.slab_bytes = (size_t)round_up(nsplit * Cout * Cin * 27 * 4, 256);
+  return p;
+}
+
+int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
+                  int W, int64_t xbs, int64_t ybs, hipStream_t st) {
+  const dim3 grid((unsigned)(p.ctiles * p.otiles * p.nsplit));
+#define M355_X3_BWW(TXV)                                                                                              \
+  hipLaunchKernelGGL((conv3_bww_x3_kernel<TXV>), grid, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, p.ty_tiles, \
+                     p.tx_tiles, p.nsplit, p.ctiles, p.otiles, xbs, ybs);
+  if (p.tx == 32) { M355_X3_BWW(32) } else if (p.tx == 16) { M355_X3_BWW(16) } else { M355_X3_BWW(8) }
+#undef M355_X3_BWW
+  return M355_OK;
+}
+
 }  // namespace m355
