@@ -31,13 +31,15 @@ sys.path.insert(0, ROOT)
 
 METRIC = "3D patches/sec (128³, 4ch) train+infer at 1/2/4/8 MI355X; Dice vs CPU ref"
 # MI355X_MICROARCH.md: dense MFMA peaks (fp32: v_mfma_f32_32x32x2_f32; bf16 / fp16: v_mfma_f32_32x32x16_*), HBM3E
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0, "fp32x3": 157.3}
-# "fp32x3": conv3_f32x3_kernel executes 6 bf16 MFMAs per 16 products (3-way operand split) over 14 tap pairs for 27 taps
-X3_KERNEL, X3_MFMA_FLOPS_PER_FLOP = "conv3_f32x3_kernel", 6.0 * 28.0 / 27.0
+PEAK_TFLOPS = {"fp32": 157.3, "fp32_mfma": 157.3, "bf16": 2500.0, "fp16": 2500.0}
+# precision "fp32": the split kernels execute six bf16 MFMAs per fp32 product group (exact 3-way operand split) and 28
+# tap slots for the 27 taps (forward / data gradient: 14 tap pairs; weight gradient: 7 taps on each of 4 waves)
+X3_KERNELS, X3_MFMA_FLOPS_PER_FLOP = ("conv3_f32x3_kernel", "conv3_bww_x3_kernel"), 6.0 * 28.0 / 27.0
 HBM_PEAK_GBS = 8000.0
 # m355_conv3d_plan(): kernel family -> kernel name
 PLAN_KERNEL = {1: "conv3_mfma_fwd_kernel", 3: "conv3_mfma_fwd_p_kernel", 2: "conv3_valu_smallcout_kernel",
-               4: "conv3_h16_kernel", 5: "conv3_h16_kernel(8 waves)", 6: "conv3_h16_kernel(one-shot)", 7: X3_KERNEL,
+               4: "conv3_h16_kernel", 5: "conv3_h16_kernel(8 waves)", 6: "conv3_h16_kernel(one-shot)", 7: "conv3_f32x3_kernel",
+               8: "conv3_bww_x3_kernel", 9: "conv3_mfma_bww2_kernel", 10: "conv3_mfma_bww_small_kernel", 11: "conv3_bww_c8_kernel",
                0: "conv3d_direct_kernel"}
 WORKLOADS = {
     # name: (in_ch, out_ch, filters, depth, patch)
@@ -119,8 +121,10 @@ def kernel_groups(prof, precision):
     """ops.CONV_PROFILE entries grouped by (kernel name, tile variant) -> [flops, bytes, ms, launches, {(tag, plan)}]"""
     groups = {}
     for (tag, flops, e0, e1, plan, nbytes) in prof:
-        if tag == "conv3d_bwd_weight":
-            key = ("conv3_mfma_bww2_kernel" if precision in ("fp32", "fp32x3") else "conv3_bww_c8_kernel", "")
+        if tag == "conv3d_bwd_weight" and plan is not None and plan[0]:   # fp32-tensor entry point (m355_conv3d_plan which = 2)
+            key = (PLAN_KERNEL.get(plan[0], "conv3d_bwd_weight"), f"<{plan[2]}>")
+        elif tag == "conv3d_bwd_weight":                                   # the c8 entry points of the 16-bit training flow
+            key = ("conv3_bww_c8_kernel", "")
         elif plan is None:
             continue
         else:
@@ -175,16 +179,17 @@ def roofline_of(prof, precision, full_prof=None, traffic=True):
     share = (fg[key][2] if key in fg else ms) / sum(g[2] for g in fg.values())
     peak_tf = PEAK_TFLOPS[precision]
     alg_flops = flops
-    if key[0] == X3_KERNEL:   # what the matrix core executes, against the peak of the instruction it executes
+    if key[0] in X3_KERNELS:   # what the matrix core executes, against the peak of the instruction it executes
         flops, peak_tf = flops * X3_MFMA_FLOPS_PER_FLOP, PEAK_TFLOPS["bf16"]
     t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
     kname = key[0] + key[1]
     if t_mfma >= t_hbm:
         ach = flops / (ms * 1e-3) / 1e12
         out = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
-        if key[0] == X3_KERNEL:
+        if key[0] in X3_KERNELS:
             out.update({"algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12, "mfma_flops_per_algorithmic_flop": X3_MFMA_FLOPS_PER_FLOP,
-                        "note": "achieved / peak: bf16 MFMA flops executed (six plane products per fp32 product, 14 tap pairs "
+                        "fp32_mfma_peak_tflops": PEAK_TFLOPS["fp32_mfma"],
+                        "note": "achieved / peak: bf16 MFMA flops EXECUTED (six plane products per fp32 product, 28 tap slots "
                                 "for 27 taps) against the dense bf16 peak; algorithmic_tflops: 2*27*Cin*Cout*voxels / time"})
     else:
         ach = nbytes / (ms * 1e-3) / 1e9
@@ -292,15 +297,16 @@ def parse_args(argv=None):
                     help="cfg2: the headline (fp32 train step + inference forward); cfg3 = cfg2 with --precision bf16; "
                          "cfg4: sliding-window inference of a 4x256^3 volume (patch 160, overlap 20), tiles sharded over the ranks")
     ap.add_argument("--batch", type=int, default=1, help="patches per rank per step")
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16", "fp32x3"],
-                    help="arithmetic of the 3x3x3 convolutions (default: exact fp32, the BASELINE cfg2 mode; bf16 / fp16: "
-                         "16-bit operands, fp32 accumulate -- BASELINE cfg3 / cfg5; fp32x3: fp32 tensors and fp32 accuracy, "
-                         "every product as six bf16 MFMAs on an exact 3-way operand split)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp32_mfma", "bf16", "fp16"],
+                    help="arithmetic of the 3x3x3 convolutions (default fp32, the BASELINE cfg2 mode: fp32 tensors and fp32 "
+                         "accuracy, the products of the wide layers as six bf16 MFMAs on an exact 3-way operand split; "
+                         "fp32_mfma: every product on the fp32 MFMA; bf16 / fp16: 16-bit operands, fp32 accumulate -- "
+                         "BASELINE cfg3 / cfg5)")
     ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire type of the gradient all-reduce buckets (bf16 halves the RCCL volume; fp32 master gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
-    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra bf16 (BASELINE cfg3) and fp32x3 measurements of the cfg2 / fp32 line")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra bf16 (BASELINE cfg3) and fp32_mfma measurements of the cfg2 / fp32 line")
     ap.add_argument("--launch-probe", default=None, help=argparse.SUPPRESS)   # tests: each rank writes its env here and exits
     args = ap.parse_args(argv)
     if args.workload == "cfg3":
@@ -354,14 +360,14 @@ def main():
             torch.cuda.empty_cache()
             c3 = run_train(args, rank, world, device, force_ddp, precision="bf16")
             sp.set_precision(args.precision)
-            # the same fp32 workload with the convolution products on the bf16 matrix pipe (exact 3-way operand split)
+            # the same fp32 workload with every convolution product on the fp32 MFMA (the arithmetic of rounds 1-3)
             torch.cuda.empty_cache()
-            x3 = run_train(args, rank, world, device, force_ddp, precision="fp32x3")
+            mf = run_train(args, rank, world, device, force_ddp, precision="fp32_mfma")
             sp.set_precision(args.precision)
             if rank == 0:
                 out["cfg3"] = c3
-                out["f32x3"] = x3
-                x3["max_abs_diff_of_step0_probabilities_vs_fp32"] = float((x3.pop("_p0") - out.pop("_p0")).abs().max())
+                out["fp32_mfma"] = mf
+                mf["max_abs_diff_of_step0_probabilities_vs_headline"] = float((mf.pop("_p0") - out.pop("_p0")).abs().max())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -391,10 +397,14 @@ def max_over_ranks(seconds, device):
 
 
 def dtype_label(precision):
-    if precision == "fp32x3":
-        return ("f32 tensors; 3x3x3 conv fwd / bwd-data products as six bf16 MFMAs on an exact three-way bf16 split of both fp32 "
-                "operands, f32 accumulate (error vs fp64 = the fp32 MFMA kernels'); f32 elsewhere")
-    return "f32" if precision == "fp32" else f"{precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere"
+    from segmentation_pipeline_amd import ops
+    if precision == "fp32" and ops.FP32_SPLIT:
+        return ("f32 (tensors, results and accumulation; the products of the 3x3x3 convolutions with >= 8 input channels run as "
+                "six bf16 MFMAs on an EXACT three-way bf16 split of both f32 operands -- error vs f64 equal to the f32 MFMA "
+                "kernels', profiles/r04_f32x3_accuracy.txt; the same step on v_mfma_f32_32x32x2_f32 is the \"fp32_mfma\" key)")
+    if precision in ("fp32", "fp32_mfma"):
+        return "f32"
+    return f"{precision} operands / f32 accumulate (3x3x3 convs), f32 elsewhere"
 
 
 def run_train(args, rank, world, device, force_ddp, precision=None):
@@ -521,9 +531,9 @@ def run_train(args, rank, world, device, force_ddp, precision=None):
                 "conv_kernels": conv_summary_of(prof_w, 1) if prof_w else None,
                 "final_loss": float(loss_dict["loss"].detach()),
                 "gpu_soft_dice_loss_step0": gpu_dice0, "gpu_hard_dice_step0": hard0,
-                **({"_p0": p0} if precision == "fp32x3" else {}),
-                "workload": ("the cfg2 workload itself (fp32 tensors, fp32 accuracy) with the convolution products on the bf16 "
-                             "matrix pipe, timed by this same command after the fp32 region" if precision == "fp32x3" else
+                **({"_p0": p0} if precision == "fp32_mfma" else {}),
+                "workload": ("the cfg2 workload itself with every convolution product on the fp32 MFMA (v_mfma_f32_32x32x2_f32), "
+                             "timed by this same command after the headline region" if precision == "fp32_mfma" else
                              "BASELINE cfg3 on this rank count: the cfg2 network and patch with bf16 conv operands "
                              "(fp32 accumulate), timed by this same command after the fp32 region")}
     # per-op summary: of the fully profiled warm-up step when there was one, else of the timed region
@@ -546,7 +556,7 @@ def run_train(args, rank, world, device, force_ddp, precision=None):
         "dice": {"gpu_soft_dice_loss_step0": gpu_dice0, "gpu_hard_dice_step0": hard0},
     }
     if args.workload == "cfg2" and precision == "fp32" and not args.no_cfg3:
-        out["_p0"] = p0   # compared with the fp32x3 leg's first forward (main)
+        out["_p0"] = p0   # compared with the fp32_mfma leg's first forward (main)
 
     def cpu_leg(out):
         cb = cpu_baseline(cfg, args.batch)

@@ -2825,10 +2825,23 @@ extern "C" int m355_conv3d_bwd_weight_c8(const m355_conv3d_desc* d, const void* 
   return check_launch("conv3d_bwd_weight_c8");
 }
 
+static bool bww_plain_h16(const m355_conv3d_desc* d);
+static bool bww_x3(const m355_conv3d_desc* d);
 extern "C" int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4) {
   M355_REQUIRE(d && out4, M355_EINVALID_ARG, "conv3d_plan: null pointer");
   out4[0] = out4[1] = out4[2] = out4[3] = 0;
   if (!is_k3s1p1(d)) return M355_OK;
+  if (which == 2) {   // weight gradient of the plain entry point: 8 = conv3_bww_x3_kernel, 9 = conv3_mfma_bww2(c)_kernel,
+                      // 10 = conv3_mfma_bww_small_kernel, 11 = the c8 kernel behind an operand pack (16-bit modes)
+    if (bww_x3(d)) {
+      const BwwX3Plan p = plan_bww_x3(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+      out4[0] = 8; out4[2] = p.tx; out4[3] = p.nsplit;
+    } else {
+      const BwwPlan p = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W);
+      out4[0] = bww_plain_h16(d) ? 11 : (small_bww(d) ? 10 : 9); out4[2] = p.gx; out4[3] = p.nsplit;
+    }
+    return M355_OK;
+  }
   if (which == 0 && small_cout_fwd(d)) { out4[0] = 2; return M355_OK; }  // z-Toeplitz small-Cout kernel
   const FwdPlan p = which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);

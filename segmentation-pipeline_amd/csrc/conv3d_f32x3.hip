@@ -39,7 +39,8 @@ __host__ __device__ constexpr int x3_pair_tap(int pair, int half) {
 }
 
 // x = hi + mid + lo, the three as the HIGH halves of the returned words (lo: the word of the exact remainder, whose low
-// half is zero).  Inf / NaN stay in the hi plane only (Inf - Inf would put a NaN next to an Inf).
+// half is zero).  Inf / NaN stay in the hi plane only (Inf - Inf would put a NaN next to an Inf); the outputs such an
+// operand touches come out non-finite (Inf, or NaN where it meets a zero plane of the other operand), as they must.
 __device__ __forceinline__ void x3_split(float v, unsigned& hi, unsigned& mid, unsigned& lo) {
   const unsigned u = __float_as_uint(v);
   hi = u & 0xffff0000u;
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
     int H, int W, int ty_tiles, int tx_tiles, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs) {
   constexpr int TY = 64 / TX, HR = TX + 2, HP = (TY + 2) * HR;   // tile rows; halo row / plane in voxels
   constexpr int XI = HP * 4, XPER = (XI + 255) / 256;            // 8-channel items of a halo plane, per thread
-  constexpr int PLANE_B = HP * 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;
+  constexpr int PLANE_B = HP * 64 + 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;   // + one pad row: where threads without an item write
+  constexpr int NU = 2 * (XPER + 1);                             // commit units (4 channels of an item) per tile
   constexpr int KH = TX >= 16 ? 8 : HR;                          // voxels 8..15 of a k-step: 8 columns on, or the next row
   constexpr unsigned OOB = 0x80000000u;
   static_assert(4 * SLOT_B + 2 * DBUF_B <= 160 * 1024 && 2 * PLANE_B + 8 * HR * 64 + 512 < 65536, "LDS size / read offsets");
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
     const int cbl = e / HP, hv = e - cbl * HP;
     const int yy = hv / HR, xx = hv - yy * HR;
     xrel[k] = cbl * 8 * S + yy * W + xx;
-    xdst[k] = hv * 64 + cbl * 16;
+    xdst[k] = e < XI ? hv * 64 + cbl * 16 : HP * 64 + (tid & 3) * 16;
     xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
   }
   const int dv = tid & 63, dcb = tid >> 6;            // dy item: (voxel of the tile, 8-channel block)
@@ -383,16 +385,16 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
   unsigned ymask = 0u;
   int colbase = 0, xlim = 0, dbase = 0;
   bool dok = false;
-  auto column_setup = [&](int col, bool live) __attribute__((always_inline)) {
+  auto column_setup = [&](int col) __attribute__((always_inline)) {
     const int txt = col % tx_tiles;
     const int c2 = col / tx_tiles;
     const int tyt = c2 % ty_tiles, n = c2 / ty_tiles;
     const int y0 = tyt * TY, x0 = txt * TX;
     const int nbx = min(32, Cin - 32 * ctile), nbd = min(32, Cout - 32 * otile);
     rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)(32 * ctile) * S), 0,
-                                           live ? nbx * S * 4 : 0, 0x00020000);
+                                           nbx * S * 4, 0x00020000);
     rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)(32 * otile) * S), 0,
-                                           live ? nbd * S * 4 : 0, 0x00020000);
+                                           nbd * S * 4, 0x00020000);
     ymask = 0u;
     for (int yy = 0; yy < TY + 2; ++yy)
       if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ymask |= 1u << yy;
@@ -430,8 +432,17 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
   };
   auto commit_plane = [&](const float (&r)[XPER][8], int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < XPER; ++k)
-      if (tid + 256 * k < XI) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
+    for (int k = 0; k < XPER; ++k) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
+  };
+  // half an item (channels 4 hf .. 4 hf + 3): the unit the steady-state commit is cut into
+  auto commit4 = [&](const float (&v)[8], int hf, unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x3_split(v[4 * hf + c], h[c], m[c], l[c]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *(u32x2*)(dst + 8 * hf) = (u32x2){x3_pack(h[0], h[1]), x3_pack(h[2], h[3])};
+    *(u32x2*)(dst + plane_bytes + 8 * hf) = (u32x2){x3_pack(m[0], m[1]), x3_pack(m[2], m[3])};
+    *(u32x2*)(dst + 2 * plane_bytes + 8 * hf) = (u32x2){x3_pack(l[0], l[1]), x3_pack(l[2], l[3])};
   };
   auto commit_dy = [&](const float (&r)[8], int buf) __attribute__((always_inline)) { commit8(r, ds + buf * DBUF_B + ddst, 4096); };
   // start of a column / of this split's range: the three planes of tile z, loaded here and now (once per D tiles)
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
   if (t_begin < t_end) {
     col = t_begin / D;
     z = t_begin - col * D;
-    column_setup(col, true);
+    column_setup(col);
     cold(z);
     float d0[8];
     fetch_dy(d0, z, true);
@@ -485,16 +496,23 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
     const bool more = tile + 1 < t_end;
     const bool newcol = z + 1 == D;
     const int zn = newcol ? 0 : z + 1;
-    col += newcol ? 1 : 0;
-    column_setup(col, more);   // every tile (uniform scalar work): keeps the descriptors in scalar registers
+    if (newcol && more) {   // (uniform; once per D tiles: the divisions of the setup stay out of the steady state)
+      col += 1;
+      column_setup(col);
+    }
     float xr[XPER][8], dr[8];
     fetch_plane(xr, zn + 1, more && !newcol);   // (a new column's planes are loaded after the barrier)
     fetch_dy(dr, zn, more);
     // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
-    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one
+    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one.  The LAST NU
+    // steps also carry the commit of the prefetched plane / dy tile, one unit (4 channels of an item: ~30 vector-ALU
+    // ops + 3 LDS writes) per step in the shadow of its MFMAs; it is unconditional -- after the last tile and before
+    // a new column the registers hold zeros and the slot they go to is rewritten before its next use.
     {
-      auto afrag = [&](int g, int pl) { return x3_tr_frag(da + pl * 4096 + g * 1024); };
-      auto bfrag = [&](int g, int t, int pl) {
+      unsigned char* xw = xs + ((z + 3) & 3) * SLOT_B;   // the slot no tap of tile z reads (plane z + 2 of this column)
+      unsigned char* dw_ = ds + (buf ^ 1) * DBUF_B + ddst;
+      auto afrag = [&](int g, int pl) __attribute__((always_inline)) { return x3_tr_frag(da + pl * 4096 + g * 1024); };
+      auto bfrag = [&](int g, int t, int pl) __attribute__((always_inline)) {
         const int goff = (TX == 32 ? (g >> 1) * HR + 16 * (g & 1) : (TX == 16 ? g * HR : 2 * g * HR)) * 64;
         return x3_tr_frag(xt[t] + pl * PLANE_B + goff);
       };
@@ -524,21 +542,24 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-        if (nb) {   // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
+        const int u = s - (28 - NU);   // commit unit of this step
+        if (u >= 0) {
+          if (u < 2 * XPER) commit4(xr[u >> 1], u & 1, xw + xdst[u >> 1], PLANE_B);
+          else commit4(dr, u & 1, dw_, 4096);
+        }
+        // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
-            if (na) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // fragment reads of the next step
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+          if (nb && i < 3) {
+            if (na) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // fragment reads of the next step
             else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // vector ALU of the commit unit
         }
+        if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);       // its LDS writes
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    if (more) {
-      if (!newcol) commit_plane(xr, (zn + 2) & 3);
-      commit_dy(dr, buf ^ 1);
     }
     __syncthreads();   // every wave is done reading this tile; the next one is in LDS
     if (more && newcol) {   // (uniform)

@@ -349,7 +349,7 @@ class Block3d(nn.Module):
                 stats = {} if wants_batch_stats(norm) else None
                 c8 = flow if (not last or c8_out) else 0
                 h = run_conv(conv, h, stats=stats, c8_out=bool(c8))   # c8 flow: the pre-norm tensor is c8 as well
-                if (pool and ops.FUSE_POOL and last and add is None and not drop and not c8 and ops.get_precision() in ("fp32", "fp32x3")
+                if (pool and ops.FUSE_POOL and last and add is None and not drop and not c8 and ops.is_fp32()
                         and isinstance(h, torch.Tensor) and all(v % 2 == 0 for v in h.shape[2:])):
                     return run_norm_act(norm, act, h, out=slot, stats=stats, pool=True)   # -> (result, pooled)
                 if (pool and last and add is None and not drop and c8 and torch.is_grad_enabled() and norm is not None

@@ -15,20 +15,27 @@ import torch
 from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 
-# Arithmetic of the 3x3x3 convolutions: "fp32" = exact fp32 MFMA (default, the mode every 1e-4 parity
-# claim refers to), "bf16" / "fp16" = operands rounded to 16 bits, fp32 accumulate (BASELINE cfg3 / cfg5).
-# "fp32x3" = fp32 tensors and fp32 accuracy on the bf16 matrix pipe: every operand split exactly into three bf16
-# values, six plane products per fp32 product, fp32 accumulation (M355_COMPUTE_F32X3, csrc/conv3d_f32x3.hip) -- the
-# same tensors, layouts and flow as "fp32", only the conv kernels differ; results differ from "fp32" by summation-order
-# noise (both sit ~1e-6 of max|y| from an fp64 convolution).
+# Arithmetic of the 3x3x3 convolutions:
+#   "fp32" (default)  fp32 tensors, fp32 results.  The convolutions with >= 8 input and > 4 output channels (forward, data
+#                     and weight gradient) run on the bf16 matrix pipe: every operand is split EXACTLY into three bf16
+#                     values (8 + 8 + 8 significant bits) and six plane products per fp32 product are accumulated in fp32
+#                     (M355_COMPUTE_F32X3, csrc/conv3d_f32x3.hip) -- measured against fp64 as accurate as the fp32 MFMA
+#                     kernels (the error of both is the fp32 accumulation's), 1.3-1.5x their rate; the edge layers run
+#                     the fp32 MFMA / vector-ALU kernels.  Every 1e-4 parity claim refers to this mode.
+#                     M355_FP32_SPLIT=0 in the environment maps "fp32" to "fp32_mfma".
+#   "fp32_mfma"       every convolution on v_mfma_f32_32x32x2_f32 (M355_COMPUTE_F32): the same tensors, layouts and flow,
+#                     only the conv kernels differ; results differ from "fp32" by summation-order noise.
+#   "bf16" / "fp16"   operands rounded to 16 bits, fp32 accumulate (BASELINE cfg3 / cfg5).
 # In the 16-bit modes the forward / data-gradient / weight-gradient kernels of the 3x3x3 stride-1 convolutions with
 # more than 4 channels on both sides read the c8 activation layout (include/m355seg.h; `H16_TRAIN_C8` below); the
 # edge layers go through the fp32-tensor entry points, which round the operands while staging them (Cin <= 4
-# forward) or run the exact fp32 kernels (Cout <= 4 forward, <= 4-channel weight gradients); strided / 1x1x1
+# forward) or take the vector-ALU fp32 path (Cout <= 4).  Normalisation, pooling, conv-transpose, softmax and loss
 # kernels always compute in fp32.
 # Under torch.no_grad() the activations between conv -> norm/act -> conv (-> pool) live ONLY in c8 (`Act16`):
 # no fp32 copy is written or read.
-_COMPUTE = {"fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16, "fp32x3": _lib.COMPUTE_F32X3}
+FP32_SPLIT = os.environ.get("M355_FP32_SPLIT", "1") != "0"
+_COMPUTE = {"fp32": _lib.COMPUTE_F32X3 if FP32_SPLIT else _lib.COMPUTE_F32, "fp32_mfma": _lib.COMPUTE_F32,
+            "bf16": _lib.COMPUTE_BF16, "fp16": _lib.COMPUTE_F16}
 _DT16 = {_lib.COMPUTE_BF16: torch.bfloat16, _lib.COMPUTE_F16: torch.float16}
 _compute_mode = "fp32"
 
@@ -42,6 +49,11 @@ def set_precision(mode: str):
 
 def get_precision() -> str:
     return _compute_mode
+
+
+def is_fp32() -> bool:
+    """fp32 tensors between the layers ("fp32" / "fp32_mfma")"""
+    return _COMPUTE[_compute_mode] not in _DT16
 
 
 class precision:
@@ -1236,7 +1248,7 @@ class _Conv3dFn(torch.autograd.Function):
         if need_w or (need_b and ctx.has_bias):
             dw = torch.empty_like(weight)
             db = torch.empty(d.Cout, dtype=weight.dtype, device=weight.device) if ctx.has_bias else None
-            prof, _ = _prof_gate("conv3d_bwd_weight")
+            prof, bplan = _prof_gate("conv3d_bwd_weight", d if x16 is None else None, 2)
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -1252,7 +1264,7 @@ class _Conv3dFn(torch.autograd.Function):
             if prof is not None:
                 e1.record()
                 vox = dy.shape[2] * dy.shape[3] * dy.shape[4]
-                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * vox, e0, e1, None,
+                prof.append(("conv3d_bwd_weight", 2.0 * d.k ** 3 * d.Cin * d.Cout * d.N * vox, e0, e1, bplan,
                              _conv_bytes(d.N, d.Cin, d.Cout, vox, d.k ** 3, 4, 4)))
         if need_x:
             # gradient w.r.t. the (possibly concatenated) input, dense, then sliced per part

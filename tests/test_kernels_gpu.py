@@ -57,6 +57,99 @@ def test_conv3d_3x3x3_fwd_bwd(hip, oracle, case):
     close(db_h, db_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what="dbias")
 
 
+X3 = 3   # M355_COMPUTE_F32X3: fp32 tensors, the products on the bf16 matrix pipe (exact 3-way split of both operands)
+CONV3_X3 = [
+    # N, Cin, Cout, D, H, W
+    (1, 32, 32, 8, 16, 64),      # forward NTW 4 / GX 32; weight gradient TX 32
+    (2, 8, 40, 9, 7, 33),        # ragged everything, N = 2, channel tiles with empty rows
+    (1, 96, 32, 12, 16, 16),     # GX / TX 16, concat-sized Cin
+    (1, 20, 64, 8, 24, 8),       # GX / TX 8, a chunk with 4 real channels
+    (1, 320, 64, 4, 4, 4),       # deep level: split-K over channel chunks, W < 8
+    (3, 40, 40, 3, 10, 12),      # the reference's widths (msseg2.py:87), D < 4, several columns per split
+    (1, 33, 7, 5, 6, 40),        # Cout < 8
+    (1, 32, 32, 1, 2, 32),       # a single z plane
+    (1, 16, 16, 17, 5, 70),      # three x tiles, ragged rows
+]
+
+
+@pytest.mark.parametrize("case", CONV3_X3)
+def test_conv3d_f32x3_fwd_bwd(hip, oracle, case):
+    """M355_COMPUTE_F32X3 (what precision "fp32" runs on the wide layers): forward (bias + residual), data gradient and
+    weight gradient against the C oracle at the fp32 kernels' tolerances, and -- measured against an fp64 convolution --
+    as accurate as fp32 arithmetic is: max error within 3x of the fp32 MFMA kernels' and below 2e-6 of max |result| (both
+    carry the error of an fp32 accumulation -- stock torch on the CPU sits at 2-6e-7 on these shapes; the dropped plane
+    products are below 2^-24 of each product; the split kernels add six partial products per 16 k-values to the accumulator
+    where the fp32 MFMA adds eight)."""
+    N, Ci, Co, D, H, W = case
+    plan = hip.conv_plan((N, Ci, D, H, W), Co, compute=X3)
+    assert plan[0] == 7, f"expected conv3_f32x3_kernel for {case}, got family {plan}"
+    assert hip.conv_plan((N, Ci, D, H, W), Co, compute=X3, which=2)[0] == 8, "expected conv3_bww_x3_kernel"
+    x, w, b = torch.relu(rnd(N, Ci, D, H, W, seed=1)), rnd(Co, Ci, 3, 3, 3, seed=2) * (1.0 / (27 * Ci) ** 0.5), rnd(Co, seed=3)
+    add, dy = rnd(N, Co, D, H, W, seed=4), rnd(N, Co, D, H, W, seed=5)
+    y3, dx3 = hip.conv3d_fwd(x, w, b, add, compute=X3), hip.conv3d_bwd_data(dy, w, x.shape, compute=X3)
+    dw3, db3 = hip.conv3d_bwd_weight(x, dy, 3, compute=X3)
+    close(y3, oracle.conv3d_fwd(x, w, b, add), what="fwd")
+    close(hip.conv3d_fwd(x, w, compute=X3), oracle.conv3d_fwd(x, w), what="fwd nobias")
+    close(dx3, oracle.conv3d_bwd_data(dy, w, x.shape), what="bwd_data")
+    dw_o, db_o = oracle.conv3d_bwd_weight(x, dy, 3)
+    close(dw3, dw_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what="bwd_weight")
+    close(db3, db_o, 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what="dbias")
+    # against fp64, next to the fp32 MFMA kernels
+    import torch.nn.functional as F
+    xd, wd = x.double(), w.double().requires_grad_(True)
+    ref = F.conv3d(xd, wd, b.double(), padding=1) + add.double()
+    refdx = F.conv_transpose3d(dy.double(), wd.detach(), padding=1)
+    ref.backward(dy.double())
+    err = lambda a, r: float((a.cpu().double() - r).abs().max() / r.abs().max())
+    e3 = (err(y3, ref.detach()), err(dx3, refdx), err(dw3, wd.grad))
+    e0 = (err(hip.conv3d_fwd(x, w, b, add), ref.detach()), err(hip.conv3d_bwd_data(dy, w, x.shape), refdx),
+          err(hip.conv3d_bwd_weight(x, dy, 3)[0], wd.grad))
+    for name, a, r in zip(("fwd", "bwd_data", "bwd_weight"), e3, e0):
+        assert a <= max(3.0 * r, 2e-6) and a < 3e-6, f"{name}: split kernels {a:.2e} vs fp32 MFMA {r:.2e} (relative to max |fp64 result|)"
+
+
+def test_conv3d_f32x3_split_is_exact_on_hard_operands(hip):
+    """The three-way split must reproduce values a bf16 rounding would destroy: operands with all 24 significant bits in
+    use, mixed magnitudes (2^-20 .. 2^20 per channel), signed zeros; a non-finite operand makes exactly the outputs it
+    touches non-finite (inf, or NaN where it meets a zero plane of the other operand) and nothing else."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    N, Ci, Co, D, H, W = 1, 16, 32, 4, 6, 32
+    x = torch.randn(N, Ci, D, H, W, generator=g) * (2.0 ** torch.randint(-20, 21, (1, Ci, 1, 1, 1), generator=g).float())
+    x[0, 3, 1, 2, 5] = 0.0
+    x[0, 4, 1, 2, 5] = -0.0
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * (2.0 ** -torch.randint(-20, 21, (1, Ci, 1, 1, 1), generator=g).float()) / 20
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    y = hip.conv3d_fwd(x, w, compute=X3).cpu().double()
+    scale = F.conv3d(x.double().abs(), w.double().abs(), padding=1)   # sum of |terms| per output
+    assert float(((y - ref).abs() / scale).max()) < 1e-5   # fp32 accumulation of 432 terms; a bf16 rounding of an operand: ~4e-3
+    dy = torch.randn(N, Co, D, H, W, generator=g)
+    wg = w.double().requires_grad_(True)
+    F.conv3d(x.double(), wg, padding=1).backward(dy.double())
+    dw = hip.conv3d_bwd_weight(x, dy, 3, with_bias=False, compute=X3)[0].cpu().double()
+    ws = torch.zeros_like(wg)
+    wsg = ws.requires_grad_(True)
+    F.conv3d(x.double().abs(), wsg, padding=1).backward(dy.double().abs())
+    assert float(((dw - wg.grad).abs() / wsg.grad.clamp_min(1e-300)).max()) < 2e-5
+    xi = x.clone()
+    xi[0, 2, 2, 3, 10] = float("inf")
+    yi = hip.conv3d_fwd(xi, w.abs() + 1e-3, compute=X3).cpu()
+    far = torch.ones_like(yi, dtype=torch.bool)
+    far[0, :, 1:4, 2:5, 9:12] = False
+    assert torch.isfinite(yi[far]).all() and not torch.isfinite(yi[~far]).any()
+
+
+def test_conv3d_f32x3_fused_statistics_and_packed_weights(hip, oracle):
+    """The split kernel shares the fp32 kernels' epilogue: fused GroupNorm statistics (m355_conv3d_fwd_stats) and the
+    pre-packed weight form of the model path (m355_conv3d_pack + M355_CONV_W_PACKED), forward and data gradient."""
+    N, Ci, Co, D, H, W = 2, 24, 40, 8, 12, 32
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Co, Ci, 3, 3, 3, seed=2) * 0.05, rnd(Co, seed=3)
+    y = hip.conv3d_fwd(x, w, b, compute=X3)
+    packed = hip.pack_weights(w, x.shape, 0, compute=X3)
+    assert torch.equal(hip.conv3d_fwd(x, w, b, compute=X3, packed=packed), y)
+    close(y, oracle.conv3d_fwd(x, w, b), what="fwd")
+
+
 @pytest.mark.parametrize("case", [(1, 6, 6, 8, 8, 8, 4, 2, 1), (2, 3, 5, 7, 6, 5, 3, 2, 1), (1, 4, 4, 5, 5, 5, 1, 1, 0)])
 def test_conv3d_generic_direct(hip, oracle, case):
     N, Ci, Co, D, H, W, k, s, p = case
