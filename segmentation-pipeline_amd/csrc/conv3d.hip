@@ -2913,7 +2913,7 @@ static bool bww_plain_h16(const m355_conv3d_desc* d) {
 // fp32 layer there, M355_F32X3_BWW=0 keeps the weight gradient on the fp32 MFMA kernels)
 static bool bww_x3(const m355_conv3d_desc* d) {
   const bool mode = d->compute == M355_COMPUTE_F32X3 || (d->compute == M355_COMPUTE_F32 && tuning().f32x3 == 2);
-  return mode && tuning().f32x3 && tuning().f32x3_bww && is_k3s1p1(d) && d->Cin > 4 && d->Cout > 4 &&
+  return mode && tuning().f32x3 && tuning().f32x3_bww && is_k3s1p1(d) && d->Cin > 4 && d->Cout > 4 && d->D >= 2 &&
          (int64_t)d->D * d->H * d->W < (1ll << 24);
 }
 

@@ -475,39 +475,54 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int z = 0, col = 0;
+  // Two register sets alternate (the tile loop is unrolled by two): while tile t is multiplied, the set fetched during
+  // tile t - 1 -- plane z + 2 and the dy tile of tile t + 1 -- is committed, and the other set receives the loads of
+  // tile t + 2, which so have a whole tile (~4 us) to land: at 128^3 the operands come from HBM, and one tile of
+  // distance left the commit waiting on them (5.5 us per tile against 4.5 at 64^3).
+  int z = 0, buf = 0;     // of the tile being multiplied
+  int pz = 0, pcol = 0;   // of the tile the loads are issued for; the staging state (column_setup) is that tile's column
+  float xa[XPER][8], da8[8], xb[XPER][8], db8[8];
   if (t_begin < t_end) {
-    col = t_begin / D;
-    z = t_begin - col * D;
-    column_setup(col);
+    pcol = t_begin / D;
+    z = t_begin - pcol * D;
+    column_setup(pcol);
     cold(z);
     float d0[8];
     fetch_dy(d0, z, true);
     commit_dy(d0, 0);
+    const bool more1 = t_begin + 1 < t_end;
+    pz = z + 1;
+    if (pz == D) {
+      pz = 0;
+      pcol += 1;
+      if (more1) column_setup(pcol);
+    }
+    fetch_plane(xa, pz + 1, more1 && pz != 0);   // (the planes of a new column are loaded by cold())
+    fetch_dy(da8, pz, more1);
   }
   __syncthreads();
-  int buf = 0;
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  auto body = [&](int tile, const float (&cx)[XPER][8], const float (&cd)[8], float (&lx)[XPER][8], float (&ld)[8])
+      __attribute__((always_inline)) {
     // fragment bases of THIS tile: tap plane dz -> ring slot (z + dz) & 3
     const unsigned char* xt[7];
 #pragma unroll
     for (int t = 0; t < 7; ++t) xt[t] = xs + tyx[t] + ((z + tdz[t]) & 3) * SLOT_B;
     const unsigned char* da = ds + buf * DBUF_B + lbA;
-    const bool more = tile + 1 < t_end;
-    const bool newcol = z + 1 == D;
-    const int zn = newcol ? 0 : z + 1;
-    if (newcol && more) {   // (uniform; once per D tiles: the divisions of the setup stay out of the steady state)
-      col += 1;
-      column_setup(col);
+    const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
+    pz += 1;
+    if (pz == D) {   // (uniform; once per D tiles: the divisions of the setup stay out of the steady state)
+      pz = 0;
+      pcol += 1;
+      if (more2) column_setup(pcol);
     }
-    float xr[XPER][8], dr[8];
-    fetch_plane(xr, zn + 1, more && !newcol);   // (a new column's planes are loaded after the barrier)
-    fetch_dy(dr, zn, more);
+    fetch_plane(lx, pz + 1, more2 && pz != 0);
+    fetch_dy(ld, pz, more2);
     // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
     // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one.  The LAST NU
-    // steps also carry the commit of the prefetched plane / dy tile, one unit (4 channels of an item: ~30 vector-ALU
-    // ops + 3 LDS writes) per step in the shadow of its MFMAs; it is unconditional -- after the last tile and before
-    // a new column the registers hold zeros and the slot they go to is rewritten before its next use.
+    // steps also carry the commit of the NEXT tile's plane / dy tile (register set c*, fetched one tile ago), one unit (4
+    // channels of an item: ~30 vector-ALU ops + 3 LDS writes) per step in the shadow of its MFMAs; it is unconditional
+    // -- after the last tile and before a new column the registers hold zeros and the slot they go to is rewritten
+    // before its next use.
     {
       unsigned char* xw = xs + ((z + 3) & 3) * SLOT_B;   // the slot no tap of tile z reads (plane z + 2 of this column)
       unsigned char* dw_ = ds + (buf ^ 1) * DBUF_B + ddst;
@@ -544,8 +559,8 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
         const int u = s - (28 - NU);   // commit unit of this step
         if (u >= 0) {
-          if (u < 2 * XPER) commit4(xr[u >> 1], u & 1, xw + xdst[u >> 1], PLANE_B);
-          else commit4(dr, u & 1, dw_, 4096);
+          if (u < 2 * XPER) commit4(cx[u >> 1], u & 1, xw + xdst[u >> 1], PLANE_B);
+          else commit4(cd, u & 1, dw_, 4096);
         }
         // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
 #pragma unroll
@@ -562,13 +577,20 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
       }
     }
     __syncthreads();   // every wave is done reading this tile; the next one is in LDS
-    if (more && newcol) {   // (uniform)
-      cold(0);
+    const bool newcol = z + 1 == D;
+    if (more1 && newcol) {   // (uniform) tile + 1 opens a column: its three planes, here and now.  The staging state is
+      cold(0);               // already that column's (tile + 2 lies in it as well: D >= 2, host check)
       __syncthreads();
     }
-    z = zn;
+    z = newcol ? 0 : z + 1;
     buf ^= 1;
+  };
+  int tile = t_begin;
+  for (; tile + 1 < t_end; tile += 2) {
+    body(tile, xa, da8, xb, db8);
+    body(tile + 1, xb, db8, xa, da8);
   }
+  if (tile < t_end) body(tile, xa, da8, xb, db8);
 
   // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
   float* sl = slab + (int64_t)split * 27 * Cout * Cin;
