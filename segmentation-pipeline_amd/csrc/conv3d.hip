@@ -1954,7 +1954,9 @@ int pick_gx(int W) {
 }
 
 // M355_COMPUTE_F32X3 (conv3d_f32x3.hip): 8-channel chunks must carry real channels, a 32-row tile real rows, and the
-// 8-channel slab of a sample must fit the 31-bit byte offsets its loads add up
+// 8-channel slab of a sample must fit the 31-bit byte offsets its loads add up.  (The edge layers gain nothing from the
+// split kernel -- 4 -> 32 @128^3 forward 0.208 vs 0.212 ms, 3 -> 32 data gradient 0.202 vs 0.200: they are bound by the
+// one-tile-per-workgroup load -> multiply -> store chain and the 268 MB they write, not by the matrix pipe.)
 static bool x3_layer(int kin, int mout, int D, int H, int W) {
   return tuning().f32x3 && kin >= 8 && mout > 4 && (int64_t)D * H * W < (1ll << 26);
 }
@@ -2564,7 +2566,8 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
   M355_REQUIRE(items || n == 0, M355_EINVALID_ARG, "conv3d_pack_batch: null items");
   hipStream_t st = (hipStream_t)stream;
   PackBatch b;
-  int nb = 0;
+  X3PackBatch b3;
+  int nb = 0, nb3 = 0;
   for (int i = 0; i < n; ++i) {
     const m355_pack_item& it = items[i];
     const m355_conv3d_desc* d = &it.desc;
@@ -2579,8 +2582,19 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
     }
     const FwdPlan p = it.which == 0 ? plan_mfma(d->N, d->Cin, d->Cout, d->D, d->H, d->W, d->compute)
                                     : plan_mfma(d->N, d->Cout, d->Cin, d->D, d->H, d->W, d->compute);
-    if (p.x3) {   // split + fragment-ordered weights: launched on their own
-      launch_pack_w3_x3(p, it.w, it.packed, d->Cout, d->Cin, it.which == 1, st);
+    if (p.x3) {   // split + fragment-ordered weights: a batch of their own
+      X3PackEntry& e = b3.e[nb3++];
+      e.w = it.w;
+      e.wq = it.packed;
+      e.Cout = d->Cout;
+      e.Cin = d->Cin;
+      e.nchunks = p.nchunks;
+      e.otiles = p.otiles;
+      e.transpose = it.which == 1;
+      if (nb3 == PACK_BATCH) {
+        launch_pack_x3_batch(b3, nb3, st);
+        nb3 = 0;
+      }
       continue;
     }
     const int kind = !is16(d->compute) ? 0 : (d->compute == M355_COMPUTE_BF16 ? 1 : 2);
@@ -2604,6 +2618,7 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
     }
   }
   if (nb) launch_pack_batch(b, nb, st);
+  if (nb3) launch_pack_x3_batch(b3, nb3, st);
   return check_launch("conv3d_pack_batch");
 }
 

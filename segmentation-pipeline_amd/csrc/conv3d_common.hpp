@@ -192,6 +192,19 @@ struct PackBatch {
   int n;
 };
 void launch_pack_batch(PackBatch& b, int n, hipStream_t st);
+// ... and of the split-kernel forms (M355_COMPUTE_F32X3, conv3d_f32x3.hip)
+struct X3PackEntry {
+  const float* w;
+  void* wq;
+  int Cout, Cin;      // of the weight tensor
+  int nchunks, otiles, transpose;
+  int blk0, nblk;
+};
+struct X3PackBatch {
+  X3PackEntry e[PACK_BATCH];
+  int n;
+};
+void launch_pack_x3_batch(X3PackBatch& b, int n, hipStream_t st);
 
 // fp32 MFMA weight layout (see pack_w3_kernel): block `bid` of `nblk` of one tensor
 __device__ __forceinline__ void pack_w3_body(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,

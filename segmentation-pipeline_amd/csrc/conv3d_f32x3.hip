@@ -55,29 +55,33 @@ __device__ __forceinline__ unsigned x3_pack(unsigned a, unsigned b) { return __b
 // wq[((((ot * nchunks + ch) * 14 + pair) * 3 + plane) * 64 + lane] = 8 bf16: the channels 8 ch .. 8 ch + 7 of output
 // channel 32 ot + (lane & 31) at tap x3_pair_tap(pair, lane >> 5); plane 0 / 1 / 2 = hi / mid / lo.
 // transpose (data gradient): the logical filter is W'[m][k][t] = w[k][m][26 - t] (m over Cin_w, k over Cout_w).
+__device__ __forceinline__ void pack_w3_x3_item(const float* __restrict__ w, u32x4* __restrict__ wq, int64_t i, int Cout_w,
+                                                int Cin_w, int kin, int mout, int nchunks, int transpose) {
+  const int lane = (int)(i & 63);
+  const int64_t f = i >> 6;
+  const int pair = (int)(f % X3_PAIRS), ch = (int)((f / X3_PAIRS) % nchunks);
+  const int o = (int)(f / ((int64_t)X3_PAIRS * nchunks)) * 32 + (lane & 31);
+  const int tap = x3_pair_tap(pair, lane >> 5);
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = ch * 8 + j;
+    float v = 0.f;
+    if (tap >= 0 && o < mout && c < kin)
+      v = transpose ? w[((int64_t)c * Cin_w + o) * 27 + (26 - tap)] : w[((int64_t)o * Cin_w + c) * 27 + tap];
+    x3_split(v, h[j], m[j], l[j]);
+  }
+  u32x4* dst = wq + f * 3 * 64 + lane;
+  dst[0] = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+  dst[64] = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+  dst[128] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+}
+
 __global__ void pack_w3_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cout_w, int Cin_w, int kin,
                                   int mout, int nchunks, int otiles, int transpose) {
   const int64_t total = (int64_t)otiles * nchunks * X3_PAIRS * 64;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63);
-    const int64_t f = i >> 6;
-    const int pair = (int)(f % X3_PAIRS), ch = (int)((f / X3_PAIRS) % nchunks);
-    const int o = (int)(f / ((int64_t)X3_PAIRS * nchunks)) * 32 + (lane & 31);
-    const int tap = x3_pair_tap(pair, lane >> 5);
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = ch * 8 + j;
-      float v = 0.f;
-      if (tap >= 0 && o < mout && c < kin)
-        v = transpose ? w[((int64_t)c * Cin_w + o) * 27 + (26 - tap)] : w[((int64_t)o * Cin_w + c) * 27 + tap];
-      x3_split(v, h[j], m[j], l[j]);
-    }
-    u32x4* dst = wq + f * 3 * 64 + lane;
-    dst[0] = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
-    dst[64] = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
-    dst[128] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    pack_w3_x3_item(w, wq, i, Cout_w, Cin_w, kin, mout, nchunks, transpose);
 }
 
 void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose, hipStream_t st) {
@@ -85,6 +89,31 @@ void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, i
   const int64_t total = (int64_t)p.otiles * p.nchunks * X3_PAIRS * 64;
   hipLaunchKernelGGL(pack_w3_x3_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, st, w,
                      (u32x4*)wp, Cout_w, Cin_w, kin, mout, p.nchunks, p.otiles, transpose ? 1 : 0);
+}
+
+// every split-kernel weight form of a model in ONE launch (m355_conv3d_pack_batch: after optimizer.step both forms of
+// every conv weight are re-packed -- 34 launches of ~6 us in a cfg2 step otherwise); blocks [blk0, blk0 + nblk) of the
+// grid belong to entry k
+__global__ __launch_bounds__(256) void pack_w3_x3_batch_kernel(const X3PackBatch b) {
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= b.e[k + 1].blk0) ++k;
+  const X3PackEntry& e = b.e[k];
+  const int64_t total = (int64_t)e.otiles * e.nchunks * X3_PAIRS * 64;
+  const int kin = e.transpose ? e.Cout : e.Cin, mout = e.transpose ? e.Cin : e.Cout;
+  for (int64_t i = (int64_t)((int)blockIdx.x - e.blk0) * 256 + threadIdx.x; i < total; i += (int64_t)e.nblk * 256)
+    pack_w3_x3_item(e.w, (u32x4*)e.wq, i, e.Cout, e.Cin, kin, mout, e.nchunks, e.transpose);
+}
+
+void launch_pack_x3_batch(X3PackBatch& b, int n, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    X3PackEntry& e = b.e[i];
+    e.blk0 = blocks;
+    e.nblk = (int)std::min<int64_t>(ceil_div((int64_t)e.otiles * e.nchunks * X3_PAIRS * 64, 256), 512);
+    blocks += e.nblk;
+  }
+  b.n = n;
+  hipLaunchKernelGGL(pack_w3_x3_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
 }
 
 // ---- the kernel: one output tile (4 z x NTW*GY y x GX x voxels, 32 channels) of one split per workgroup ----

@@ -269,16 +269,16 @@ def test_conv3d_packed_weights_reused_across_launches(hip, compute, env, tuning)
 
 
 def test_conv3d_pack_batch_matches_single_packs(hip):
-    """m355_conv3d_pack_batch writes the very bytes of one m355_conv3d_pack per item: fp32 / bf16 / fp16 layouts, forward
-    and data-gradient forms, ragged channel counts, the Cout <= 4 forward layout, and more items than one launch holds
+    """m355_conv3d_pack_batch writes the very bytes of one m355_conv3d_pack per item: fp32 / bf16 / fp16 / split (compute 3)
+    layouts, forward and data-gradient forms, ragged channel counts, the Cout <= 4 forward layout, and more items than one launch holds
     (64 per launch)."""
     cases = []
     for i, (ci, co, D, H, W) in enumerate([(12, 40, 9, 10, 36), (16, 3, 8, 8, 32), (32, 32, 8, 16, 64), (4, 32, 8, 8, 32),
                                            (96, 32, 8, 8, 32), (40, 80, 6, 6, 12), (320, 320, 4, 4, 8)]):
         w = rnd(co, ci, 3, 3, 3, seed=10 + i)
-        for compute in (0, 1, 2):
+        for compute in (0, 1, 2, 3):
             for which in (0, 1):
-                if ci <= 4 and which == 1 and compute:
+                if ci <= 4 and which == 1 and compute in (1, 2):
                     continue
                 cases.append((w, (1 + i % 2, ci, D, H, W), which, compute))
     assert len(cases) > 32

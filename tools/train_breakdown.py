@@ -5,11 +5,11 @@ import csv
 import sys
 
 FAMILIES = [
-    ("conv 3x3x3 fwd/bwd-data", ("conv3_mfma_fwd", "conv3_h16_kernel", "conv3_valu", "conv3_small", "conv3_direct")),
+    ("conv 3x3x3 fwd/bwd-data", ("conv3_mfma_fwd", "conv3_f32x3", "conv3_h16_kernel", "conv3_valu", "conv3_small", "conv3_direct")),
     ("conv transpose", ("convt_",)),
     ("conv weight gradient", ("bww", "slab_reduce", "dbias")),
     ("conv split-K / stats reduce", ("splitk_reduce",)),
-    ("weight packs", ("pack_w3", "pack_wt", "blur_")),
+    ("weight packs", ("pack_w3", "pack_wt", "pack_batch", "blur_")),
     ("activation packs (fp32 -> c8)", ("pack_act16", "unpack_act16")),
     ("norm statistics", ("norm_partial", "norm_finalize", "norm_from_partials", "act16_partials", "norm_sums")),
     ("norm+act forward", ("norm_act_fwd", "norm_act_pool", "norm_act_c8")),
