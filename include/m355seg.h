@@ -61,14 +61,19 @@ enum { M355_F32 = 0 };
  *                     fp32 accumulation (BASELINE cfg3).
  *   M355_COMPUTE_F16  the same with IEEE fp16 operands, v_mfma_f32_32x32x16_f16 (BASELINE cfg5:
  *                     "mixed fp16 with MFMA channel-GEMM path"); values beyond +-65504 become inf.
- *   M355_COMPUTE_F32X3 fp32 tensors in and out, fp32 accuracy, bf16 matrix pipe: every operand is split EXACTLY
- *                     into three bf16 values (x = hi + mid + lo, 8 + 8 + 8 significant bits) and six of the nine plane
- *                     products -- all but the three below 2^-24 of the product -- run on v_mfma_f32_32x32x16_bf16
- *                     with fp32 accumulation (conv3d_f32x3.hip).  Measured against fp64 the error equals the fp32
- *                     MFMA kernels' (it is the fp32 accumulation's in both).  Forward / data gradient of layers with
- *                     Cin >= 8 and Cout > 4; every other descriptor and entry point treats it as M355_COMPUTE_F32.
- * Applies to conv3d fwd, bwd_data and (when W % 32 == 0 and both channel counts > 4) bwd_weight;
- * every other case of the weight gradient runs in exact fp32.
+ *   M355_COMPUTE_F32X3 fp32 tensors in and out, fp32 results, bf16 matrix pipe: every operand is split EXACTLY into
+ *                     three bf16 values (x = hi + mid + lo, 8 + 8 + 8 significant bits; each step exact in fp32) and
+ *                     six of the nine plane products -- all but the three below 2^-24 of the product -- run on
+ *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (conv3d_f32x3.hip): 6 MFMAs of K = 16 stand for
+ *                     8 fp32 MFMAs of K = 2 at a sixteenth of the cost per K.  Measured against fp64 the results are
+ *                     as accurate as fp32 arithmetic is: max error 2e-7 .. 1.5e-6 of max |result| on the BASELINE
+ *                     layers, within 2.5x of the fp32 MFMA kernels' (profiles/r04_f32x3_accuracy.txt; both carry the
+ *                     error of an fp32 accumulation).  Applies to the 3x3x3 / stride 1 / pad 1 forward and data gradient of
+ *                     layers with >= 8 K-channels and > 4 M-channels, and to the weight gradient of layers with > 4
+ *                     channels on both sides, at least two z planes and < 2^24 voxels per sample; every other
+ *                     descriptor and entry point treats it as M355_COMPUTE_F32.  This is what the host side's
+ *                     default precision "fp32" passes (ops.py); "fp32_mfma" passes M355_COMPUTE_F32.
+ * The 16-bit modes apply to conv3d fwd, bwd_data and bwd_weight (the edge layers' weight gradient runs in exact fp32).
  * In the 16-bit modes the convolution kernels read their input in the "c8" layout
  *     x16[n][cb][voxel][8]   cb = channel block of 8 (zero-padded past C), 16-bit elements,
  * i.e. the 8 channels of a voxel are one aligned 16-byte item = one MFMA operand fragment (h16.hpp).
@@ -207,10 +212,14 @@ int m355_conv3d_bwd_weight_h16(const m355_conv3d_desc* d, const void* x16, int64
                                size_t workspace_bytes, void* stream);
 
 /* Introspection for profiling: which kernel variant a 3x3x3 conv dispatches to.
- * which: 0 = forward, 1 = data gradient.  out[0] = kernel family: 0 generic direct kernel, 1 MFMA
- * implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel (workgroups walk
- * several tiles), 2 z-Toeplitz small-Cout kernel, 4 the 16-bit operand kernel (persistent), 5 its 8-wave double-buffered variant, 6 its one-item-per-workgroup variant; out[1] = voxel groups per wave (NTW), out[2] = lanes
- * along x per group (GX), out[3] = split-K factor.  Pure host function. */
+ * which: 0 = forward, 1 = data gradient, 2 = weight gradient (of m355_conv3d_bwd_weight).  out[0] = kernel family:
+ * 0 generic direct kernel, 1 MFMA implicit GEMM (one output tile per workgroup), 3 the same as a persistent kernel
+ * (workgroups walk several tiles), 2 z-Toeplitz small-Cout kernel, 4 the 16-bit operand kernel (persistent), 5 its
+ * 8-wave double-buffered variant, 6 its one-item-per-workgroup variant, 7 the split kernel of M355_COMPUTE_F32X3
+ * (conv3_f32x3_kernel); weight gradient: 8 conv3_bww_x3_kernel, 9 conv3_mfma_bww2(c)_kernel, 10 the edge-layer kernel
+ * conv3_mfma_bww_small_kernel, 11 the c8 kernel behind an operand pack (16-bit modes).  out[1] = voxel groups per wave
+ * (NTW), out[2] = lanes along x per group (GX; weight gradient: tile width), out[3] = split-K factor (weight gradient:
+ * voxel-range splits).  Pure host function. */
 int m355_conv3d_plan(const m355_conv3d_desc* d, int32_t which, int32_t* out4);
 
 /* dx = conv-transpose of dy with w (autograd of the op above w.r.t. x).

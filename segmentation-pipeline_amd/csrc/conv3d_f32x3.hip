@@ -219,7 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
       (void*)(wq + (int64_t)otile * nchunks * (X3_PAIRS * 3 * 64)), 0, nchunks * (X3_PAIRS * 3 * 1024), 0x00020000);
   const int pg_last = ch_end * X3_PAIRS - 1;
   const unsigned lane16 = (unsigned)lane * 16u;
-  u32x4 afr[3][3];   // [slot][plane]; pair p of a chunk sits in slot p % 3
+  // Weight fragments in flight: a pair step is 6 * NTW MFMAs, so at NTW = 4 two pairs of distance (~1500 cycles) cover
+  // the L2 latency; at NTW <= 2 (the 32^3 .. 8^3 levels: 6 or 12 MFMAs per pair) they did not -- six pairs ahead there
+  // (a ring of 7 slots divides the 14 pairs of a chunk: no rotation at the chunk boundary).
+  constexpr int AR = NTW >= 4 ? 3 : 7, AD = AR - 1;
+  u32x4 afr[AR][3];   // [slot][plane]; pair p of a chunk sits in slot p % AR
   auto aload = [&](int slot, int pg) {
     const int q = min(pg, pg_last) * 3;   // (uniform; past the end of this split: a harmless re-read)
 #pragma unroll
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
     chunk_setup(ch_begin, true);
 #pragma unroll
     for (int k = 0; k < NLOAD; ++k) fetch(k);
-    aload(0, ch_begin * X3_PAIRS);
-    aload(1, ch_begin * X3_PAIRS + 1);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) aload(i, ch_begin * X3_PAIRS + i);
     commit();
   }
   __syncthreads();
@@ -247,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
       const int t0 = x3_pair_tap(p, 0);
       const int off = (t0 / 9) * PS + ((t0 / 3) % 3) * RS + t0 % 3;
       const int vb = (p < 9 ? vbx : (p < 12 ? vby : (p == 12 ? vbz : vb0))) + off;
-      aload((p + 2) % 3, pg + p + 2);
-      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[p % 3][0]), a_mid = __builtin_bit_cast(bf16x8, afr[p % 3][1]),
-                   a_lo = __builtin_bit_cast(bf16x8, afr[p % 3][2]);
+      aload((p + AD) % AR, pg + p + AD);
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[p % AR][0]), a_mid = __builtin_bit_cast(bf16x8, afr[p % AR][1]),
+                   a_lo = __builtin_bit_cast(bf16x8, afr[p % AR][2]);
       bf16x8 bh[NTW], bm[NTW], bl[NTW];
 #pragma unroll
       for (int g = 0; g < NTW; ++g) bh[g] = __builtin_bit_cast(bf16x8, xs[0][vb + g * GY * RS]);
@@ -273,12 +277,13 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
 #pragma unroll
       for (int k = 0; k < LPS; ++k) fetch(p * LPS + k);
     }
-    // the next chunk's pairs 0 / 1 were loaded into slots 14 % 3 = 2 and 15 % 3 = 0
+    if constexpr (AR == 3) {   // the next chunk's pairs 0 / 1 were loaded into slots 14 % 3 = 2 and 15 % 3 = 0
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      const u32x4 t = afr[0][pl];
-      afr[0][pl] = afr[2][pl];
-      afr[1][pl] = t;
+      for (int pl = 0; pl < 3; ++pl) {
+        const u32x4 t = afr[0][pl];
+        afr[0][pl] = afr[2][pl];
+        afr[1][pl] = t;
+      }
     }
     __syncthreads();   // every wave has read its fragments of this chunk
     if (more) {

@@ -15,27 +15,33 @@ case "${1:-a}" in
     step bench_cfg4_bf16 300 python bench.py --workload cfg4 --steps 5 --warmup 1 --precision bf16 --no-cpu-baseline
     M355_FORCE_DDP=1 step bench_cfg3_rccl1 300 python bench.py --workload cfg3 --bucket-dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline
     stats prof_fp32 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg3
+    stats prof_fp32_mfma python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg3 --precision fp32_mfma
     stats prof_bf16 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --precision bf16
     stats prof_bf16_infer python3 tools/infer_profile.py bf16 20
     ;;
   b)
     step pmc 900 bash tools/pmc_collect.sh fp32
+    step pmc_fp32_mfma 900 bash tools/pmc_collect.sh fp32_mfma
     step pmc_bf16 900 bash tools/pmc_collect.sh bf16
     step pmc_fp16 900 bash tools/pmc_collect.sh fp16
     step pmc_sq 600 bash tools/pmc_sq.sh
     ;;
   c)
     step arch 300 python tools/arch_bench.py
+    step arch_fp32_mfma 300 python tools/arch_bench.py all fp32_mfma
     step arch_bf16 300 python tools/arch_bench.py all bf16
     step layers_cfg2 200 python tools/layer_table.py cfg2
-    step conv_fp32 200 python tools/conv_bench.py
+    step conv_fp32 200 python tools/conv_bench.py --f32x3
+    step conv_fp32_mfma 200 python tools/conv_bench.py
+    step x3_accuracy 200 bash -c "python tools/r04/x3_check.py; python tools/r04/x3_bww_check.py"
     step conv_bf16 200 python tools/conv_bench.py --bf16
     step convt_c8 200 python tools/convt_bench_c8.py
     step sliding 300 python tools/sliding_window_bench.py
     step c8_probe 400 python tools/c8_train_probe.py cfg2 cfg5
     step ceiling 200 bash -c "./tools/micro/h16_loop; python tools/r04/gemm_peak.py; ./tools/micro/f32_loop"
-    step host 300 python tools/host_overhead_train.py fp32 bf16 fp16
+    step host 300 python tools/host_overhead_train.py fp32 fp32_mfma bf16 fp16
     ( echo "cfg2 train step only (rocprofv3 kernel stats of bench.py --no-infer, 12 train steps), fp32"; bash tools/train_breakdown.sh fp32 | grep -v "^W20\|^{";
+      echo; echo "fp32_mfma"; bash tools/train_breakdown.sh fp32_mfma | grep -v "^W20\|^{";
       echo; echo "bf16"; bash tools/train_breakdown.sh bf16 | grep -v "^W20\|^{";
       echo; echo "fp16"; bash tools/train_breakdown.sh fp16 | grep -v "^W20\|^{" ) > $O/train_breakdown.log 2>&1
     ;;
