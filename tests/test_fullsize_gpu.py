@@ -113,9 +113,12 @@ def _check_probs(case, p, ld, prob_tol, dice_tol, exact_argmax_gap):
     return err
 
 
-def test_cfg2_full_size_fp32_forward_loss_gradients_vs_cpu_oracle(cfg2):
-    """BASELINE cfg2: 5-level GN/ConvT U-Net, 1x4x128^3, fp32, 18.08 M parameters."""
-    model, p, ld = _forward(cfg2, "fp32", train=True)
+@pytest.mark.parametrize("mode", ["fp32", "fp32_mfma"])
+def test_cfg2_full_size_fp32_forward_loss_gradients_vs_cpu_oracle(cfg2, mode):
+    """BASELINE cfg2: 5-level GN/ConvT U-Net, 1x4x128^3, fp32, 18.08 M parameters.  "fp32": the wide convolutions on the
+    split kernels (six bf16 MFMAs per product group on the exact three-way operand split); "fp32_mfma": every product on
+    the fp32 MFMA -- the same tolerances for both."""
+    model, p, ld = _forward(cfg2, mode, train=True)
     _check_probs(cfg2, p, ld, 1e-4, 1e-4, 1e-3)
     for k in ("loss", "dice_loss", "logistic_loss"):
         assert abs(ld[k].item() - cfg2.loss_ref[k]) <= 1e-4, k

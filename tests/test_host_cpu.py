@@ -199,3 +199,22 @@ def test_graphed_forward_is_transparent_off_the_gpu():
     gf = GraphedForward(lin)
     x = torch.randn(1, 2, 3, 4, 5)
     assert torch.equal(gf(x), lin(x)) and not gf._graphs
+
+
+def test_precision_modes_map_to_the_abi_compute_codes():
+    """"fp32" (the default) asks the library for M355_COMPUTE_F32X3 -- fp32 tensors and results, the wide convolutions on the
+    bf16 matrix pipe through the exact three-way operand split; "fp32_mfma" for M355_COMPUTE_F32; the 16-bit modes for
+    theirs.  Unknown names are refused."""
+    import pytest
+    from segmentation_pipeline_amd import _lib, ops
+    assert (_lib.COMPUTE_F32, _lib.COMPUTE_BF16, _lib.COMPUTE_F16, _lib.COMPUTE_F32X3) == (0, 1, 2, 3)
+    assert ops.get_precision() == "fp32" and ops.is_fp32()
+    assert ops._COMPUTE["fp32"] == (_lib.COMPUTE_F32X3 if ops.FP32_SPLIT else _lib.COMPUTE_F32)
+    assert ops._COMPUTE["fp32_mfma"] == _lib.COMPUTE_F32
+    with ops.precision("bf16"):
+        assert not ops.is_fp32() and ops.get_precision() == "bf16"
+    with ops.precision("fp32_mfma"):
+        assert ops.is_fp32()
+    assert ops.get_precision() == "fp32"
+    with pytest.raises(ValueError):
+        ops.set_precision("fp32x3")

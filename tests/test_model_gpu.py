@@ -226,9 +226,18 @@ def test_adam_through_graphed_train_step(golden, mode):
         assert rel <= 5e-2 and worst_buf <= 1e-4
 
 
-def test_cfg2_architecture_reduced_patch(golden):
+@pytest.mark.parametrize("mode", ["fp32", "fp32_mfma"])
+def test_cfg2_architecture_reduced_patch(golden, mode):
     """The real 5-level [32,64,128,256,320] GN/ConvT network (18.08 M params) on a 32^3 patch;
-    weights re-created from seed 0 exactly as the fixture generator did."""
+    weights re-created from seed 0 exactly as the fixture generator did.  Both fp32 arithmetics against the SAME
+    reference vectors at the same tolerances: "fp32" (the wide convolutions as six bf16 MFMAs on the exact three-way
+    operand split) and "fp32_mfma" (every product on the fp32 MFMA)."""
+    import segmentation_pipeline_amd as sp
+    with sp.precision(mode):
+        _cfg2_architecture_reduced_patch(golden)
+
+
+def _cfg2_architecture_reduced_patch(golden):
     g = golden("cfg2_arch_32cube.npz")
     torch.manual_seed(0)
     model = ModularUNet(4, 3, [32, 64, 128, 256, 320], 5, block_params=dict(GN8), **CONVT)
