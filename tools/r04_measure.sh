@@ -33,7 +33,7 @@ case "${1:-a}" in
     step layers_cfg2 200 python tools/layer_table.py cfg2
     step conv_fp32 200 python tools/conv_bench.py --f32x3
     step conv_fp32_mfma 200 python tools/conv_bench.py
-    step x3_accuracy 200 bash -c "python tools/r04/x3_check.py; python tools/r04/x3_bww_check.py"
+    step x3_accuracy 300 bash -c "python tools/r04/x3_check.py; python tools/r04/x3_bww_check.py; python tools/r04/split_probe.py"
     step conv_bf16 200 python tools/conv_bench.py --bf16
     step convt_c8 200 python tools/convt_bench_c8.py
     step sliding 300 python tools/sliding_window_bench.py
