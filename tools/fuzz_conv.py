@@ -2,7 +2,8 @@
 """Randomised parity sweep of the 3x3x3 conv family (forward / data gradient / weight gradient, fused
 statistics) against the C oracle: random N, channels, ragged volumes, and random planner overrides so
 that every kernel variant (one-shot / persistent, every NTW and lane-group width, split-K, both
-bwd-weight generations) sees odd shapes.   usage: python tools/fuzz_conv.py [--convt | --h16] [cases] [seed]"""
+bwd-weight generations) sees odd shapes.   usage: python tools/fuzz_conv.py [--convt | --h16 | --x3] [cases] [seed]
+--x3: every qualifying layer on the split kernels (M355_F32X3=2: conv3_f32x3_kernel / conv3_bww_x3_kernel), same sweep."""
 import os
 import random
 import sys
@@ -129,6 +130,9 @@ def main():
         sys.argv.remove("--convt")
         return fuzz_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 80,
                           random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0))
+    if "--x3" in sys.argv:
+        sys.argv.remove("--x3")
+        os.environ["M355_F32X3"] = "2"
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     hip, oracle = RawOps("hip"), RawOps("oracle")
