@@ -246,36 +246,59 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
     const bool more = ch + 1 < ch_end;
     chunk_setup(more ? ch + 1 : ch, more);
     const int pg = ch * X3_PAIRS;
+    // A pair step is cut into NH sub-steps of GH voxel groups: while the 6 * GH MFMAs of a sub-step run, the B fragments of
+    // the NEXT sub-step (3 planes x GH groups) are read from LDS into the other half of bq -- every read has a sub-step of
+    // MFMAs to land, with the registers of one pair step.  (Left to the compiler the reads sat directly in front of their
+    // MFMAs and the weight loads directly in front of their use: 60 % MFMA-busy.)  The scheduling barriers pin the
+    // interleave: LDS reads behind the first MFMAs, global loads (weights of pair p + AD, activations of the next chunk)
+    // behind the rest.
+    {
+      constexpr int NH = NTW >= 2 ? 2 : 1, GH = NTW / NH, NSUB = X3_PAIRS * NH;
+      bf16x8 bq[2][GH][3];
+      auto bload = [&](int buf, int p, int h) __attribute__((always_inline)) {
+        const int t0 = x3_pair_tap(p, 0);
+        const int off = (t0 / 9) * PS + ((t0 / 3) % 3) * RS + t0 % 3;
+        const int vb = (p < 9 ? vbx : (p < 12 ? vby : (p == 12 ? vbz : vb0))) + off;
 #pragma unroll
-    for (int p = 0; p < X3_PAIRS; ++p) {
-      const int t0 = x3_pair_tap(p, 0);
-      const int off = (t0 / 9) * PS + ((t0 / 3) % 3) * RS + t0 % 3;
-      const int vb = (p < 9 ? vbx : (p < 12 ? vby : (p == 12 ? vbz : vb0))) + off;
-      aload((p + AD) % AR, pg + p + AD);
-      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[p % AR][0]), a_mid = __builtin_bit_cast(bf16x8, afr[p % AR][1]),
-                   a_lo = __builtin_bit_cast(bf16x8, afr[p % AR][2]);
-      bf16x8 bh[NTW], bm[NTW], bl[NTW];
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) bh[g] = __builtin_bit_cast(bf16x8, xs[0][vb + g * GY * RS]);
+          for (int gi = 0; gi < GH; ++gi) bq[buf][gi][pl] = __builtin_bit_cast(bf16x8, xs[pl][vb + (h * GH + gi) * GY * RS]);
+      };
+      bload(0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) bm[g] = __builtin_bit_cast(bf16x8, xs[1][vb + g * GY * RS]);
+      for (int sb = 0; sb < NSUB; ++sb) {
+        const int p = sb / NH, h = sb % NH;
+        const bool nb = sb + 1 < NSUB, first = h == 0, last = h == NH - 1;
+        if (nb) bload((sb + 1) & 1, (sb + 1) / NH, (sb + 1) % NH);
+        if (first) aload((p + AD) % AR, pg + p + AD);
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[p % AR][0]), a_mid = __builtin_bit_cast(bf16x8, afr[p % AR][1]),
+                     a_lo = __builtin_bit_cast(bf16x8, afr[p % AR][2]);
+        // (the small terms of a product group first; consecutive MFMAs write different accumulators)
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) bl[g] = __builtin_bit_cast(bf16x8, xs[2][vb + g * GY * RS]);
-      // the small terms first
+        for (int pr = 0; pr < 6; ++pr) {
+          constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
+          const bf16x8 a = pr == 0 ? a_lo : (pr == 1 || pr == 3 ? a_mid : a_hi);   // (lo,hi) (mid,hi) (hi,hi) (mid,mid) (hi,mid) (hi,lo)
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh[g], acc[g], 0, 0, 0);
+          for (int gi = 0; gi < GH; ++gi)
+            acc[h * GH + gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[sb & 1][gi][PB[pr]], acc[h * GH + gi], 0, 0, 0);
+        }
+        if (last) {
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bh[g], acc[g], 0, 0, 0);
+          for (int k = 0; k < LPS; ++k) fetch(p * LPS + k);
+        }
+        constexpr int NM = 6 * GH, NR = 3 * GH;
+        const int nv = (first ? 3 : 0) + (last ? LPS : 0);   // global loads of this sub-step
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh[g], acc[g], 0, 0, 0);
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+          if (nb && i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // a B fragment of the next sub-step
+          if (i >= NR && i - NR < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+        }
 #pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bm[g], acc[g], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bm[g], acc[g], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl[g], acc[g], 0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < LPS; ++k) fetch(p * LPS + k);
+        for (int i = NM - NR; i < 3 + LPS; ++i)
+          if (i < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if constexpr (AR == 3) {   // the next chunk's pairs 0 / 1 were loaded into slots 14 % 3 = 2 and 15 % 3 = 0
 #pragma unroll

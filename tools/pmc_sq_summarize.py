@@ -26,7 +26,7 @@ def main():
             seen = set()
             for r in csv.DictReader(open(fn)):
                 name = re.sub(r"\(.*", "", demangle(r["Kernel_Name"]))
-                if "conv3_mfma" not in name:
+                if not any(k in name for k in ("conv3_mfma", "conv3_f32x3", "conv3_bww_x3")):
                     continue
                 a = acc[name][r["Counter_Name"]]
                 a[0] += float(r["Counter_Value"])
@@ -49,7 +49,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import source_hash
     doc = {"method": "rocprofv3 --pmc (four passes of three counters, --kernel-trace only; tools/pmc_sq.sh) on 3 forward + 3 "
-                     "weight-gradient launches of the largest layer (96->32 @128^3); per-launch means; clock = GRBM_GUI_ACTIVE / "
+                     "weight-gradient launches of the largest layer (96->32 @128^3) on the split kernels and on the fp32 MFMA kernels; per-launch means; clock = GRBM_GUI_ACTIVE / "
                      "(8 XCDs x time); MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)",
            "source_hash": source_hash(), "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
