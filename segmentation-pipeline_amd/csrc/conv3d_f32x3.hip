@@ -479,6 +479,21 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
     for (int j = 0; j < 8; ++j)
       r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
   };
+  // half an item (channels 4 hf .. 4 hf + 3): the unit the steady-state prefetch is cut into (one per MFMA step)
+  auto fetch4_x = [&](float (&r)[8], int k, int hf, int p, bool on) __attribute__((always_inline)) {
+    const int xx = (int)(xcode[k] >> 16);
+    const bool ok = (on && p >= 0 && p < D) & (((xcode[k] & 0xffffu) & ~ymask) == 0u) & ((unsigned)(xlim + xx) < (unsigned)W);
+    const unsigned off = ok ? (unsigned)(colbase + p * iHW + xrel[k]) * 4u : OOB;
+#pragma unroll
+    for (int j = 4 * hf; j < 4 * hf + 4; ++j)
+      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + j * cstride, 0, 0));
+  };
+  auto fetch4_dy = [&](float (&r)[8], int hf, int z, bool on) __attribute__((always_inline)) {
+    const unsigned off = (on & dok) ? (unsigned)(dbase + z * iHW) * 4u : OOB;
+#pragma unroll
+    for (int j = 4 * hf; j < 4 * hf + 4; ++j)
+      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
+  };
   auto commit8 = [&](const float (&v)[8], unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {   // split + three 16-byte items
     unsigned h[8], m[8], l[8];
 #pragma unroll
@@ -572,8 +587,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
       pcol += 1;
       if (more2) column_setup(pcol);
     }
-    fetch_plane(lx, pz + 1, more2 && pz != 0);
-    fetch_dy(ld, pz, more2);
+    const bool fx_on = more2 && pz != 0;   // (the planes of a new column are loaded by cold())
     // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
     // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one.  The LAST NU
     // steps also carry the commit of the NEXT tile's plane / dy tile (register set c*, fetched one tile ago), one unit (4
@@ -619,6 +633,13 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
           if (u < 2 * XPER) commit4(cx[u >> 1], u & 1, xw + xdst[u >> 1], PLANE_B);
           else commit4(cd, u & 1, dw_, 4096);
         }
+        // ... and the FIRST NU steps the loads of tile t + 2, four dwords (half an item) per step: issued at the top of the
+        // tile, their ~250 instructions of address arithmetic and issue ran with the matrix pipe idle (one wave per SIMD)
+        const bool fu = s < NU;
+        if (fu) {
+          if (s < 2 * XPER) fetch4_x(lx[s >> 1], s >> 1, s & 1, pz + 1, fx_on);
+          else fetch4_dy(ld, s & 1, pz, more2);
+        }
         // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -628,6 +649,10 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
             else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           }
           if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // vector ALU of the commit unit
+          if (fu && i >= 2) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               // address arithmetic of a load
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // the load
+          }
         }
         if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);       // its LDS writes
         __builtin_amdgcn_sched_barrier(0);
