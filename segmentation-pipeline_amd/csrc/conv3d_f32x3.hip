@@ -416,19 +416,23 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
   const int iHW = H * W, S = D * iHW;
   const unsigned cstride = (unsigned)S * 4u;   // S < 2^24 (host check): 32 channels stay below 2^31 bytes
 
-  // thread-invariant part of the staging: item e of a halo plane = (8-channel block e / HP, halo voxel e % HP)
+  // thread-invariant part of the staging: item e of a halo plane = (halo voxel e / 4, 8-channel block e % 4).  The channel
+  // block runs fastest over the lanes, so a wave's 16-byte LDS writes of an item row are 1 KB contiguous (voxel-fastest
+  // they sat 64 bytes apart: 16 lanes on one bank, and the conflicted writes kept the LDS busy for 70 % of a tile --
+  // SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE); a global load instruction then covers 16 voxels of 4 channel
+  // blocks: four 64-byte runs.
   int xrel[XPER], xdst[XPER];
   unsigned xcode[XPER];
 #pragma unroll
   for (int k = 0; k < XPER; ++k) {
     const int e = tid + 256 * k;
-    const int cbl = e / HP, hv = e - cbl * HP;
+    const int cbl = e & 3, hv = e >> 2;
     const int yy = hv / HR, xx = hv - yy * HR;
     xrel[k] = cbl * 8 * S + yy * W + xx;
     xdst[k] = e < XI ? hv * 64 + cbl * 16 : HP * 64 + (tid & 3) * 16;
     xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
   }
-  const int dv = tid & 63, dcb = tid >> 6;            // dy item: (voxel of the tile, 8-channel block)
+  const int dv = tid >> 2, dcb = tid & 3;             // dy item: (voxel of the tile, 8-channel block)
   const int dvy = dv / TX, dvx = dv - dvy * TX;
   const int ddst = dv * 64 + dcb * 16;
 
@@ -507,14 +511,21 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
     for (int k = 0; k < XPER; ++k) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
   };
   // half an item (channels 4 hf .. 4 hf + 3): the unit the steady-state commit is cut into
+  // (the first half only splits and keeps its six packed words; the second writes the three 16-byte items)
+  unsigned pk[3][2];
   auto commit4 = [&](const float (&v)[8], int hf, unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) x3_split(v[4 * hf + c], h[c], m[c], l[c]);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    *(u32x2*)(dst + 8 * hf) = (u32x2){x3_pack(h[0], h[1]), x3_pack(h[2], h[3])};
-    *(u32x2*)(dst + plane_bytes + 8 * hf) = (u32x2){x3_pack(m[0], m[1]), x3_pack(m[2], m[3])};
-    *(u32x2*)(dst + 2 * plane_bytes + 8 * hf) = (u32x2){x3_pack(l[0], l[1]), x3_pack(l[2], l[3])};
+    const unsigned w[3][2] = {{x3_pack(h[0], h[1]), x3_pack(h[2], h[3])}, {x3_pack(m[0], m[1]), x3_pack(m[2], m[3])},
+                              {x3_pack(l[0], l[1]), x3_pack(l[2], l[3])}};
+    if (hf == 0) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) pk[pl][0] = w[pl][0], pk[pl][1] = w[pl][1];
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *(u32x4*)(dst + pl * plane_bytes) = (u32x4){pk[pl][0], pk[pl][1], w[pl][0], w[pl][1]};
+    }
   };
   auto commit_dy = [&](const float (&r)[8], int buf) __attribute__((always_inline)) { commit8(r, ds + buf * DBUF_B + ddst, 4096); };
   // start of a column / of this split's range: the three planes of tile z, loaded here and now (once per D tiles)
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // the load
           }
         }
-        if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);       // its LDS writes
+        if (u >= 0 && (u & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);   // the item's LDS writes
         __builtin_amdgcn_sched_barrier(0);
       }
     }
