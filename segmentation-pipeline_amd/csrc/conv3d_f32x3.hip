@@ -373,11 +373,16 @@ int launch_x3_conv(const FwdPlan& p, const float* in, const void* wp, const floa
 // channel per lane); the three dy planes of a k-step are read once for the wave's 7 taps, the three x planes once per
 // tap, and feed six MFMAs: 0.57 fragment reads per MFMA where the 16-bit kernel needs 1.14.
 // Tile = ONE z plane of TY x TX = 64 voxels (4 k-steps).  A workgroup walks its tiles along z; the x halo planes sit in
-// a RING of four slots (plane p in slot (p + 1) & 3): tile z reads planes z - 1 .. z + 1 while plane z + 2 -- fetched
-// into registers before the MFMAs of tile z -- is split and committed to the fourth slot, so a tile costs ONE barrier and
-// one new halo plane ((TY + 2) x (TX + 2) voxels x 32 channels) + its dy tile (double-buffered) in global loads.
-// LDS: 4 x 3 x HP x 64 B + 2 x 3 x 4 KB = 126 KB at TX = 32: one workgroup per CU, latency is hidden by the software
-// pipeline (fragments of the next tap are requested between the MFMAs of this one), not by a second workgroup.
+// a RING of four slots (plane p in slot (p + 1) & 3): tile z reads planes z - 1 .. z + 1 while plane z + 2 is split and
+// committed to the fourth slot, so a tile costs ONE barrier and one new halo plane ((TY + 2) x (TX + 2) voxels x 32
+// channels) + its dy tile (double-buffered) in global loads.
+// The workgroup is EIGHT waves in two roles.  Waves 0..3 multiply: fragment reads and MFMAs, nothing else.  Waves 4..7
+// stage: they wait for the loads of tile t + 1 (issued a tile ago), split them, write the LDS planes and issue the loads
+// of tile t + 2.  With one wave per SIMD doing both (the first version) the ~390 vector-ALU instructions of a tile's
+// split and address arithmetic did NOT hide behind that wave's own MFMAs: the kernel without them ran 34 % faster
+// (188 -> 252 TF on the cfg2 layers), with them the matrix pipe was 63 % busy.  A staging wave shares its SIMD with one
+// multiplying wave and fills exactly the issue slots the MFMAs leave.
+// LDS: 4 x 3 x HP x 64 B + 2 x 3 x 4 KB = 127 KB at TX = 32: one workgroup per CU.
 typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
 typedef short x3_s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 x3_tr_frag(const unsigned char* p) {   // two transposed 4-voxel blocks -> 8 k-values
@@ -388,22 +393,23 @@ __device__ __forceinline__ bf16x8 x3_tr_frag(const unsigned char* p) {   // two 
 }
 
 template <int TX>
-__global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
+__global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int Cin, int Cout, int D,
     int H, int W, int ty_tiles, int tx_tiles, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs) {
   constexpr int TY = 64 / TX, HR = TX + 2, HP = (TY + 2) * HR;   // tile rows; halo row / plane in voxels
-  constexpr int XI = HP * 4, XPER = (XI + 255) / 256;            // 8-channel items of a halo plane, per thread
+  constexpr int XI = HP * 4, XPER = (XI + 255) / 256;            // 8-channel items of a halo plane, per staging thread
   constexpr int PLANE_B = HP * 64 + 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;   // + one pad row: where threads without an item write
-  constexpr int NU = 2 * (XPER + 1);                             // commit units (4 channels of an item) per tile
   constexpr int KH = TX >= 16 ? 8 : HR;                          // voxels 8..15 of a k-step: 8 columns on, or the next row
   constexpr unsigned OOB = 0x80000000u;
   static_assert(4 * SLOT_B + 2 * DBUF_B <= 160 * 1024 && 2 * PLANE_B + 8 * HR * 64 + 512 < 65536, "LDS size / read offsets");
   __shared__ __attribute__((aligned(16))) unsigned char xs[4 * SLOT_B];   // [slot][split plane][halo voxel][32 channels]
   __shared__ __attribute__((aligned(16))) unsigned char ds[2 * DBUF_B];   // [buffer][split plane][voxel][32 channels]
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l32 = lane & 31;
+  const int lane = threadIdx.x & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool stager = wave8 >= 4;
+  const int wave = wave8 & 3;                 // of its role
+  const int tid = threadIdx.x & 255;          // thread of its role
   int vid;  // XCD-aware placement, (c-tile, o-tile) pair fastest: see conv3_mfma_bww2_kernel
   {
     const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
@@ -414,131 +420,147 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
   const int pair = vid % pairs, split = vid / pairs;
   const int ctile = pair % ctiles, otile = pair / ctiles;
   const int iHW = H * W, S = D * iHW;
-  const unsigned cstride = (unsigned)S * 4u;   // S < 2^24 (host check): 32 channels stay below 2^31 bytes
-
-  // thread-invariant part of the staging: item e of a halo plane = (halo voxel e / 4, 8-channel block e % 4).  The channel
-  // block runs fastest over the lanes, so a wave's 16-byte LDS writes of an item row are 1 KB contiguous (voxel-fastest
-  // they sat 64 bytes apart: 16 lanes on one bank, and the conflicted writes kept the LDS busy for 70 % of a tile --
-  // SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE); a global load instruction then covers 16 voxels of 4 channel
-  // blocks: four 64-byte runs.
-  int xrel[XPER], xdst[XPER];
-  unsigned xcode[XPER];
-#pragma unroll
-  for (int k = 0; k < XPER; ++k) {
-    const int e = tid + 256 * k;
-    const int cbl = e & 3, hv = e >> 2;
-    const int yy = hv / HR, xx = hv - yy * HR;
-    xrel[k] = cbl * 8 * S + yy * W + xx;
-    xdst[k] = e < XI ? hv * 64 + cbl * 16 : HP * 64 + (tid & 3) * 16;
-    xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
-  }
-  const int dv = tid >> 2, dcb = tid & 3;             // dy item: (voxel of the tile, 8-channel block)
-  const int dvy = dv / TX, dvx = dv - dvy * TX;
-  const int ddst = dv * 64 + dcb * 16;
 
   // tiles: z fastest inside a (sample, y tile, x tile) column; split s owns a contiguous range
   const int ntiles = N * ty_tiles * tx_tiles * D;
   const int per = ntiles / nsplit, rem = ntiles - per * nsplit;
   const int t_begin = split * per + min(split, rem), t_end = t_begin + per + (split < rem ? 1 : 0);
+  const int col0 = t_begin < t_end ? t_begin / D : 0;
+  int z = t_begin - col0 * D, buf = 0;        // of the tile being multiplied (both roles keep them)
 
-  // staging state of the column that is fetched from
-  __amdgpu_buffer_rsrc_t rx, rd;
-  unsigned ymask = 0u;
-  int colbase = 0, xlim = 0, dbase = 0;
-  bool dok = false;
-  auto column_setup = [&](int col) __attribute__((always_inline)) {
-    const int txt = col % tx_tiles;
-    const int c2 = col / tx_tiles;
-    const int tyt = c2 % ty_tiles, n = c2 / ty_tiles;
-    const int y0 = tyt * TY, x0 = txt * TX;
-    const int nbx = min(32, Cin - 32 * ctile), nbd = min(32, Cout - 32 * otile);
-    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)(32 * ctile) * S), 0,
-                                           nbx * S * 4, 0x00020000);
-    rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)(32 * otile) * S), 0,
-                                           nbd * S * 4, 0x00020000);
-    ymask = 0u;
-    for (int yy = 0; yy < TY + 2; ++yy)
-      if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ymask |= 1u << yy;
-    colbase = (y0 - 1) * W + x0 - 1;
-    xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
-    const int gy = y0 + dvy, gx = x0 + dvx;
-    dok = (gy < H) & (gx < W);
-    dbase = dcb * 8 * S + gy * W + gx;
-  };
-  auto fetch_plane = [&](float (&r)[XPER][8], int p, bool on) __attribute__((always_inline)) {   // halo plane p (absolute z, may lie outside) of the column
-    const bool pv = on && p >= 0 && p < D;
+  if (stager) {
+    // ------------------------------------------------------------------------------------------------ staging waves
+    const unsigned cstride = (unsigned)S * 4u;   // S < 2^24 (host check): 32 channels stay below 2^31 bytes
+    // thread-invariant part: item e of a halo plane = (halo voxel e / 4, 8-channel block e % 4).  The channel block runs
+    // fastest over the lanes, so a wave's 16-byte LDS writes of an item row are 1 KB contiguous (voxel-fastest they sat
+    // 64 bytes apart, 16 lanes on one bank: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE); a global load
+    // instruction then covers 16 voxels of 4 channel blocks: four 64-byte runs.
+    int xrel[XPER], xdst[XPER];
+    unsigned xcode[XPER];
 #pragma unroll
     for (int k = 0; k < XPER; ++k) {
-      const int xx = (int)(xcode[k] >> 16);
-      const bool ok = pv & (((xcode[k] & 0xffffu) & ~ymask) == 0u) & ((unsigned)(xlim + xx) < (unsigned)W);
-      const unsigned off = ok ? (unsigned)(colbase + p * iHW + xrel[k]) * 4u : OOB;
+      const int e = tid + 256 * k;
+      const int cbl = e & 3, hv = e >> 2;
+      const int yy = hv / HR, xx = hv - yy * HR;
+      xrel[k] = cbl * 8 * S + yy * W + xx;
+      xdst[k] = e < XI ? hv * 64 + cbl * 16 : HP * 64 + (tid & 3) * 16;
+      xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
+    }
+    const int dv = tid >> 2, dcb = tid & 3;             // dy item: (voxel of the tile, 8-channel block)
+    const int dvy = dv / TX, dvx = dv - dvy * TX;
+    const int ddst = dv * 64 + dcb * 16;
+
+    // staging state of the column that is fetched from
+    __amdgpu_buffer_rsrc_t rx, rd;
+    unsigned ymask = 0u;
+    int colbase = 0, xlim = 0, dbase = 0;
+    bool dok = false;
+    auto column_setup = [&](int col) __attribute__((always_inline)) {
+      const int txt = col % tx_tiles;
+      const int c2 = col / tx_tiles;
+      const int tyt = c2 % ty_tiles, n = c2 / ty_tiles;
+      const int y0 = tyt * TY, x0 = txt * TX;
+      const int nbx = min(32, Cin - 32 * ctile), nbd = min(32, Cout - 32 * otile);
+      rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)(32 * ctile) * S), 0, nbx * S * 4, 0x00020000);
+      rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)(32 * otile) * S), 0, nbd * S * 4, 0x00020000);
+      ymask = 0u;
+      for (int yy = 0; yy < TY + 2; ++yy)
+        if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ymask |= 1u << yy;
+      colbase = (y0 - 1) * W + x0 - 1;
+      xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
+      const int gy = y0 + dvy, gx = x0 + dvx;
+      dok = (gy < H) & (gx < W);
+      dbase = dcb * 8 * S + gy * W + gx;
+    };
+    auto fetch_plane = [&](float (&r)[XPER][8], int p, bool on) __attribute__((always_inline)) {   // halo plane p (absolute z, may lie outside)
+      const bool pv = on && p >= 0 && p < D;
+#pragma unroll
+      for (int k = 0; k < XPER; ++k) {
+        const int xx = (int)(xcode[k] >> 16);
+        const bool ok = pv & (((xcode[k] & 0xffffu) & ~ymask) == 0u) & ((unsigned)(xlim + xx) < (unsigned)W);
+        const unsigned off = ok ? (unsigned)(colbase + p * iHW + xrel[k]) * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          r[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + j * cstride, 0, 0));
+      }
+    };
+    auto fetch_dy = [&](float (&r)[8], int zz, bool on) __attribute__((always_inline)) {
+      const unsigned off = (on & dok) ? (unsigned)(dbase + zz * iHW) * 4u : OOB;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        r[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + j * cstride, 0, 0));
-    }
-  };
-  auto fetch_dy = [&](float (&r)[8], int z, bool on) __attribute__((always_inline)) {
-    const unsigned off = (on & dok) ? (unsigned)(dbase + z * iHW) * 4u : OOB;
+        r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
+    };
+    auto commit8 = [&](const float (&v)[8], unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {   // split + three 16-byte items
+      unsigned h[8], m[8], l[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
-  };
-  // half an item (channels 4 hf .. 4 hf + 3): the unit the steady-state prefetch is cut into (one per MFMA step)
-  auto fetch4_x = [&](float (&r)[8], int k, int hf, int p, bool on) __attribute__((always_inline)) {
-    const int xx = (int)(xcode[k] >> 16);
-    const bool ok = (on && p >= 0 && p < D) & (((xcode[k] & 0xffffu) & ~ymask) == 0u) & ((unsigned)(xlim + xx) < (unsigned)W);
-    const unsigned off = ok ? (unsigned)(colbase + p * iHW + xrel[k]) * 4u : OOB;
+      for (int c = 0; c < 8; ++c) x3_split(v[c], h[c], m[c], l[c]);
+      *(u32x4*)(dst) = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+      *(u32x4*)(dst + plane_bytes) = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+      *(u32x4*)(dst + 2 * plane_bytes) = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+    };
+    auto commit_plane = [&](const float (&r)[XPER][8], int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 4 * hf; j < 4 * hf + 4; ++j)
-      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + j * cstride, 0, 0));
-  };
-  auto fetch4_dy = [&](float (&r)[8], int hf, int z, bool on) __attribute__((always_inline)) {
-    const unsigned off = (on & dok) ? (unsigned)(dbase + z * iHW) * 4u : OOB;
-#pragma unroll
-    for (int j = 4 * hf; j < 4 * hf + 4; ++j)
-      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off + j * cstride, 0, 0));
-  };
-  auto commit8 = [&](const float (&v)[8], unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {   // split + three 16-byte items
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) x3_split(v[c], h[c], m[c], l[c]);
-    *(u32x4*)(dst) = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
-    *(u32x4*)(dst + plane_bytes) = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
-    *(u32x4*)(dst + 2 * plane_bytes) = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
-  };
-  auto commit_plane = [&](const float (&r)[XPER][8], int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < XPER; ++k) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
-  };
-  // half an item (channels 4 hf .. 4 hf + 3): the unit the steady-state commit is cut into
-  // (the first half only splits and keeps its six packed words; the second writes the three 16-byte items)
-  unsigned pk[3][2];
-  auto commit4 = [&](const float (&v)[8], int hf, unsigned char* dst, int plane_bytes) __attribute__((always_inline)) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) x3_split(v[4 * hf + c], h[c], m[c], l[c]);
-    const unsigned w[3][2] = {{x3_pack(h[0], h[1]), x3_pack(h[2], h[3])}, {x3_pack(m[0], m[1]), x3_pack(m[2], m[3])},
-                              {x3_pack(l[0], l[1]), x3_pack(l[2], l[3])}};
-    if (hf == 0) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) pk[pl][0] = w[pl][0], pk[pl][1] = w[pl][1];
-    } else {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *(u32x4*)(dst + pl * plane_bytes) = (u32x4){pk[pl][0], pk[pl][1], w[pl][0], w[pl][1]};
-    }
-  };
-  auto commit_dy = [&](const float (&r)[8], int buf) __attribute__((always_inline)) { commit8(r, ds + buf * DBUF_B + ddst, 4096); };
-  // start of a column / of this split's range: the three planes of tile z, loaded here and now (once per D tiles)
-  auto cold = [&](int z) __attribute__((always_inline)) {
-    float r0[XPER][8], r1[XPER][8], r2[XPER][8];
-    fetch_plane(r0, z - 1, true);
-    fetch_plane(r1, z, true);
-    fetch_plane(r2, z + 1, true);
-    commit_plane(r0, z & 3);
-    commit_plane(r1, (z + 1) & 3);
-    commit_plane(r2, (z + 2) & 3);
-  };
+      for (int k = 0; k < XPER; ++k) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
+    };
+    auto commit_dy = [&](const float (&r)[8], int b) __attribute__((always_inline)) { commit8(r, ds + b * DBUF_B + ddst, 4096); };
+    // start of a column / of this split's range: the three planes of tile zz, loaded here and now (once per D tiles)
+    auto cold = [&](int zz) __attribute__((always_inline)) {
+      float r0[XPER][8], r1[XPER][8], r2[XPER][8];
+      fetch_plane(r0, zz - 1, true);
+      fetch_plane(r1, zz, true);
+      fetch_plane(r2, zz + 1, true);
+      commit_plane(r0, zz & 3);
+      commit_plane(r1, (zz + 1) & 3);
+      commit_plane(r2, (zz + 2) & 3);
+    };
 
+    int pz = 0, pcol = col0;   // of the tile the loads are issued for; the staging state is that tile's column
+    float xr[XPER][8], dr[8];  // plane z + 2 and the dy tile of tile t + 1, in flight while tile t is multiplied
+    if (t_begin < t_end) {
+      column_setup(pcol);
+      cold(z);
+      float d0[8];
+      fetch_dy(d0, z, true);
+      commit_dy(d0, 0);
+      const bool more1 = t_begin + 1 < t_end;
+      pz = z + 1;
+      if (pz == D) {
+        pz = 0;
+        pcol += 1;
+        if (more1) column_setup(pcol);
+      }
+      fetch_plane(xr, pz + 1, more1 && pz != 0);   // (the planes of a new column are loaded by cold())
+      fetch_dy(dr, pz, more1);
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
+      // the data of tile + 1 (a tile in flight) into the slot no tap of tile z reads and the other dy buffer; unconditional:
+      // after the last tile and before a new column the registers hold zeros and their targets are rewritten before use
+      commit_plane(xr, (z + 3) & 3);
+      commit_dy(dr, buf ^ 1);
+      pz += 1;
+      if (pz == D) {   // (uniform; once per D tiles)
+        pz = 0;
+        pcol += 1;
+        if (more2) column_setup(pcol);
+      }
+      fetch_plane(xr, pz + 1, more2 && pz != 0);
+      fetch_dy(dr, pz, more2);
+      __syncthreads();   // the multiplying waves are done with tile z; tile z + 1 is in LDS
+      const bool newcol = z + 1 == D;
+      if (more1 && newcol) {   // (uniform) tile + 1 opens a column: its three planes, here and now.  The staging state is
+        cold(0);               // already that column's (tile + 2 lies in it as well: D >= 2, host check)
+        __syncthreads();
+      }
+      z = newcol ? 0 : z + 1;
+      buf ^= 1;
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- multiplying waves
+  const int half = lane >> 5, l32 = lane & 31;
   // transposed-read lane bases: lane 4q + p of a 16-lane group addresses voxel row q, channels 4p .. 4p+3 of its
   // group's 16-channel half; groups 2, 3 (the upper MFMA half) take the voxels 8 .. 15 of the k-step
   const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -558,56 +580,16 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // Two register sets alternate (the tile loop is unrolled by two): while tile t is multiplied, the set fetched during
-  // tile t - 1 -- plane z + 2 and the dy tile of tile t + 1 -- is committed, and the other set receives the loads of
-  // tile t + 2, which so have a whole tile (~4 us) to land: at 128^3 the operands come from HBM, and one tile of
-  // distance left the commit waiting on them (5.5 us per tile against 4.5 at 64^3).
-  int z = 0, buf = 0;     // of the tile being multiplied
-  int pz = 0, pcol = 0;   // of the tile the loads are issued for; the staging state (column_setup) is that tile's column
-  float xa[XPER][8], da8[8], xb[XPER][8], db8[8];
-  if (t_begin < t_end) {
-    pcol = t_begin / D;
-    z = t_begin - pcol * D;
-    column_setup(pcol);
-    cold(z);
-    float d0[8];
-    fetch_dy(d0, z, true);
-    commit_dy(d0, 0);
-    const bool more1 = t_begin + 1 < t_end;
-    pz = z + 1;
-    if (pz == D) {
-      pz = 0;
-      pcol += 1;
-      if (more1) column_setup(pcol);
-    }
-    fetch_plane(xa, pz + 1, more1 && pz != 0);   // (the planes of a new column are loaded by cold())
-    fetch_dy(da8, pz, more1);
-  }
-  __syncthreads();
-  auto body = [&](int tile, const float (&cx)[XPER][8], const float (&cd)[8], float (&lx)[XPER][8], float (&ld)[8])
-      __attribute__((always_inline)) {
+  __syncthreads();   // the first tile is in LDS
+  for (int tile = t_begin; tile < t_end; ++tile) {
     // fragment bases of THIS tile: tap plane dz -> ring slot (z + dz) & 3
     const unsigned char* xt[7];
 #pragma unroll
     for (int t = 0; t < 7; ++t) xt[t] = xs + tyx[t] + ((z + tdz[t]) & 3) * SLOT_B;
     const unsigned char* da = ds + buf * DBUF_B + lbA;
-    const bool more1 = tile + 1 < t_end, more2 = tile + 2 < t_end;
-    pz += 1;
-    if (pz == D) {   // (uniform; once per D tiles: the divisions of the setup stay out of the steady state)
-      pz = 0;
-      pcol += 1;
-      if (more2) column_setup(pcol);
-    }
-    const bool fx_on = more2 && pz != 0;   // (the planes of a new column are loaded by cold())
     // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
-    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one.  The LAST NU
-    // steps also carry the commit of the NEXT tile's plane / dy tile (register set c*, fetched one tile ago), one unit (4
-    // channels of an item: ~30 vector-ALU ops + 3 LDS writes) per step in the shadow of its MFMAs; it is unconditional
-    // -- after the last tile and before a new column the registers hold zeros and the slot they go to is rewritten
-    // before its next use.
+    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one
     {
-      unsigned char* xw = xs + ((z + 3) & 3) * SLOT_B;   // the slot no tap of tile z reads (plane z + 2 of this column)
-      unsigned char* dw_ = ds + (buf ^ 1) * DBUF_B + ddst;
       auto afrag = [&](int g, int pl) __attribute__((always_inline)) { return x3_tr_frag(da + pl * 4096 + g * 1024); };
       auto bfrag = [&](int g, int t, int pl) __attribute__((always_inline)) {
         const int goff = (TX == 32 ? (g >> 1) * HR + 16 * (g & 1) : (TX == 16 ? g * HR : 2 * g * HR)) * 64;
@@ -639,18 +621,6 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-        const int u = s - (28 - NU);   // commit unit of this step
-        if (u >= 0) {
-          if (u < 2 * XPER) commit4(cx[u >> 1], u & 1, xw + xdst[u >> 1], PLANE_B);
-          else commit4(cd, u & 1, dw_, 4096);
-        }
-        // ... and the FIRST NU steps the loads of tile t + 2, four dwords (half an item) per step: issued at the top of the
-        // tile, their ~250 instructions of address arithmetic and issue ran with the matrix pipe idle (one wave per SIMD)
-        const bool fu = s < NU;
-        if (fu) {
-          if (s < 2 * XPER) fetch4_x(lx[s >> 1], s >> 1, s & 1, pz + 1, fx_on);
-          else fetch4_dy(ld, s & 1, pz, more2);
-        }
         // the reads of the next step go out behind the first three MFMAs: three MFMAs of slack before their use
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -659,31 +629,16 @@ __global__ __launch_bounds__(256, 1) void conv3_bww_x3_kernel(
             if (na) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // fragment reads of the next step
             else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           }
-          if (u >= 0) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // vector ALU of the commit unit
-          if (fu && i >= 2) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               // address arithmetic of a load
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // the load
-          }
         }
-        if (u >= 0 && (u & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);   // the item's LDS writes
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();   // every wave is done reading this tile; the next one is in LDS
     const bool newcol = z + 1 == D;
-    if (more1 && newcol) {   // (uniform) tile + 1 opens a column: its three planes, here and now.  The staging state is
-      cold(0);               // already that column's (tile + 2 lies in it as well: D >= 2, host check)
-      __syncthreads();
-    }
+    if (tile + 1 < t_end && newcol) __syncthreads();   // (the staging waves load the three planes of the new column)
     z = newcol ? 0 : z + 1;
     buf ^= 1;
-  };
-  int tile = t_begin;
-  for (; tile + 1 < t_end; tile += 2) {
-    body(tile, xa, da8, xb, db8);
-    body(tile + 1, xb, db8, xa, da8);
   }
-  if (tile < t_end) body(tile, xa, da8, xb, db8);
 
   // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
   float* sl = slab + (int64_t)split * 27 * Cout * Cin;
@@ -753,7 +708,7 @@ int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* sl
                   int W, int64_t xbs, int64_t ybs, hipStream_t st) {
   const dim3 grid((unsigned)(p.ctiles * p.otiles * p.nsplit));
 #define M355_X3_BWW(TXV)                                                                                              \
-  hipLaunchKernelGGL((conv3_bww_x3_kernel<TXV>), grid, dim3(256), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, p.ty_tiles, \
+  hipLaunchKernelGGL((conv3_bww_x3_kernel<TXV>), grid, dim3(512), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, p.ty_tiles, \
                      p.tx_tiles, p.nsplit, p.ctiles, p.otiles, xbs, ybs);
   if (p.tx == 32) { M355_X3_BWW(32) } else if (p.tx == 16) { M355_X3_BWW(16) } else { M355_X3_BWW(8) }
 #undef M355_X3_BWW
