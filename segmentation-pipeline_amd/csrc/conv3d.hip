@@ -1953,12 +1953,12 @@ int pick_gx(int W) {
   return best;
 }
 
-// M355_COMPUTE_F32X3 (conv3d_f32x3.hip): 8-channel chunks must carry real channels, a 32-row tile real rows, and the
-// 8-channel slab of a sample must fit the 31-bit byte offsets its loads add up.  (The edge layers gain nothing from the
-// split kernel -- 4 -> 32 @128^3 forward 0.208 vs 0.212 ms, 3 -> 32 data gradient 0.202 vs 0.200: they are bound by the
-// one-tile-per-workgroup load -> multiply -> store chain and the 268 MB they write, not by the matrix pipe.)
+// M355_COMPUTE_F32X3 (conv3d_f32x3.hip): a 32-row tile must carry real rows, and the 8-channel slab of a sample must fit
+// the 31-bit byte offsets its loads add up.  The edge layers (4 -> 32 forward, 3 -> 32 data gradient @128^3: one chunk,
+// 4 / 3 of its 8 channels real) run 0.183 / 0.174 ms there against 0.21 / 0.19 on the fp32 MFMA; 0.06 ms of that is the
+// 268 MB they write, the rest the half-empty K of their MFMAs.
 static bool x3_layer(int kin, int mout, int D, int H, int W) {
-  return tuning().f32x3 && kin >= 8 && mout > 4 && (int64_t)D * H * W < (1ll << 26);
+  return tuning().f32x3 && kin >= 3 && mout > 4 && (int64_t)D * H * W < (1ll << 26);
 }
 
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
