@@ -70,8 +70,9 @@ enum { M355_F32 = 0 };
  *                     layers, within 2.5x of the fp32 MFMA kernels' (profiles/r04_f32x3_accuracy.txt; both carry the
  *                     error of an fp32 accumulation).  Applies to the 3x3x3 / stride 1 / pad 1 forward and data gradient of
  *                     layers with >= 3 K-channels and > 4 M-channels, and to the weight gradient of layers with > 4
- *                     channels on both sides, at least two z planes and < 2^24 voxels per sample; every other
- *                     descriptor and entry point treats it as M355_COMPUTE_F32.  This is what the host side's
+ *                     channels on both sides, at least two z planes and < 2^24 voxels per sample, and to the forward of
+ *                     the k = 2 / stride 2 conv-transpose (m355_conv_transpose3d_fwd); every other descriptor and entry
+ *                     point treats it as M355_COMPUTE_F32.  This is what the host side's
  *                     default precision "fp32" passes (ops.py); "fp32_mfma" passes M355_COMPUTE_F32.
  * The 16-bit modes apply to conv3d fwd, bwd_data and bwd_weight (the edge layers' weight gradient runs in exact fp32).
  * In the 16-bit modes the convolution kernels read their input in the "c8" layout
@@ -121,7 +122,7 @@ typedef struct m355_conv3d_desc {
   int32_t out_pad;          /* conv-transpose only */
   int64_t x_batch_stride;   /* elements; 0 = dense */
   int64_t y_batch_stride;   /* elements; 0 = dense */
-  int32_t compute;          /* M355_COMPUTE_* (3x3x3 / s1 / p1 only; ignored elsewhere) */
+  int32_t compute;          /* M355_COMPUTE_* (3x3x3 / s1 / p1; M355_COMPUTE_F32X3 also k2 s2 conv-transpose fwd; ignored elsewhere) */
   int32_t flags;            /* M355_CONV_* bits, 0 by default */
 } m355_conv3d_desc;
 

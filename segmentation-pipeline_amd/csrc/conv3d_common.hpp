@@ -162,6 +162,10 @@ struct BwwX3Plan {
 BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W);
 int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
                   int W, int64_t xbs, int64_t ybs, hipStream_t st);
+// ConvTranspose3d k2 s2 forward on the split (conv3d_f32x3.hip; caller: convt.hip)
+int convt_fwd_x3_nvt(int Cin);
+void launch_convt_fwd_x3(int nvt, dim3 grid, const float* x, const float* w, const float* bias, float* y, int Cin, int Cout,
+                         int D, int H, int W, int64_t xbs, int64_t ybs, int mt_per_wg, hipStream_t st);
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute = M355_COMPUTE_F32);
 
 // 16-bit operand convolution (conv3d_h16.hip).  in16: c8 layout (h16.hpp) with `in16_bs` ELEMENTS between

@@ -715,4 +715,161 @@ int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* sl
   return M355_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ ConvTranspose3d k2 s2, forward
+// Y[m, v] = bias[o] + sum_ci W[ci, m] * X[ci, v], m = o * 8 + t (convt.hip: every input voxel owns its 2x2x2 output block)
+// on the same split: the fp32-MFMA kernel (convt_k2s2_fwd_mfma_kernel) spends ~65 us of matrix-pipe time on the 64 -> 32
+// level @64^3 -> 128^3 against ~60 us of stores; here the pipe needs a third of that.  The [Cin][NVT] x tile is staged as
+// three bf16 planes of c8 items [plane][channel block][voxel] (loads coalesced along the voxels, 16-byte LDS writes and
+// fragment reads contiguous over the lanes); a wave walks 32-row m-tiles (4 output channels x 8 taps), splits its
+// weight fragment (8 input channels of a weight column, straight from L2) in registers -- once per (m-tile, 16-channel
+// chunk), used for 6 x NVT / 32 MFMAs -- and stores float2 pairs exactly as the fp32 kernel does.
+template <int NVT>
+__global__ __launch_bounds__(256) void convt_k2s2_fwd_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int Cin,
+    int Cout, int D, int H, int W, int64_t xbs, int64_t ybs, int mt_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs3_raw[];   // [plane][CB][NVT] x 16 B
+  u32x4* xs3 = reinterpret_cast<u32x4*>(xs3_raw);
+  constexpr int NG = NVT / 32, P = 256 / NVT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int S = D * H * W;
+  const int v0 = blockIdx.x * NVT;
+  const int n = blockIdx.z;
+  const float* xn = x + (int64_t)n * xbs;
+  float* yn = y + (int64_t)n * ybs;
+  const int CB = (Cin + 15) / 16 * 2;          // 8-channel blocks, whole 16-channel chunks
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t OS = (int64_t)S * 8;
+  {
+    const int sv = tid % NVT, part = tid / NVT;
+    const bool vin = v0 + sv < S;
+    const float* xp = xn + (vin ? v0 + sv : 0);
+    for (int cb = part; cb < CB; cb += P) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const bool ok = vin && c < Cin;
+        const float t = xp[ok ? (int64_t)c * S : 0];   // unconditional load from a clamped address
+        v[j] = ok ? t : 0.f;
+      }
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x3_split(v[j], h[j], m[j], l[j]);
+      xs3[(0 * CB + cb) * NVT + sv] = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+      xs3[(1 * CB + cb) * NVT + sv] = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+      xs3[(2 * CB + cb) * NVT + sv] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+    }
+  }
+  __syncthreads();
+  const int mtiles = (Cout + 3) / 4;
+  const int mt_begin = blockIdx.y * mt_per_wg, mt_end = min(mtiles, mt_begin + mt_per_wg);
+  const int wrow = Cout * 8;  // weight offsets fit 32 bits (host: convt_fits_i32)
+  int64_t obase[NG];          // output offsets of this lane's voxels (a = half)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int v = min(v0 + g * 32 + l32, S - 1);
+    const int ix = v % W, iy = (v / W) % H, iz = v / (W * H);
+    obase[g] = ((int64_t)(2 * iz + half) * OH + 2 * iy) * OW + 2 * ix;
+  }
+  // weights: the 8 channels (k0 + 8 half .. + 7) of weight column mt * 32 + l32, raw; the next chunk (possibly of the next
+  // m-tile) is in flight during the MFMAs of the current one.  Loads from clamped addresses, the zero mask at the split.
+  float a_nxt[8];
+  auto wload = [&](int mt, int k0) __attribute__((always_inline)) {
+    const int col = min(mt * 32 + l32, Cout * 8 - 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_nxt[j] = w[min(k0 + 8 * half + j, Cin - 1) * wrow + col];
+  };
+  bf16x8 ah, am, al;
+  auto wsplit = [&](int mt, int k0) __attribute__((always_inline)) {
+    const bool ook = mt * 4 + (l32 >> 3) < Cout;
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x3_split((ook && k0 + 8 * half + j < Cin) ? a_nxt[j] : 0.f, h[j], m[j], l[j]);
+    ah = __builtin_bit_cast(bf16x8, (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])});
+    am = __builtin_bit_cast(bf16x8, (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])});
+    al = __builtin_bit_cast(bf16x8, (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])});
+  };
+  const int nchunks = CB / 2;
+  int mt = mt_begin + wave;
+  if (mt < mt_end) {
+    wload(mt, 0);
+    wsplit(mt, 0);
+  }
+  while (mt < mt_end) {
+    const int o0 = mt * 4;
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const bool last = ch + 1 >= nchunks;
+      const int nmt = last ? mt + 4 : mt, nk0 = last ? 0 : (ch + 1) * 16;
+      if (nmt < mt_end) wload(nmt, nk0);
+      const u32x4* bp = xs3 + (2 * ch + half) * NVT + l32;
+      bf16x8 bh[NG], bm[NG], bl[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bh[g] = __builtin_bit_cast(bf16x8, bp[g * 32]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bm[g] = __builtin_bit_cast(bf16x8, bp[CB * NVT + g * 32]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bl[g] = __builtin_bit_cast(bf16x8, bp[2 * CB * NVT + g * 32]);
+      // (the small terms of a product group first; consecutive MFMAs write different accumulators)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
+      wsplit(nmt, nk0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // q = output channel inside the tile (r >> 2)
+      const int o = o0 + q;
+      if (o >= Cout) continue;
+      const float bv = bias ? bias[o] : 0.f;
+      float* yo = yn + (int64_t)o * OS;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (v0 + g * 32 + l32 >= S) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          *reinterpret_cast<float2*>(yo + obase[g] + (int64_t)b * OW) =
+              make_float2(acc[g][q * 4 + b * 2] + bv, acc[g][q * 4 + b * 2 + 1] + bv);
+      }
+    }
+    mt += 4;
+  }
+}
+
+// voxels per workgroup: the three planes of the x tile (6 bytes per element) within 64 KB, so that two workgroups share a CU
+int convt_fwd_x3_nvt(int Cin) {
+  const int64_t cin2 = round_up(Cin, 16);
+  for (int nvt : {128, 64, 32})
+    if (cin2 * nvt * 6 <= 65536) return nvt;
+  return 0;
+}
+
+void launch_convt_fwd_x3(int nvt, dim3 grid, const float* x, const float* w, const float* bias, float* y, int Cin, int Cout,
+                         int D, int H, int W, int64_t xbs, int64_t ybs, int mt_per_wg, hipStream_t st) {
+  const size_t lds = (size_t)round_up(Cin, 16) * nvt * 6;
+#define M355_CONVT_X3(NVT) \
+  hipLaunchKernelGGL(convt_k2s2_fwd_x3_kernel<NVT>, grid, dim3(256), lds, st, x, w, bias, y, Cin, Cout, D, H, W, xbs, ybs, mt_per_wg)
+  switch (nvt) {
+    case 128: M355_CONVT_X3(128); break;
+    case 64: M355_CONVT_X3(64); break;
+    default: M355_CONVT_X3(32); break;
+  }
+#undef M355_CONVT_X3
+}
+
 }  // namespace m355

@@ -16,6 +16,11 @@ namespace m355 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// the k2s2 forward of M355_COMPUTE_F32X3 (conv3d_f32x3.hip)
+int convt_fwd_x3_nvt(int Cin);
+void launch_convt_fwd_x3(int nvt, dim3 grid, const float* x, const float* w, const float* bias, float* y, int Cin, int Cout,
+                         int D, int H, int W, int64_t xbs, int64_t ybs, int mt_per_wg, hipStream_t st);
+
 // =============================== k2s2 as fp32-MFMA GEMMs ===============================
 // Every input voxel owns its 2x2x2 output block, so with t = a*4 + b*2 + c (the position
 // inside the block) and m = o*8 + t:
@@ -1181,7 +1186,9 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
   M355_REQUIRE(OD > 0 && OH > 0 && OW > 0, M355_EINVALID_ARG, "conv_transpose3d_fwd: empty output");
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
-  const int nvt = convt_fwd_nvt(d);
+  // M355_COMPUTE_F32X3: the same GEMM on the bf16 matrix pipe through the exact three-way operand split (conv3d_f32x3.hip)
+  const bool x3 = d->compute == M355_COMPUTE_F32X3 && tuning().f32x3 && convt_fwd_x3_nvt(d->Cin) != 0;
+  const int nvt = x3 ? convt_fwd_x3_nvt(d->Cin) : convt_fwd_nvt(d);
   if (is_k2s2(d) && nvt && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;
     const int64_t vox_tiles = ceil_div(S, nvt) * d->N;
@@ -1190,6 +1197,10 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
     const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, vox_tiles), ceil_div(mtiles, 4)));
     const int mt_per_wg = (int)round_up(ceil_div(mtiles, groups), 4);
     dim3 grid((unsigned)ceil_div(S, nvt), (unsigned)ceil_div(mtiles, mt_per_wg), (unsigned)d->N);
+    if (x3) {
+      launch_convt_fwd_x3(nvt, grid, x, w, bias, y, d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, mt_per_wg, st);
+      return check_launch("convt_k2s2_fwd_x3");
+    }
     const size_t lds = (size_t)round_up(d->Cin, 16) * nvt * 4;
 #define M355_CONVT_FWD(NVT)                                                                                   \
   hipLaunchKernelGGL(convt_k2s2_fwd_mfma_kernel<NVT>, grid, dim3(256), lds, st, x, w, bias, y, d->Cin, d->Cout, \

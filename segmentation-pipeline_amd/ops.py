@@ -1355,7 +1355,8 @@ class _ConvT3dFn(torch.autograd.Function):
         oshape = (N, Cout, od(D), od(H), od(W))
         y = _alloc_out(out, oshape, x)
         y, ybs = _dense_channels(y)
-        d = _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad)
+        # (the fp32 entry points honour M355_COMPUTE_F32X3 -- the k2 s2 forward on the split kernels -- and ignore the 16-bit codes)
+        d = _conv_desc(N, Cin, Cout, D, H, W, k, stride, pad, xbs, ybs, out_pad, compute=_COMPUTE[_compute_mode])
         ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(d)), x.device)
         check(L.m355_conv_transpose3d_fwd(C.byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws), ws.numel(),
                                           _stream()), "conv_transpose3d_fwd")
@@ -1369,11 +1370,11 @@ class _ConvT3dFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         d = ctx.desc
         dy, dybs = _dense_channels(dy)
-        d = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.x_batch_stride, dybs, d.out_pad)
+        d = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, d.x_batch_stride, dybs, d.out_pad, compute=d.compute)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.Cin, d.D, d.H, d.W), dtype=x.dtype, device=x.device)
-            dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, dybs, d.out_pad)
+            dd = _conv_desc(d.N, d.Cin, d.Cout, d.D, d.H, d.W, d.k, d.stride, d.pad, 0, dybs, d.out_pad, compute=d.compute)
             ws = _workspace(L.m355_conv_transpose3d_workspace(C.byref(dd)), x.device)
             check(L.m355_conv_transpose3d_bwd_data(C.byref(dd), _p(dy), _p(weight), _p(dx), _p(ws), ws.numel(),
                                                    _stream()), "conv_transpose3d_bwd_data")

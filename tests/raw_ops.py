@@ -433,10 +433,10 @@ class RawOps:
                                                self._stream()), "conv3d_bwd_weight")
         return dw, db
 
-    def convt_fwd(self, x, w, bias=None, stride=2, pad=0, out_pad=0):
+    def convt_fwd(self, x, w, bias=None, stride=2, pad=0, out_pad=0, compute=0):
         x, w, bias = map(self.to, (x, w, bias))
         k = w.shape[2]
-        d = self.conv_desc(x.shape, w.shape[1], k, stride, pad, out_pad)
+        d = self.conv_desc(x.shape, w.shape[1], k, stride, pad, out_pad, compute=compute)
         od = lambda n: (n - 1) * stride - 2 * pad + k + out_pad
         y = self.empty(x.shape[0], w.shape[1], od(x.shape[2]), od(x.shape[3]), od(x.shape[4]))
         ws = self._ws("conv_transpose3d_workspace", d)

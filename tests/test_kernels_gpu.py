@@ -443,6 +443,24 @@ def test_conv_transpose3d_fwd_bwd(hip, oracle, case):
     close(db_h, db_o, 3e-5, 1e-4, what="dbias")
 
 
+def test_conv_transpose3d_k2s2_forward_on_the_split_kernel(hip, oracle):
+    """M355_COMPUTE_F32X3 on the fp32 conv-transpose entry point: the k2 s2 forward as six bf16 MFMAs per product group
+    on the exact three-way operand split (convt_k2s2_fwd_x3_kernel) -- every voxel-tile width (Cin 64 / 130 / 320),
+    ragged channel counts and voxel tiles, N = 2, a concat-slot output stride; against the oracle at the fp32 kernel's
+    tolerance and against fp64 next to the fp32 MFMA kernel."""
+    import torch.nn.functional as F
+    for (N, ci, co, D, H, W) in [(1, 64, 64, 8, 8, 16), (2, 17, 5, 3, 5, 7), (1, 320, 320, 4, 4, 4), (1, 130, 70, 2, 9, 20),
+                                 (1, 8, 8, 1, 1, 1), (2, 32, 33, 6, 6, 6)]:
+        x, w, b = rnd(N, ci, D, H, W, seed=1), rnd(ci, co, 2, 2, 2, seed=2) * (1.0 / ci ** 0.5), rnd(co, seed=3)
+        y3 = hip.convt_fwd(x, w, b, compute=X3)
+        close(y3, oracle.convt_fwd(x, w, b, 2, 0, 0), what=f"fwd {ci}->{co}")
+        close(hip.convt_fwd(x, w, None, compute=X3), oracle.convt_fwd(x, w, None, 2, 0, 0), what="fwd nobias")
+        ref = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=2)
+        e3 = float((y3.cpu().double() - ref).abs().max() / ref.abs().max())
+        e0 = float((hip.convt_fwd(x, w, b).cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e3 <= max(3.0 * e0, 2e-6) and e3 < 3e-6, (ci, co, e3, e0)
+
+
 NORM = [
     # N, C, D, H, W, groups, act
     (1, 32, 16, 16, 16, 8, 1),

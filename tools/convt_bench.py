@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-level timing of the k=2,s=2 ConvTranspose3d kernels (HBM-bound) through the C ABI.
 Reports the achieved fraction of HBM bandwidth on the algorithmic bytes (x + y once each).
-usage: python tools/convt_bench.py"""
+usage: python tools/convt_bench.py [--f32x3]   (--f32x3: M355_COMPUTE_F32X3, the split kernels where they exist)"""
 import os
 import sys
 import torch
@@ -17,6 +17,7 @@ LEVELS = [("u0", 64, 64, 64), ("u1", 128, 128, 32), ("u2", 256, 256, 16), ("u3",
 
 def main():
     hip = RawOps("hip")
+    compute = 3 if "--f32x3" in sys.argv else 0
     print(f"{'level':6s} {'Cin':>4s} {'Cout':>4s} {'S':>4s} " + " ".join(f"{o + ' ms':>14s} {'GB/s':>7s}" for o in
                                                                       ("fwd", "bwd_data", "bwd_weight")))
     tot = [0.0, 0.0, 0.0]
@@ -27,7 +28,7 @@ def main():
         dy = torch.randn(1, co, 2 * sp, 2 * sp, 2 * sp, device="cuda")
         nbytes = 4.0 * (x.numel() + dy.numel())
         row = f"{name:6s} {ci:4d} {co:4d} {sp:4d} "
-        for i, fn in enumerate((lambda: hip.convt_fwd(x, w, b), lambda: hip.convt_bwd_data(dy, w, x.shape),
+        for i, fn in enumerate((lambda: hip.convt_fwd(x, w, b, compute=compute), lambda: hip.convt_bwd_data(dy, w, x.shape),
                                 lambda: hip.convt_bwd_weight(x, dy, 2))):
             ms = timeit(fn, 10)
             tot[i] += ms
