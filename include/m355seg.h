@@ -69,7 +69,7 @@ enum { M355_F32 = 0 };
  *                     as accurate as fp32 arithmetic is: max error 2e-7 .. 1.5e-6 of max |result| on the BASELINE
  *                     layers, within 2.5x of the fp32 MFMA kernels' (profiles/r04_f32x3_accuracy.txt; both carry the
  *                     error of an fp32 accumulation).  Applies to the 3x3x3 / stride 1 / pad 1 forward and data gradient of
- *                     layers with >= 3 K-channels and > 4 M-channels, and to the weight gradient of layers with > 4
+ *                     layers with >= 8 K-channels and > 4 M-channels, and to the weight gradient of layers with > 4
  *                     channels on both sides, at least two z planes and < 2^24 voxels per sample, and to the forward of
  *                     the k = 2 / stride 2 conv-transpose (m355_conv_transpose3d_fwd); every other descriptor and entry
  *                     point treats it as M355_COMPUTE_F32.  This is what the host side's

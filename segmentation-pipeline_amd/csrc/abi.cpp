@@ -29,6 +29,8 @@ static Tuning read_tuning() {
   t.smallcout_valu = env_int("M355_SMALLCOUT_VALU", 1);
   t.f32x3 = env_int("M355_F32X3", 1);
   t.f32x3_bww = env_int("M355_F32X3_BWW", 1);
+  t.f32x3_edge = env_int("M355_F32X3_EDGE", 0);
+  t.f32x3_convt = env_int("M355_F32X3_CONVT", 1);
   t.bww_nsplit = env_int("M355_BWW_NSPLIT", 0);
   t.bww_gen = env_int("M355_BWW_GEN", 2);
   t.bww_queue = env_int("M355_BWW_QUEUE", 1);

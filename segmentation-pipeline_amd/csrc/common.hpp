@@ -74,6 +74,8 @@ struct Tuning {
   int fuse_softmax = 1;
   int f32x3 = 1;         // M355_COMPUTE_F32X3 layers run conv3_f32x3_kernel (0: they run the fp32 MFMA kernels)
   int f32x3_bww = 1;     // ... and conv3_bww_x3_kernel for the weight gradient
+  int f32x3_edge = 0;    // 1: the split kernel also for layers with 3..7 K-channels (M355_F32X3_EDGE; see x3_layer)
+  int f32x3_convt = 1;   // ... and convt_k2s2_fwd_x3_kernel for the k2 s2 conv-transpose forward
   int convt_wgs = 0;     // c8 conv-transpose kernels: workgroups per CU of the persistent grids (0 = built-in)
   int h16_stagger = 2;   // 16-bit conv kernel: start offset of the odd workgroup of a CU, in units of 1024 cycles
 };

@@ -1954,11 +1954,13 @@ int pick_gx(int W) {
 }
 
 // M355_COMPUTE_F32X3 (conv3d_f32x3.hip): a 32-row tile must carry real rows, and the 8-channel slab of a sample must fit
-// the 31-bit byte offsets its loads add up.  The edge layers (4 -> 32 forward, 3 -> 32 data gradient @128^3: one chunk,
-// 4 / 3 of its 8 channels real) run 0.183 / 0.174 ms there against 0.21 / 0.19 on the fp32 MFMA; 0.06 ms of that is the
-// 268 MB they write, the rest the half-empty K of their MFMAs.
+// the 31-bit byte offsets its loads add up.  Layers with 3..7 K-channels (4 -> 32 forward, 3 -> 32 data gradient @128^3:
+// one chunk, 4 / 3 of its 8 channels real) run 0.183 / 0.174 ms on the split kernel against 0.21 / 0.19 on the fp32 MFMA
+// (0.06 ms of that is the 268 MB they write, the rest the half-empty K of their MFMAs) -- behind M355_F32X3_EDGE=1, off
+// by default: with the FIRST layer of the net on the split kernel one voxel of the 2.1 M of the bench volume (a near-tie
+// of two class probabilities) takes the other side of the CPU reference's argmax; with it on the fp32 MFMA none does.
 static bool x3_layer(int kin, int mout, int D, int H, int W) {
-  return tuning().f32x3 && kin >= 3 && mout > 4 && (int64_t)D * H * W < (1ll << 26);
+  return tuning().f32x3 && kin >= (tuning().f32x3_edge ? 3 : 8) && mout > 4 && (int64_t)D * H * W < (1ll << 26);
 }
 
 FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {

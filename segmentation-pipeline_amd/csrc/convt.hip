@@ -1187,7 +1187,7 @@ extern "C" int m355_conv_transpose3d_fwd(const m355_conv3d_desc* d, const float*
   const int64_t xbs = dense_or(d->x_batch_stride, (int64_t)d->Cin * d->D * d->H * d->W);
   const int64_t ybs = dense_or(d->y_batch_stride, (int64_t)d->Cout * OD * OH * OW);
   // M355_COMPUTE_F32X3: the same GEMM on the bf16 matrix pipe through the exact three-way operand split (conv3d_f32x3.hip)
-  const bool x3 = d->compute == M355_COMPUTE_F32X3 && tuning().f32x3 && convt_fwd_x3_nvt(d->Cin) != 0;
+  const bool x3 = d->compute == M355_COMPUTE_F32X3 && tuning().f32x3 && tuning().f32x3_convt && convt_fwd_x3_nvt(d->Cin) != 0;
   const int nvt = x3 ? convt_fwd_x3_nvt(d->Cin) : convt_fwd_nvt(d);
   if (is_k2s2(d) && nvt && (ybs % 2 == 0) && ((uintptr_t)y & 7) == 0 && convt_fits_i32(d)) {
     const int64_t S = (int64_t)d->D * d->H * d->W;

@@ -16,8 +16,8 @@ from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ConvDesc, NormDesc, check
 
 # Arithmetic of the 3x3x3 convolutions:
-#   "fp32" (default)  fp32 tensors, fp32 results.  The 3x3x3 convolutions with > 4 output channels (forward / data gradient;
-#                     weight gradient: > 4 channels on both sides) run on the bf16 matrix pipe: every operand is split EXACTLY into three bf16
+#   "fp32" (default)  fp32 tensors, fp32 results.  The 3x3x3 convolutions with >= 8 input and > 4 output channels (forward / data
+#                     gradient; weight gradient: > 4 channels on both sides) and the k2 s2 conv-transpose forward run on the bf16 matrix pipe: every operand is split EXACTLY into three bf16
 #                     values (8 + 8 + 8 significant bits) and six plane products per fp32 product are accumulated in fp32
 #                     (M355_COMPUTE_F32X3, csrc/conv3d_f32x3.hip) -- measured against fp64 as accurate as the fp32 MFMA
 #                     kernels (the error of both is the fp32 accumulation's), 1.5-1.7x their rate; the output conv and the

@@ -76,7 +76,7 @@ CONV3_X3 = [
 
 
 @pytest.mark.parametrize("case", CONV3_X3)
-def test_conv3d_f32x3_fwd_bwd(hip, oracle, case):
+def test_conv3d_f32x3_fwd_bwd(hip, oracle, case, tuning):
     """M355_COMPUTE_F32X3 (what precision "fp32" runs on the wide layers): forward (bias + residual), data gradient and
     weight gradient against the C oracle at the fp32 kernels' tolerances, and -- measured against an fp64 convolution --
     as accurate as fp32 arithmetic is: max error within 3x of the fp32 MFMA kernels' and below 2e-6 of max |result| (both
@@ -84,6 +84,7 @@ def test_conv3d_f32x3_fwd_bwd(hip, oracle, case):
     products are below 2^-24 of each product; the split kernels add six partial products per 16 k-values to the accumulator
     where the fp32 MFMA adds eight)."""
     N, Ci, Co, D, H, W = case
+    tuning(M355_F32X3_EDGE=1)   # (3..7 K-channels on the split kernel too: opt-in, see x3_layer in conv3d.hip)
     plan = hip.conv_plan((N, Ci, D, H, W), Co, compute=X3)
     assert plan[0] == 7, f"expected conv3_f32x3_kernel for {case}, got family {plan}"
     # (a single z plane has no ring to walk: the weight gradient stays on the fp32 MFMA kernel)
