@@ -23,4 +23,11 @@ for (n, ci, co, d, h, w) in ((1, 32, 32, 16, 16, 32), (2, 8, 40, 9, 7, 33), (1, 
     plan = hip.conv_plan(x.shape, co, compute=3)
     print(f"{(n, ci, co, d, h, w)} plan {plan}: fwd err fp32 {out[0][0]:.2e} x3 {out[3][0]:.2e} | bwd_data err fp32 {out[0][1]:.2e} x3 {out[3][1]:.2e}", flush=True)
     assert out[3][0] < 3e-6 and out[3][1] < 3e-6
+# the k2 s2 conv-transpose forward on the split (convt_k2s2_fwd_x3_kernel)
+for (n, ci, co, d, h, w) in ((1, 64, 64, 8, 8, 16), (2, 17, 5, 3, 5, 7), (1, 320, 320, 4, 4, 4), (1, 130, 70, 2, 9, 20)):
+    x, wt, b = torch.randn(n, ci, d, h, w), torch.randn(ci, co, 2, 2, 2) / ci ** 0.5, torch.randn(co)
+    ref = F.conv_transpose3d(x.double(), wt.double(), b.double(), stride=2)
+    e = {c: float((hip.convt_fwd(x, wt, b, compute=c).cpu().double() - ref).abs().max() / ref.abs().max()) for c in (0, 3)}
+    print(f"conv-transpose k2s2 {(n, ci, co, d, h, w)}: fwd err fp32 {e[0]:.2e} x3 {e[3]:.2e}", flush=True)
+    assert e[3] < 3e-6
 print("ok")
