@@ -209,75 +209,6 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_fwd_kernel(
   }
 }
 
-// ---- 16-row output tile (v_mfma_f32_16x16x4_f32) for the remainder of channel counts that are no multiple of
-// 32 (the reference's real widths are 40 / 80 / 120: research/msseg2/msseg2.py:87, main_config.py:123-127;
-// a 32-row tile for 8 remaining channels is 75 % padding).  Same flop rate as the 32x32x2 form; the K-step of 4
-// is exactly one 4-channel LDS chunk at a tap.  C/D layout: col = lane & 15 (voxel), row = 4 * (lane >> 4) + reg.
-// A 32-voxel group is two MFMAs (x-halves h2); acc[g][h2] holds 4 channels of one voxel per lane.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int NTW, int GX>
-__device__ __forceinline__ void store_conv_tile16(const f32x4v (&acc)[NTW][2], float* __restrict__ dst,
-                                                  const float* __restrict__ addp, const float* __restrict__ bias,
-                                                  int o0, int Cout, int z, int y0, int x0, int lane, int D, int H, int W,
-                                                  float* __restrict__ stat) {
-  constexpr int GY = 32 / GX;
-  const int64_t HW = (int64_t)H * W, DHW = HW * D;
-  const int ob = o0 + 4 * (lane >> 4);
-  float bb[4], s1[4], s2[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    bb[r] = (bias && ob + r < Cout) ? bias[ob + r] : 0.f;
-    s1[r] = s2[r] = 0.f;
-  }
-#pragma unroll
-  for (int g = 0; g < NTW; ++g)
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int vox = 16 * h2 + (lane & 15);
-      const int yg = y0 + g * GY + vox / GX, xg = x0 + vox % GX;
-      const bool ok = z < D && yg < H && xg < W;
-      const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[g][h2][r] + bb[r];
-      if (addp) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += addp[(ok && ob + r < Cout) ? base + (int64_t)r * DHW : 0];
-      }
-      if (stat) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = ok ? v[r] : 0.f;
-          s1[r] += t;
-          s2[r] = fmaf(t, t, s2[r]);
-        }
-      }
-      if (ok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ob + r < Cout) dst[base + (int64_t)r * DHW] = v[r];
-      }
-    }
-  if (stat) {  // sum over the 16 lanes (voxels) of each channel quad, fixed order
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) {
-        s1[r] += __shfl_xor(s1[r], off, 64);
-        s2[r] += __shfl_xor(s2[r], off, 64);
-      }
-    }
-    if ((lane & 15) == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (ob + r < Cout) {
-          stat[(int64_t)(ob + r) * 2] = s1[r];
-          stat[(int64_t)(ob + r) * 2 + 1] = s2[r];
-        }
-    }
-  }
-}
-
 // ---- persistent variant of conv3_mfma_fwd_kernel ----
 // A workgroup of the kernel above lives for nchunks/ksplit chunks and pays ~2.5 chunks of fixed
 // cost around them (measured: 8-chunk layers reach 112 TFLOP/s, 48-chunk layers 140): the first
@@ -1979,7 +1910,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   p.otiles = p.mout_pad / 32;
   // fp32: a remainder of 1..16 channels runs as ONE 16-row tile on v_mfma_f32_16x16x4_f32 (half the MFMA time of a
   // padded 32-row tile): 40 channels = 32 + 16 rows instead of 64, 80 = 64 + 16 instead of 96
-  p.tile16 = (!h16 && !x3 && tuning().tile16 && mout % 32 >= 1 && mout % 32 <= 16) ? 1 : 0;
+  p.tile16 = (!h16 && tuning().tile16 && mout % 32 >= 1 && mout % 32 <= 16) ? 1 : 0;   // (split kernels: conv3_f32x3_m16_kernel)
   if (p.tile16) p.otiles -= 1;
   const int wtiles = p.otiles + p.tile16;   // workgroup items per spatial tile
   p.nchunks = p.kin_pad / cc;
@@ -2055,7 +1986,7 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
       if (force_ntw && ntw != force_ntw && force_ntw != 8) continue;
       const int ty = ntw * gy;
       if (ty > H && ntw > 1 && !force_ntw) continue;
-      const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * p.otiles * N;
+      const int64_t base_wg = (int64_t)p.tz_tiles * ceil_div(H, ty) * p.tx_tiles * (p.otiles + p.tile16) * N;   // (a 16-row item: half the time)
       const double chunk_us = 14.0 * 6.0 * ntw * 32.0 / 1600.0 / (ntw >= 4 ? 1.0 : ntw == 2 ? 0.9 : 0.75);
       for (int ks = 1; ks <= std::min(p.nchunks, 8); ++ks) {
         if (ks > 1 && (ks - 1) * ceil_div(p.nchunks, ks) >= p.nchunks) continue;
@@ -2146,7 +2077,8 @@ FwdPlan plan_mfma(int N, int kin, int mout, int D, int H, int W, int compute) {
   }
   // packed weights + 256 B for the work counter of the persistent kernel
   p.wp_bytes = (size_t)round_up((int64_t)p.kin_pad * 27 * p.mout_pad * (h16 ? 2 : 4), 256) + 256;
-  if (x3) p.wp_bytes = (size_t)p.otiles * p.nchunks * (14 * 3 * 1024) + 256;   // [tile][chunk][pair][plane][lane] x 16 B
+  if (x3)   // [tile][chunk][pair][plane][lane] x 16 B, then the 16-row tile's [chunk][quad][plane][lane] x 16 B
+    p.wp_bytes = (size_t)p.otiles * p.nchunks * (14 * 3 * 1024) + (size_t)p.tile16 * p.nchunks * (7 * 3 * 1024) + 256;
   p.slab_bytes = ksplit > 1 ? (size_t)ksplit * N * mout * D * H * W * 4 : 0;
   return p;
 }
@@ -2592,6 +2524,7 @@ extern "C" int m355_conv3d_pack_batch(const m355_pack_item* items, int32_t n, vo
       e.Cin = d->Cin;
       e.nchunks = p.nchunks;
       e.otiles = p.otiles;
+      e.tile16 = p.tile16;
       e.transpose = it.which == 1;
       if (nb3 == PACK_BATCH) {
         launch_pack_x3_batch(b3, nb3, st);

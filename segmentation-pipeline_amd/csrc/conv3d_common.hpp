@@ -147,6 +147,75 @@ struct FwdPlan {
   size_t wp_bytes, slab_bytes;
 };
 
+// ---- 16-row output tile (v_mfma_f32_16x16x4_f32) for the remainder of channel counts that are no multiple of
+// 32 (the reference's real widths are 40 / 80 / 120: research/msseg2/msseg2.py:87, main_config.py:123-127;
+// a 32-row tile for 8 remaining channels is 75 % padding).  Same flop rate as the 32x32x2 form; the K-step of 4
+// is exactly one 4-channel LDS chunk at a tap.  C/D layout: col = lane & 15 (voxel), row = 4 * (lane >> 4) + reg.
+// A 32-voxel group is two MFMAs (x-halves h2); acc[g][h2] holds 4 channels of one voxel per lane.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NTW, int GX>
+__device__ __forceinline__ void store_conv_tile16(const f32x4v (&acc)[NTW][2], float* __restrict__ dst,
+                                                  const float* __restrict__ addp, const float* __restrict__ bias,
+                                                  int o0, int Cout, int z, int y0, int x0, int lane, int D, int H, int W,
+                                                  float* __restrict__ stat) {
+  constexpr int GY = 32 / GX;
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  const int ob = o0 + 4 * (lane >> 4);
+  float bb[4], s1[4], s2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bb[r] = (bias && ob + r < Cout) ? bias[ob + r] : 0.f;
+    s1[r] = s2[r] = 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int vox = 16 * h2 + (lane & 15);
+      const int yg = y0 + g * GY + vox / GX, xg = x0 + vox % GX;
+      const bool ok = z < D && yg < H && xg < W;
+      const int64_t base = ok ? (int64_t)ob * DHW + (int64_t)z * HW + (int64_t)yg * W + xg : 0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[g][h2][r] + bb[r];
+      if (addp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += addp[(ok && ob + r < Cout) ? base + (int64_t)r * DHW : 0];
+      }
+      if (stat) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = ok ? v[r] : 0.f;
+          s1[r] += t;
+          s2[r] = fmaf(t, t, s2[r]);
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < Cout) dst[base + (int64_t)r * DHW] = v[r];
+      }
+    }
+  if (stat) {  // sum over the 16 lanes (voxels) of each channel quad, fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        s1[r] += __shfl_xor(s1[r], off, 64);
+        s2[r] += __shfl_xor(s2[r], off, 64);
+      }
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ob + r < Cout) {
+          stat[(int64_t)(ob + r) * 2] = s1[r];
+          stat[(int64_t)(ob + r) * 2 + 1] = s2[r];
+        }
+    }
+  }
+}
+
 int pick_gx(int W);
 inline bool is16(int compute) { return compute == M355_COMPUTE_BF16 || compute == M355_COMPUTE_F16; }
 // M355_COMPUTE_F32X3 (conv3d_f32x3.hip): split + fragment-ordered weights, and the kernel launch of a plan with x3 != 0
@@ -201,7 +270,7 @@ struct X3PackEntry {
   const float* w;
   void* wq;
   int Cout, Cin;      // of the weight tensor
-  int nchunks, otiles, transpose;
+  int nchunks, otiles, tile16, transpose;
   int blk0, nblk;
 };
 struct X3PackBatch {

@@ -29,6 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_PAIRS = 14;
+constexpr int X3_QUADS = 7;   // 16-row tile (conv3_f32x3_m16_kernel): K = 32 = 8 channels x 4 taps, tap 4 q + (lane >> 4)
 // tap (dz*9 + dy*3 + dx) of lane half `half` of pair `pair`; -1 = no tap (zero weights)
 //   pairs 0..8   (dz, dy) = (pair / 3, pair % 3): dx = 0 | 1         -> the halves are one voxel apart along x
 //   pairs 9..11  dz = pair - 9, dx = 2: dy = 0 | 1                   -> one tile row apart
@@ -77,18 +78,54 @@ __device__ __forceinline__ void pack_w3_x3_item(const float* __restrict__ w, u32
   dst[128] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
 }
 
-__global__ void pack_w3_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cout_w, int Cin_w, int kin,
-                                  int mout, int nchunks, int otiles, int transpose) {
-  const int64_t total = (int64_t)otiles * nchunks * X3_PAIRS * 64;
+// the 16-row remainder tile (conv3_f32x3_m16_kernel), behind the 32-row tiles' region:
+// wq16[((ch * 7 + quad) * 3 + plane) * 64 + lane] = 8 bf16: the channels 8 ch .. 8 ch + 7 of output channel o16 + (lane & 15)
+// at tap 4 quad + (lane >> 4) (tap 27: zeros)
+__device__ __forceinline__ void pack_w3_x3_item16(const float* __restrict__ w, u32x4* __restrict__ wq16, int64_t i, int Cout_w,
+                                                  int Cin_w, int kin, int mout, int o16, int transpose) {
+  const int lane = (int)(i & 63);
+  const int64_t f = i >> 6;
+  const int quad = (int)(f % X3_QUADS), ch = (int)(f / X3_QUADS);
+  const int o = o16 + (lane & 15);
+  const int tap = 4 * quad + (lane >> 4);
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = ch * 8 + j;
+    float v = 0.f;
+    if (tap < 27 && o < mout && c < kin)
+      v = transpose ? w[((int64_t)c * Cin_w + o) * 27 + (26 - tap)] : w[((int64_t)o * Cin_w + c) * 27 + tap];
+    x3_split(v, h[j], m[j], l[j]);
+  }
+  u32x4* dst = wq16 + f * 3 * 64 + lane;
+  dst[0] = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+  dst[64] = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+  dst[128] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+}
+
+// items [0, n32) are the 32-row tiles', [n32, n32 + n16) the 16-row tile's
+__device__ __forceinline__ void pack_w3_x3_any(const float* __restrict__ w, u32x4* __restrict__ wq, int64_t i, int Cout_w, int Cin_w,
+                                               int nchunks, int otiles, int tile16, int transpose) {
+  const int kin = transpose ? Cout_w : Cin_w, mout = transpose ? Cin_w : Cout_w;
+  const int64_t n32 = (int64_t)otiles * nchunks * X3_PAIRS * 64;
+  if (i < n32) pack_w3_x3_item(w, wq, i, Cout_w, Cin_w, kin, mout, nchunks, transpose);
+  else if (tile16) pack_w3_x3_item16(w, wq + n32 * 3, i - n32, Cout_w, Cin_w, kin, mout, otiles * 32, transpose);
+}
+__host__ __device__ inline int64_t x3_pack_items(int nchunks, int otiles, int tile16) {
+  return (int64_t)otiles * nchunks * X3_PAIRS * 64 + (tile16 ? (int64_t)nchunks * X3_QUADS * 64 : 0);
+}
+
+__global__ void pack_w3_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cout_w, int Cin_w, int nchunks,
+                                  int otiles, int tile16, int transpose) {
+  const int64_t total = x3_pack_items(nchunks, otiles, tile16);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    pack_w3_x3_item(w, wq, i, Cout_w, Cin_w, kin, mout, nchunks, transpose);
+    pack_w3_x3_any(w, wq, i, Cout_w, Cin_w, nchunks, otiles, tile16, transpose);
 }
 
 void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, int Cin_w, bool transpose, hipStream_t st) {
-  const int kin = transpose ? Cout_w : Cin_w, mout = transpose ? Cin_w : Cout_w;
-  const int64_t total = (int64_t)p.otiles * p.nchunks * X3_PAIRS * 64;
+  const int64_t total = x3_pack_items(p.nchunks, p.otiles, p.tile16);
   hipLaunchKernelGGL(pack_w3_x3_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, st, w,
-                     (u32x4*)wp, Cout_w, Cin_w, kin, mout, p.nchunks, p.otiles, transpose ? 1 : 0);
+                     (u32x4*)wp, Cout_w, Cin_w, p.nchunks, p.otiles, p.tile16, transpose ? 1 : 0);
 }
 
 // every split-kernel weight form of a model in ONE launch (m355_conv3d_pack_batch: after optimizer.step both forms of
@@ -98,10 +135,9 @@ __global__ __launch_bounds__(256) void pack_w3_x3_batch_kernel(const X3PackBatch
   int k = 0;
   while (k + 1 < b.n && (int)blockIdx.x >= b.e[k + 1].blk0) ++k;
   const X3PackEntry& e = b.e[k];
-  const int64_t total = (int64_t)e.otiles * e.nchunks * X3_PAIRS * 64;
-  const int kin = e.transpose ? e.Cout : e.Cin, mout = e.transpose ? e.Cin : e.Cout;
+  const int64_t total = x3_pack_items(e.nchunks, e.otiles, e.tile16);
   for (int64_t i = (int64_t)((int)blockIdx.x - e.blk0) * 256 + threadIdx.x; i < total; i += (int64_t)e.nblk * 256)
-    pack_w3_x3_item(e.w, (u32x4*)e.wq, i, e.Cout, e.Cin, kin, mout, e.nchunks, e.transpose);
+    pack_w3_x3_any(e.w, (u32x4*)e.wq, i, e.Cout, e.Cin, e.nchunks, e.otiles, e.tile16, e.transpose);
 }
 
 void launch_pack_x3_batch(X3PackBatch& b, int n, hipStream_t st) {
@@ -109,7 +145,7 @@ void launch_pack_x3_batch(X3PackBatch& b, int n, hipStream_t st) {
   for (int i = 0; i < n; ++i) {
     X3PackEntry& e = b.e[i];
     e.blk0 = blocks;
-    e.nblk = (int)std::min<int64_t>(ceil_div((int64_t)e.otiles * e.nchunks * X3_PAIRS * 64, 256), 512);
+    e.nblk = (int)std::min<int64_t>(ceil_div(x3_pack_items(e.nchunks, e.otiles, e.tile16), 256), 512);
     blocks += e.nblk;
   }
   b.n = n;
@@ -328,14 +364,222 @@ __global__ __launch_bounds__(256, 2) void conv3_f32x3_kernel(
   }
 }
 
+// ---- the 16-row remainder tile of channel counts that are no multiple of 32 (the reference's real widths are 40 / 80 / 120:
+// research/msseg2/msseg2.py:87) on v_mfma_f32_16x16x32_bf16: half the matrix-pipe time of a padded 32-row tile.  Staging,
+// chunk loop and weight streaming as conv3_f32x3_kernel; C/D layout and epilogue as the fp32 kernels' 16-row tile
+// (store_conv_tile16: col = lane & 15 (voxel), row = 4 * (lane >> 4) + reg).
+template <int NTW, int GX>
+__global__ __launch_bounds__(256, 2) void conv3_f32x3_m16_kernel(
+    const float* __restrict__ x, const u32x4* __restrict__ wq, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ y, float* __restrict__ slab, int Cin, int Cout, int D, int H, int W,
+    int ty_tiles, int tx_tiles, int nchunks, int ksplit, int64_t xbs, int64_t ybs, int64_t slab_stride,
+    float* __restrict__ stat, int o16) {
+  using T = FwdTile<NTW, GX>;
+  constexpr int GY = T::GY, TZ = T::TZ, TY = T::TY, TX = T::TX, RS = T::RS, PS = T::PS;
+  constexpr int NV = (TZ + 2) * PS;            // voxels of the halo tile
+  constexpr int VPER = (NV + 255) / 256;       // voxels staged per thread
+  constexpr int NLOAD = VPER * 8;              // dword loads per thread and chunk
+  constexpr int LPS = (NLOAD + X3_QUADS - 1) / X3_QUADS;   // ... issued per quad step
+  static_assert(3 * NV * 16 <= 64 * 1024 && ((2 * PS + (NTW * GY + 2) * RS + 2) * 16 + 2 * NV * 16) < 65536, "LDS offsets");
+  __shared__ u32x4 xs[3][NV];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const int ly = l32 / GX, lx = l32 % GX;
+
+  // XCD-aware placement: see conv3_mfma_fwd_kernel (one channel tile: the grid is the spatial tiles)
+  int bt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bt = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int sp_count = (int)gridDim.x;
+  const int sp_index = bt;
+  const int txt = bt % tx_tiles;
+  bt /= tx_tiles;
+  const int tyt = bt % ty_tiles;
+  const int tzt = bt / ty_tiles;
+  const int z0 = tzt * TZ, y0 = tyt * TY, x0 = txt * TX;
+  const int o0 = o16;
+  const int n = blockIdx.z / ksplit;
+  const int ks = blockIdx.z % ksplit;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  const int ch_begin = ks * cps;
+  const int ch_end = min(nchunks, ch_begin + cps);
+
+  const float* xn = x + (int64_t)n * xbs;
+  const int iHW = H * W;
+  const int DHW = iHW * D;
+  const unsigned cstride = (unsigned)DHW * 4u;   // < 2^28 (host check): OOB + 7 * cstride does not wrap
+
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[VPER];
+#pragma unroll
+  for (int i = 0; i < VPER; ++i) {
+    const int v = tid + 256 * i;
+    unsigned off = OOB;
+    if (v < NV) {
+      const int zz = v / PS, r2 = v - zz * PS;
+      const int yy = r2 / RS, xx = r2 - yy * RS;
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        off = (unsigned)(gz * iHW + gy * W + gx) * 4u;
+    }
+    goff[i] = off;
+  }
+
+  f32x4v acc[NTW][2];   // [voxel group][16-voxel half]: 4 channels of one voxel per lane
+#pragma unroll
+  for (int g = 0; g < NTW; ++g)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[g][h2][r] = 0.f;
+
+  float xr[VPER][8];
+  __amdgpu_buffer_rsrc_t rx;
+  auto chunk_setup = [&](int ch, bool live) {   // descriptor over the channels of the chunk that exist: the rest reads 0
+    const int c0 = ch * 8;
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (int64_t)c0 * DHW), 0, live ? min(8, Cin - c0) * DHW * 4 : 0,
+                                           0x00020000);
+  };
+  auto fetch = [&](int k) {   // k: compile-time load index
+    if (k < NLOAD)
+      xr[k >> 3][k & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, goff[k >> 3] + (k & 7) * cstride, 0, 0));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < VPER; ++i) {
+      const int v = tid + 256 * i;
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x3_split(xr[i][c], h[c], m[c], l[c]);
+      if (v < NV) {
+        xs[0][v] = (u32x4){x3_pack(h[0], h[1]), x3_pack(h[2], h[3]), x3_pack(h[4], h[5]), x3_pack(h[6], h[7])};
+        xs[1][v] = (u32x4){x3_pack(m[0], m[1]), x3_pack(m[2], m[3]), x3_pack(m[4], m[5]), x3_pack(m[6], m[7])};
+        xs[2][v] = (u32x4){x3_pack(l[0], l[1]), x3_pack(l[2], l[3]), x3_pack(l[4], l[5]), x3_pack(l[6], l[7])};
+      }
+    }
+  };
+
+  // the weight fragments of the tile are one linear stream of (quad, plane) items over the chunks, six quads ahead of
+  // their use (a ring of 7 slots = the quads of a chunk)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wq, 0, nchunks * (X3_QUADS * 3 * 1024), 0x00020000);
+  const int qg_last = ch_end * X3_QUADS - 1;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  constexpr int AR = 7, AD = AR - 1;
+  u32x4 afr[AR][3];   // [slot][plane]; quad q of a chunk sits in slot q
+  auto aload = [&](int slot, int qg) {
+    const int q = min(qg, qg_last) * 3;   // (uniform; past the end of this split: a harmless re-read)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) afr[slot][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, (q + pl) * 1024, 0));
+  };
+
+  if (ch_begin < ch_end) {
+    chunk_setup(ch_begin, true);
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) fetch(k);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) aload(i, ch_begin * X3_QUADS + i);
+    commit();
+  }
+  __syncthreads();
+
+  // K = 32 of a 16x16x32 MFMA = 8 channels x 4 TAPS: 16-lane group kg of a fragment holds tap 4 q + kg of quad q (27 taps = 7
+  // quads, the last slot empty); a 32-voxel group is two MFMAs (its 16-voxel halves).  Per-lane: the halo voxel of its
+  // column for both halves and the tap offsets of its group.
+  const int kg = lane >> 4, l16 = lane & 15;
+  int toff[X3_QUADS], vb16[2];
+#pragma unroll
+  for (int q = 0; q < X3_QUADS; ++q) {
+    const int tap = min(4 * q + kg, 26);   // (slot 27: zero weights)
+    toff[q] = (tap / 9) * PS + ((tap / 3) % 3) * RS + tap % 3;
+  }
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int vox = 16 * h2 + l16;
+    vb16[h2] = wave * PS + (vox / GX) * RS + vox % GX;
+  }
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const bool more = ch + 1 < ch_end;
+    chunk_setup(more ? ch + 1 : ch, more);
+    const int qg = ch * X3_QUADS;
+    // a step = one (quad, voxel group): 12 MFMAs alternating between the group's two halves, the 6 B fragments of the next
+    // step read behind the first six of them, the weights of quad q + 6 and the next chunk's activations behind the rest
+    {
+      constexpr int NSTEP = X3_QUADS * NTW;
+      bf16x8 bq[2][2][3];
+      auto bload = [&](int buf, int q, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bq[buf][h2][pl] = __builtin_bit_cast(bf16x8, xs[pl][vb16[h2] + toff[q] + g * GY * RS]);
+      };
+      bload(0, 0, 0);
+#pragma unroll
+      for (int sb = 0; sb < NSTEP; ++sb) {
+        const int q = sb / NTW, g = sb % NTW;
+        const bool nb = sb + 1 < NSTEP, first = g == 0, last = g == NTW - 1;
+        if (nb) bload((sb + 1) & 1, (sb + 1) / NTW, (sb + 1) % NTW);
+        if (first) aload((q + AD) % AR, qg + q + AD);
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, afr[q][0]), a_mid = __builtin_bit_cast(bf16x8, afr[q][1]),
+                     a_lo = __builtin_bit_cast(bf16x8, afr[q][2]);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+          constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
+          const bf16x8 a = pr == 0 ? a_lo : (pr == 1 || pr == 3 ? a_mid : a_hi);   // (lo,hi) (mid,hi) (hi,hi) (mid,mid) (hi,mid) (hi,lo)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+            acc[g][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[sb & 1][h2][PB[pr]], acc[g][h2], 0, 0, 0);
+        }
+        if (last) {
+#pragma unroll
+          for (int k = 0; k < LPS; ++k) fetch(q * LPS + k);
+        }
+        const int nv = (first ? 3 : 0) + (last ? LPS : 0);   // global loads of this step
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+          if (nb && i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // a B fragment of the next step
+          if (i >= 6 && i - 6 < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+        }
+#pragma unroll
+        for (int i = 6; i < 3 + LPS; ++i)
+          if (i < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();   // every wave has read its fragments of this chunk
+    if (more) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  const int z = z0 + wave;
+  if (ksplit == 1) {
+    float* st = stat ? stat + (((int64_t)n * sp_count + sp_index) * 4 + wave) * Cout * 2 : nullptr;
+    store_conv_tile16<NTW, GX>(acc, y + (int64_t)n * ybs, add ? add + (int64_t)n * ybs : nullptr, bias, o0, Cout, z, y0, x0, lane,
+                               D, H, W, st);
+  } else {
+    store_conv_tile16<NTW, GX>(acc, slab + (int64_t)ks * slab_stride + (int64_t)n * Cout * D * iHW, nullptr, nullptr, o0, Cout, z,
+                               y0, x0, lane, D, H, W, nullptr);
+  }
+}
+
 template <int NTW, int GX>
 static void launch_x3(const FwdPlan& p, const float* x, const void* wp, const float* bias, const float* add, float* y,
                       float* slab, int N, int kin, int mout, int D, int H, int W, int64_t xbs, int64_t ybs, hipStream_t st,
                       float* stat) {
-  dim3 grid((unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles * p.otiles), 1u, (unsigned)(N * p.ksplit));
-  hipLaunchKernelGGL((conv3_f32x3_kernel<NTW, GX>), grid, dim3(256), 0, st, x, (const u32x4*)wp, bias, add, y, slab, kin, mout,
-                     D, H, W, p.ty_tiles, p.tx_tiles, p.nchunks, p.ksplit, xbs, ybs, (int64_t)N * mout * D * H * W, stat,
-                     p.otiles, tuning().conv_cube & 2);
+  const unsigned sp = (unsigned)(p.tz_tiles * p.ty_tiles * p.tx_tiles);
+  if (p.otiles > 0)
+    hipLaunchKernelGGL((conv3_f32x3_kernel<NTW, GX>), dim3(sp * p.otiles, 1u, (unsigned)(N * p.ksplit)), dim3(256), 0, st, x,
+                       (const u32x4*)wp, bias, add, y, slab, kin, mout, D, H, W, p.ty_tiles, p.tx_tiles, p.nchunks, p.ksplit, xbs,
+                       ybs, (int64_t)N * mout * D * H * W, stat, p.otiles, tuning().conv_cube & 2);
+  if (p.tile16)   // the 1..16 remaining channels: their own launch over the spatial tiles (disjoint channels of y / the slabs)
+    hipLaunchKernelGGL((conv3_f32x3_m16_kernel<NTW, GX>), dim3(sp, 1u, (unsigned)(N * p.ksplit)), dim3(256), 0, st, x,
+                       (const u32x4*)wp + (int64_t)p.otiles * p.nchunks * (X3_PAIRS * 3 * 64), bias, add, y, slab, kin, mout, D, H, W,
+                       p.ty_tiles, p.tx_tiles, p.nchunks, p.ksplit, xbs, ybs, (int64_t)N * mout * D * H * W, stat, p.otiles * 32);
 }
 
 // launches the kernel of plan p (p.x3 != 0); the caller (run_mfma_conv) has checked the workspace, packed the weights
