@@ -1149,11 +1149,6 @@ __global__ __launch_bounds__(256, 1) void conv3_mfma_bww_kernel(
 // 40 x 40 channels are 2.25 pair-units of MFMA time instead of 4.  K is a quad of x-adjacent voxels; the fragments
 // are (channel = lane & 15, voxel = lane >> 4), so the LDS channel strides are == 2 (mod 32) there.
 // C/D layout 16x16x4: col (c) = lane & 15, row (o) = 4 * (lane >> 4) + reg.
-struct BwwClasses {
-  int of, cf, orem, crem;   // full 32-channel tiles per side, and whether a 16-row remainder tile follows them
-  int ns[4];                // voxel-range splits of a pair of class (o remainder ? 2 : 0) + (c remainder ? 1 : 0)
-  int start[4];             // first workgroup of each class
-};
 
 template <int GX, int MT, int NT>
 __device__ __forceinline__ void bww2_body(const float* __restrict__ x, const float* __restrict__ dy,
@@ -2901,11 +2896,7 @@ extern "C" int m355_conv3d_bwd_weight(const m355_conv3d_desc* d, const float* x,
     M355_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 3) == 0, M355_EINVALID_ARG, "conv3d_bwd_weight: misaligned tensor");
     float* slab = (float*)workspace;
     if (int rc = launch_bww_x3(p, x, dy, slab, d->N, d->Cin, d->Cout, d->D, d->H, d->W, xbs, ybs, st)) return rc;
-    BwwClasses kred{};
-    kred.of = p.otiles;
-    kred.cf = p.ctiles;
-    for (int c = 0; c < 4; ++c) kred.ns[c] = p.nsplit;
-    launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, p.ctiles, kred, 1.f, st);
+    launch_slab_reduce_t(slab, dw, d->Cin, d->Cout, p.ctiles, p.k, 1.f, st);   // p.k.ns: splits of each pair class
     slab_used = p.slab_bytes;
   } else if (is_k3s1p1(d)) {
     const BwwPlan p = plan_bww(d->N, d->Cin, d->Cout, d->D, d->H, d->W);

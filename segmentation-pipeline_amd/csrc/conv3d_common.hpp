@@ -223,9 +223,20 @@ void launch_pack_w3_x3(const FwdPlan& p, const float* w, void* wp, int Cout_w, i
 int launch_x3_conv(const FwdPlan& p, const float* in, const void* wp, const float* bias, const float* add, float* out,
                    float* slab, int N, int kin, int mout, int D, int H, int W, int64_t in_bs, int64_t out_bs, hipStream_t st,
                    float* stat);
-// ... and its weight gradient (conv3_bww_x3_kernel): slab[nsplit][27][Cout][Cin] partials, reduced by the caller
+// pair classes of a weight gradient whose channel counts leave a 1..16 channel remainder (conv3_mfma_bww2c_kernel,
+// conv3_bww_x3c_kernel)
+struct BwwClasses {
+  int of, cf, orem, crem;   // full 32-channel tiles per side, and whether a 16-row remainder tile follows them
+  int ns[4];                // voxel-range splits of a pair of class (o remainder ? 2 : 0) + (c remainder ? 1 : 0)
+  int start[4];             // first workgroup of each class
+};
+// ... and its weight gradient (conv3_bww_x3_kernel / conv3_bww_x3c_kernel): slab[split][27][Cout][Cin] partials, reduced by
+// the caller with k.ns[class] splits per pair class
 struct BwwX3Plan {
   int tx, ty_tiles, tx_tiles, ctiles, otiles, nsplit;
+  bool classes;     // a 1..16 channel remainder on either side: the class kernel
+  BwwClasses k;     // always filled: without remainders one class with ns[*] = nsplit
+  int class_wgs;
   size_t slab_bytes;
 };
 BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W);

@@ -636,33 +636,39 @@ __device__ __forceinline__ bf16x8 x3_tr_frag(const unsigned char* p) {   // two 
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// Channel counts that are no multiple of 32 (the reference's real widths are 40 / 80 / 120): as in conv3_mfma_bww2c_kernel a
+// remainder of 1..16 channels on the o and / or the c side runs on 16-channel sub-tiles (MT x NT of them), here on
+// v_mfma_f32_16x16x32_bf16 -- K = 32 voxels = two of the tile's 16-voxel k-steps at once, the four 16-lane groups of the
+// transposed read take its four voxel octets -- and the staging waves stage only the channel blocks the sub-tiles read:
+// a (32 o, 16 c) pair costs half a full pair, (16, 16) about a third (it is then the staging that sets its tile time).
+// C/D layout 16x16: col (c) = lane & 15, row (o) = 4 * (lane >> 4) + reg.
 template <int TX>
-__global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int Cin, int Cout, int D,
-    int H, int W, int ty_tiles, int tx_tiles, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs) {
+struct BwX3 {
+  static constexpr int TY = 64 / TX, HR = TX + 2, HP = (TY + 2) * HR;
+  static constexpr int PLANE_B = HP * 64 + 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;
+};
+
+template <int TX, int MT, int NT>
+__device__ __forceinline__ void bww_x3_body(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ sl, int N, int Cin, int Cout, int D,
+    int H, int W, int ty_tiles, int tx_tiles, int nsplit, int split, int c0, int o0, int64_t xbs, int64_t ybs,
+    unsigned char* __restrict__ xs, unsigned char* __restrict__ ds) {
+  constexpr bool F = MT == 2 && NT == 2;                         // full pair: 32x32x16 MFMAs, 4 k-steps of 16 voxels
+  constexpr int CBX = 2 * NT, CBD = 2 * MT;                      // 8-channel blocks staged of x / of dy
   constexpr int TY = 64 / TX, HR = TX + 2, HP = (TY + 2) * HR;   // tile rows; halo row / plane in voxels
-  constexpr int XI = HP * 4, XPER = (XI + 255) / 256;            // 8-channel items of a halo plane, per staging thread
+  constexpr int XI = HP * CBX, XPER = (XI + 255) / 256;          // 8-channel items of a halo plane, per staging thread
   constexpr int PLANE_B = HP * 64 + 64, SLOT_B = 3 * PLANE_B, DBUF_B = 3 * 4096;   // + one pad row: where threads without an item write
   constexpr int KH = TX >= 16 ? 8 : HR;                          // voxels 8..15 of a k-step: 8 columns on, or the next row
   constexpr unsigned OOB = 0x80000000u;
   static_assert(4 * SLOT_B + 2 * DBUF_B <= 160 * 1024 && 2 * PLANE_B + 8 * HR * 64 + 512 < 65536, "LDS size / read offsets");
-  __shared__ __attribute__((aligned(16))) unsigned char xs[4 * SLOT_B];   // [slot][split plane][halo voxel][32 channels]
-  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * DBUF_B];   // [buffer][split plane][voxel][32 channels]
+  static_assert(PLANE_B == BwX3<TX>::PLANE_B, "layout");
+  // xs: [slot][split plane][halo voxel][32 channels]; ds: [buffer][split plane][voxel][32 channels]
 
   const int lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const bool stager = wave8 >= 4;
   const int wave = wave8 & 3;                 // of its role
   const int tid = threadIdx.x & 255;          // thread of its role
-  int vid;  // XCD-aware placement, (c-tile, o-tile) pair fastest: see conv3_mfma_bww2_kernel
-  {
-    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int pairs = ctiles * otiles;
-  const int pair = vid % pairs, split = vid / pairs;
-  const int ctile = pair % ctiles, otile = pair / ctiles;
   const int iHW = H * W, S = D * iHW;
 
   // tiles: z fastest inside a (sample, y tile, x tile) column; split s owns a contiguous range
@@ -684,13 +690,14 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
 #pragma unroll
     for (int k = 0; k < XPER; ++k) {
       const int e = tid + 256 * k;
-      const int cbl = e & 3, hv = e >> 2;
+      const int cbl = e % CBX, hv = e / CBX;
       const int yy = hv / HR, xx = hv - yy * HR;
       xrel[k] = cbl * 8 * S + yy * W + xx;
       xdst[k] = e < XI ? hv * 64 + cbl * 16 : HP * 64 + (tid & 3) * 16;
       xcode[k] = e < XI ? (1u << yy) | ((unsigned)xx << 16) : 0xffffu;   // past the end: never valid
     }
-    const int dv = tid >> 2, dcb = tid & 3;             // dy item: (voxel of the tile, 8-channel block)
+    const int dv = (tid / CBD) & 63, dcb = tid % CBD;   // dy item: (voxel of the tile, 8-channel block); threads past 64 CBD: none
+    const bool dhas = tid < 64 * CBD;
     const int dvy = dv / TX, dvx = dv - dvy * TX;
     const int ddst = dv * 64 + dcb * 16;
 
@@ -704,16 +711,16 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
       const int c2 = col / tx_tiles;
       const int tyt = c2 % ty_tiles, n = c2 / ty_tiles;
       const int y0 = tyt * TY, x0 = txt * TX;
-      const int nbx = min(32, Cin - 32 * ctile), nbd = min(32, Cout - 32 * otile);
-      rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)(32 * ctile) * S), 0, nbx * S * 4, 0x00020000);
-      rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)(32 * otile) * S), 0, nbd * S * 4, 0x00020000);
+      const int nbx = min(16 * NT, Cin - c0), nbd = min(16 * MT, Cout - o0);
+      rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * xbs + (int64_t)c0 * S), 0, nbx * S * 4, 0x00020000);
+      rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * ybs + (int64_t)o0 * S), 0, nbd * S * 4, 0x00020000);
       ymask = 0u;
       for (int yy = 0; yy < TY + 2; ++yy)
         if (y0 + yy - 1 >= 0 && y0 + yy - 1 < H) ymask |= 1u << yy;
       colbase = (y0 - 1) * W + x0 - 1;
       xlim = x0 - 1;                                   // halo column xx is inside the volume iff 0 <= xlim + xx < W
       const int gy = y0 + dvy, gx = x0 + dvx;
-      dok = (gy < H) & (gx < W);
+      dok = dhas & (gy < H) & (gx < W);
       dbase = dcb * 8 * S + gy * W + gx;
     };
     auto fetch_plane = [&](float (&r)[XPER][8], int p, bool on) __attribute__((always_inline)) {   // halo plane p (absolute z, may lie outside)
@@ -746,7 +753,9 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
 #pragma unroll
       for (int k = 0; k < XPER; ++k) commit8(r[k], xs + slot * SLOT_B + xdst[k], PLANE_B);
     };
-    auto commit_dy = [&](const float (&r)[8], int b) __attribute__((always_inline)) { commit8(r, ds + b * DBUF_B + ddst, 4096); };
+    auto commit_dy = [&](const float (&r)[8], int b) __attribute__((always_inline)) {
+      if (dhas) commit8(r, ds + b * DBUF_B + ddst, 4096);   // (wave-uniform: 64 CBD is a multiple of 64)
+    };
     // start of a column / of this split's range: the three planes of tile zz, loaded here and now (once per D tiles)
     auto cold = [&](int zz) __attribute__((always_inline)) {
       float r0[XPER][8], r1[XPER][8], r2[XPER][8];
@@ -806,10 +815,12 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
   // ---------------------------------------------------------------------------------------------- multiplying waves
   const int half = lane >> 5, l32 = lane & 31;
   // transposed-read lane bases: lane 4q + p of a 16-lane group addresses voxel row q, channels 4p .. 4p+3 of its
-  // group's 16-channel half; groups 2, 3 (the upper MFMA half) take the voxels 8 .. 15 of the k-step
+  // group's 16-channel half; groups 2, 3 (the upper MFMA half) take the voxels 8 .. 15 of the k-step.  Sub-tile form:
+  // the four groups take the four voxel octets of a 32-voxel step, all of the same 16 channels.
   const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int lbA = (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
-  const int lbB = (KH * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8;
+  const int oct = TX == 32 ? 8 * grp : (TX == 16 ? (grp >> 1) * HR + 8 * (grp & 1) : grp * HR);
+  const int lbA = F ? (8 * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8 : (8 * grp + tq) * 64 + tp * 8;
+  const int lbB = F ? (KH * (grp >> 1) + tq) * 64 + (grp & 1) * 32 + tp * 8 : (oct + tq) * 64 + tp * 8;
   int tdz[7], tyx[7];   // this wave's taps: plane offset dz, byte offset of (dy, dx) inside a plane
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
@@ -818,11 +829,24 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
     tyx[t] = (((tap / 3) % 3) * HR + tap % 3) * 64 + lbB;
   }
 
-  f32x16 acc[7];
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  f32x16 acc[F ? 7 : 1];
+  f32x4a acc16[F ? 1 : 7][MT][NT];
+  if constexpr (F) {
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+    for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc16[t][mt][nt][r] = 0.f;
+  }
 
   __syncthreads();   // the first tile is in LDS
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -831,9 +855,9 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
 #pragma unroll
     for (int t = 0; t < 7; ++t) xt[t] = xs + tyx[t] + ((z + tdz[t]) & 3) * SLOT_B;
     const unsigned char* da = ds + buf * DBUF_B + lbA;
-    // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
-    // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one
-    {
+    if constexpr (F) {
+      // 4 k-steps x 7 taps, software-pipelined by one tap: the three x planes of the next (k-step, tap) -- and, once per
+      // k-step, the three dy planes of the next k-step -- are requested between the six MFMAs of this one
       auto afrag = [&](int g, int pl) __attribute__((always_inline)) { return x3_tr_frag(da + pl * 4096 + g * 1024); };
       auto bfrag = [&](int g, int t, int pl) __attribute__((always_inline)) {
         const int goff = (TX == 32 ? (g >> 1) * HR + 16 * (g & 1) : (TX == 16 ? g * HR : 2 * g * HR)) * 64;
@@ -876,6 +900,62 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+      // sub-tile form: 2 steps of 32 voxels x 7 taps; per (step, tap) MT x NT x 6 MFMAs 16x16x32, product by product over
+      // the sub-tiles, software-pipelined by one tap
+      auto afrag = [&](int ks, int mt, int pl) __attribute__((always_inline)) {
+        return x3_tr_frag(da + pl * 4096 + ks * 2048 + mt * 32);
+      };
+      auto bfrag = [&](int ks, int t, int nt, int pl) __attribute__((always_inline)) {
+        const int koff = (TX == 32 ? ks * HR : (TX == 16 ? 2 * ks * HR : 4 * ks * HR)) * 64;
+        return x3_tr_frag(xt[t] + pl * PLANE_B + koff + nt * 32);
+      };
+      bf16x8 aq[2][MT][3], bq[2][NT][3];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) aq[0][mt][pl] = afrag(0, mt, pl);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bq[0][nt][pl] = bfrag(0, 0, nt, pl);
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        const int g = s / 7, t = s % 7;
+        const bool nb = s + 1 < 14, na = t == 0 && g + 1 < 2;
+        if (nb) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[(s + 1) & 1][nt][pl] = bfrag((s + 1) / 7, (s + 1) % 7, nt, pl);
+        }
+        if (na) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) aq[(g + 1) & 1][mt][pl] = afrag(g + 1, mt, pl);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+          constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 0, 1, 2, 1, 0};   // (lo,hi) (mid,hi) (mid,mid) (hi,lo) (hi,mid) (hi,hi)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc16[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[g & 1][mt][PA[pr]], bq[s & 1][nt][PB[pr]],
+                                                                          acc16[t][mt][nt], 0, 0, 0);
+        }
+        constexpr int NM = 6 * MT * NT;   // MFMAs of a step; its reads go out behind the first half of them
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+          if (nb && i < NM / 2) {
+            if (na) __builtin_amdgcn_sched_group_barrier(0x100, (6 * NT + 6 * MT + NM / 2 - 1) / (NM / 2), 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, (6 * NT + NM / 2 - 1) / (NM / 2), 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();   // every wave is done reading this tile; the next one is in LDS
     const bool newcol = z + 1 == D;
@@ -884,19 +964,86 @@ __global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
     buf ^= 1;
   }
 
-  // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 consecutive floats per store)
-  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
-  const int c = ctile * 32 + l32;
+  // partial dW -> slab[split][27][Cout][Cin] (lane = input channel: 32 / 16 consecutive floats per store)
+  if constexpr (F) {
+    const int c = c0 + l32;
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = wave * 7 + t;
-    if (tap < 27 && c < Cin) {
+    for (int t = 0; t < 7; ++t) {
+      const int tap = wave * 7 + t;
+      if (tap < 27 && c < Cin) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = otile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc[t][r];
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int tap = wave * 7 + t;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int c = c0 + 16 * nt + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * mt + 4 * grp + r;
+            if (tap < 27 && c < Cin && o < Cout) sl[((int64_t)tap * Cout + o) * Cin + c] = acc16[t][mt][nt][r];
+          }
+        }
+    }
+  }
+}
+
+template <int TX>
+__global__ __launch_bounds__(512, 1) void conv3_bww_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int Cin, int Cout, int D,
+    int H, int W, int ty_tiles, int tx_tiles, int nsplit, int ctiles, int otiles, int64_t xbs, int64_t ybs) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[4 * BwX3<TX>::SLOT_B];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * BwX3<TX>::DBUF_B];
+  int vid;  // XCD-aware placement, (c-tile, o-tile) pair fastest: see conv3_mfma_bww2_kernel
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pairs = ctiles * otiles;
+  const int pair = vid % pairs, split = vid / pairs;
+  bww_x3_body<TX, 2, 2>(x, dy, slab + (int64_t)split * 27 * Cout * Cin, N, Cin, Cout, D, H, W, ty_tiles, tx_tiles, nsplit, split,
+                        (pair % ctiles) * 32, (pair / ctiles) * 32, xbs, ybs, xs, ds);
+}
+
+// The same with the pairs of a channel remainder on their 16-channel sub-tiles: ONE launch holds all four pair classes, each
+// cut into a number of voxel-range splits proportional to its cost (see conv3_mfma_bww2c_kernel).
+template <int TX>
+__global__ __launch_bounds__(512, 1) void conv3_bww_x3c_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int Cin, int Cout, int D,
+    int H, int W, int ty_tiles, int tx_tiles, BwwClasses k, int64_t xbs, int64_t ybs) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[4 * BwX3<TX>::SLOT_B];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[2 * BwX3<TX>::DBUF_B];
+  int vid;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int cls = vid >= k.start[3] ? 3 : (vid >= k.start[2] ? 2 : (vid >= k.start[1] ? 1 : 0));
+  const int idx = vid - k.start[cls];
+  const int npairs = cls == 0 ? k.of * k.cf : (cls == 1 ? k.of : (cls == 2 ? k.cf : 1));
+  const int pair = idx % npairs, split = idx / npairs;
+  float* sl = slab + (int64_t)split * 27 * Cout * Cin;
+  const int ns = k.ns[cls];
+  if (cls == 0) {
+    bww_x3_body<TX, 2, 2>(x, dy, sl, N, Cin, Cout, D, H, W, ty_tiles, tx_tiles, ns, split, (pair % k.cf) * 32, (pair / k.cf) * 32,
+                          xbs, ybs, xs, ds);
+  } else if (cls == 1) {   // c remainder: 32 o x 16 c
+    bww_x3_body<TX, 2, 1>(x, dy, sl, N, Cin, Cout, D, H, W, ty_tiles, tx_tiles, ns, split, k.cf * 32, pair * 32, xbs, ybs, xs, ds);
+  } else if (cls == 2) {   // o remainder: 16 o x 32 c
+    bww_x3_body<TX, 1, 2>(x, dy, sl, N, Cin, Cout, D, H, W, ty_tiles, tx_tiles, ns, split, pair * 32, k.of * 32, xbs, ybs, xs, ds);
+  } else {
+    bww_x3_body<TX, 1, 1>(x, dy, sl, N, Cin, Cout, D, H, W, ty_tiles, tx_tiles, ns, split, k.cf * 32, k.of * 32, xbs, ybs, xs, ds);
   }
 }
 
@@ -919,15 +1066,27 @@ BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W) {
   p.tx_tiles = (int)ceil_div(W, p.tx);
   p.ctiles = (int)ceil_div(Cin, 32);
   p.otiles = (int)ceil_div(Cout, 32);
-  const int64_t ntiles = (int64_t)N * p.ty_tiles * p.tx_tiles * D, pairs = (int64_t)p.ctiles * p.otiles;
+  const int64_t ntiles = (int64_t)N * p.ty_tiles * p.tx_tiles * D;
+  const auto rem16 = [](int c) { return c % 32 >= 1 && c % 32 <= 16 ? 1 : 0; };
+  p.k.orem = tuning().tile16 ? rem16(Cout) : 0;
+  p.k.crem = tuning().tile16 ? rem16(Cin) : 0;
+  p.k.of = p.otiles - p.k.orem;
+  p.k.cf = p.ctiles - p.k.crem;
+  p.classes = p.k.orem || p.k.crem;
+  // cost of a tile of each pair class in units of a full 32 x 32 pair (the (16, 16) class is bound by its staging)
+  const double cost[4] = {1.0, 0.5, 0.5, 0.35};
+  const int64_t npairs[4] = {(int64_t)p.k.of * p.k.cf, (int64_t)p.k.of * p.k.crem, (int64_t)p.k.orem * p.k.cf,
+                             (int64_t)p.k.orem * p.k.crem};
+  double units = 0;
+  for (int c = 0; c < 4; ++c) units += cost[c] * (double)npairs[c];
   const int cus = num_cus();
-  // one workgroup per CU: time ~ residencies x (tiles per split x ~4 us + ~10 us of cold start and slab write) + the
+  // one workgroup per CU: time ~ residencies x (tiles per split x ~3.5 us + ~10 us of cold start and slab write) + the
   // slab traffic (written here, read by the reduction)
   const double slab_us = 2.0 * (double)Cout * Cin * 27 * 4 / 4.0e6;   // per split
   int64_t cand[32];
   int nc = 0;
   for (int64_t ns = 1; ns < ntiles && nc < 20; ns *= 2) cand[nc++] = ns;
-  for (int r = 1; r <= 6; ++r) cand[nc++] = std::max<int64_t>(1, (int64_t)cus * r / pairs);
+  for (int r = 1; r <= 6; ++r) cand[nc++] = std::max<int64_t>(1, (int64_t)((double)cus * r / units));
   cand[nc++] = std::max<int64_t>(1, ntiles);
   std::sort(cand, cand + nc);
   double best = 1e30;
@@ -935,21 +1094,52 @@ BwwX3Plan plan_bww_x3(int N, int Cin, int Cout, int D, int H, int W) {
   for (int i = 0; i < nc; ++i) {
     const int64_t ns = std::min<int64_t>(cand[i], std::max<int64_t>(1, ntiles));
     if (ns * Cout * Cin * 27 * 4 > (256ll << 20) && ns > 1) continue;
-    const double rounds = (double)ceil_div(pairs * ns, cus);
-    const double cost = rounds * ((double)ceil_div(ntiles, ns) * 4.0 + 10.0) + (double)ns * slab_us;
-    if (cost < best * 0.97) {
-      best = cost;
+    const double rounds = std::ceil(units * (double)ns / (double)cus - 1e-9);
+    const double cost_us = rounds * ((double)ceil_div(ntiles, ns) * 4.0 + 10.0) + (double)ns * slab_us;
+    if (cost_us < best * 0.97) {
+      best = cost_us;
       nsplit = ns;
     }
   }
   if (const int force = tuning().bww_nsplit) nsplit = std::min<int64_t>(force, std::max<int64_t>(1, ntiles));
   p.nsplit = (int)nsplit;
-  p.slab_bytes = (size_t)round_up(nsplit * Cout * Cin * 27 * 4, 256);
+  int64_t max_ns = nsplit;
+  for (int c = 0; c < 4; ++c) p.k.ns[c] = p.nsplit;
+  if (p.classes) {
+    // the split count of a class is proportional to its cost, so that every workgroup of the launch lasts about equally
+    // long; the rounding of the per-class counts must not spill a workgroup into another residency
+    double base = (double)nsplit;
+    const int64_t budget = (int64_t)std::ceil(units * base / (double)cus - 1e-9) * cus;
+    for (;;) {
+      int wg = 0;
+      max_ns = 1;
+      for (int c = 0; c < 4; ++c) {
+        const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)(base * cost[c] + 0.5)));
+        p.k.ns[c] = npairs[c] ? (int)ns : 1;
+        p.k.start[c] = wg;
+        wg += (int)(npairs[c] * p.k.ns[c]);
+        if (npairs[c]) max_ns = std::max<int64_t>(max_ns, ns);
+      }
+      p.class_wgs = wg;
+      if (wg <= budget || base <= 1.0 || tuning().bww_nsplit) break;
+      base *= 0.99;
+    }
+  }
+  p.slab_bytes = (size_t)round_up(max_ns * Cout * Cin * 27 * 4, 256);
   return p;
 }
 
 int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* slab, int N, int Cin, int Cout, int D, int H,
                   int W, int64_t xbs, int64_t ybs, hipStream_t st) {
+  if (p.classes) {
+    const dim3 grid((unsigned)p.class_wgs);
+#define M355_X3_BWWC(TXV)                                                                                               \
+  hipLaunchKernelGGL((conv3_bww_x3c_kernel<TXV>), grid, dim3(512), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, p.ty_tiles, \
+                     p.tx_tiles, p.k, xbs, ybs);
+    if (p.tx == 32) { M355_X3_BWWC(32) } else if (p.tx == 16) { M355_X3_BWWC(16) } else { M355_X3_BWWC(8) }
+#undef M355_X3_BWWC
+    return M355_OK;
+  }
   const dim3 grid((unsigned)(p.ctiles * p.otiles * p.nsplit));
 #define M355_X3_BWW(TXV)                                                                                              \
   hipLaunchKernelGGL((conv3_bww_x3_kernel<TXV>), grid, dim3(512), 0, st, x, dy, slab, N, Cin, Cout, D, H, W, p.ty_tiles, \
@@ -958,7 +1148,6 @@ int launch_bww_x3(const BwwX3Plan& p, const float* x, const float* dy, float* sl
 #undef M355_X3_BWW
   return M355_OK;
 }
-
 
 // ------------------------------------------------------------------------------------ ConvTranspose3d k2 s2, forward
 // Y[m, v] = bias[o] + sum_ci W[ci, m] * X[ci, v], m = o * 8 + t (convt.hip: every input voxel owns its 2x2x2 output block)
