@@ -1,5 +1,8 @@
-// fp32 convolution on the bf16 matrix pipe: M355_COMPUTE_F32X3 (3x3x3 / stride 1 / pad 1, forward and data gradient of
-// nn.Conv3d in Block3d, /root/reference/segmentation_pipeline/models/components.py:48-56).
+// fp32 convolution on the bf16 matrix pipe: M355_COMPUTE_F32X3 -- forward, data gradient and weight gradient of the
+// 3x3x3 / stride 1 / pad 1 nn.Conv3d in Block3d (/root/reference/segmentation_pipeline/models/components.py:48-56) and the
+// forward of the k2 s2 nn.ConvTranspose3d (models/modular_unet.py:72-81).  In this file: conv3_f32x3_kernel (+ the 16-row
+// remainder tile conv3_f32x3_m16_kernel), conv3_bww_x3_kernel / conv3_bww_x3c_kernel, convt_k2s2_fwd_x3_kernel, the weight
+// packs and the planners of the weight gradient.
 //
 // The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate and this chip clocks both down under load
 // (DESIGN 4.6), so the fp32 layers sit at the power ceiling of that instruction.  An fp32 number splits EXACTLY into three
@@ -9,8 +12,9 @@
 //     x * w = hi*hi + (hi*mid + mid*hi) + (hi*lo + mid*mid + lo*hi) + [mid*lo + lo*mid + lo*lo <= 2^-24 |x*w|]
 // Six v_mfma_f32_32x32x16_bf16 (K = 16 each) stand for eight fp32 MFMAs (K = 2 each) at a sixteenth of the cost per K:
 // 2.7x fewer matrix-core cycles for the same sum, with the dropped terms below half an ulp of each product.  Measured
-// against an fp64 convolution the result is as accurate as the fp32 MFMA kernel's (max |err| / max |y| 4e-7 .. 1.2e-6
-// for both on the cfg2 layers: the error is the fp32 ACCUMULATION's either way; profiles/r04_f32x3_accuracy.txt).
+// against an fp64 convolution the result is as accurate as fp32 arithmetic is (max |err| / max |y| 2e-7 .. 1.5e-6 on the
+// cfg2 layers, within 2.5x of the fp32 MFMA kernel's: the error is an fp32 ACCUMULATION's either way;
+// profiles/r04_f32x3_accuracy.txt).
 //
 // Data flow: the activations stay fp32 NCDHW in HBM.  A workgroup stages the halo tile of an 8-channel chunk through
 // registers (coalesced dword loads along x through a buffer descriptor that returns 0 for padding), splits every
@@ -20,7 +24,8 @@
 // half tap t1 of a pair (27 taps = 14 pairs, the last one half empty), so a chunk is 8 channels and its three planes
 // fit LDS twice per CU (58.8 KB per workgroup at NTW = 4).  The weights are split and laid out in fragment order once
 // per optimizer step (pack_w3_x3_kernel: [channel tile][chunk][pair][plane][lane] x 16 B) and stream from L2 straight
-// into registers, two pairs ahead of their use -- their three planes would not fit LDS next to the activations.
+// into registers, two (NTW = 4) or six (NTW <= 2) pairs ahead of their use -- their three planes would not fit LDS next
+// to the activations.
 #include "conv3d_common.hpp"
 
 namespace m355 {
