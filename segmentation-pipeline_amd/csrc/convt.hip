@@ -9,7 +9,8 @@
 // 2x2x2 output block, i.e. a [8*Cout x Cin] x [Cin x voxels] GEMM with AI ~ 28
 // flop/B in fp32 -> HBM-bound.  The three k2s2 ops run as
 // fp32-MFMA GEMMs with the voxel on the lane (coalesced x reads, float2-coalesced
-// y / dy accesses); any other geometry takes the generic direct kernels below.
+// y / dy accesses); any other geometry takes the generic direct kernels below.  (M355_COMPUTE_F32X3: the forward runs
+// on the bf16 matrix pipe through the exact three-way operand split -- convt_k2s2_fwd_x3_kernel, conv3d_f32x3.hip.)
 #include "h16.hpp"
 
 namespace m355 {
