@@ -113,6 +113,28 @@ def test_conv3d_f32x3_fwd_bwd(hip, oracle, case, tuning):
         assert a <= max(3.0 * r, 2e-6) and a < 3e-6, f"{name}: split kernels {a:.2e} vs fp32 MFMA {r:.2e} (relative to max |fp64 result|)"
 
 
+def test_conv3d_f32x3_channel_remainders_on_16_row_tiles(hip, oracle, tuning):
+    """Channel counts that are no multiple of 32 (the reference's 40 / 80 / 120, research/msseg2/msseg2.py:87) on the split
+    kernels: the 1..16 remaining output channels of forward / data gradient on conv3_f32x3_m16_kernel (v_mfma_f32_16x16x32_bf16),
+    the weight gradient's remainder pairs on the 16-channel sub-tiles of conv3_bww_x3c_kernel -- against the oracle and
+    against the padded 32-row plans (M355_TILE16=0), which must agree to summation-order noise; every lane width, fused
+    statistics, split-K."""
+    for (N, ci, co, D, H, W) in [(1, 64, 40, 8, 8, 16), (1, 40, 80, 8, 12, 32), (2, 12, 8, 9, 10, 36), (1, 33, 16, 5, 9, 8),
+                                 (1, 48, 33, 6, 7, 20), (1, 20, 120, 4, 8, 8), (1, 80, 40, 6, 10, 24)]:
+        x, w, b = torch.relu(rnd(N, ci, D, H, W, seed=1)), rnd(co, ci, 3, 3, 3, seed=2) * (1.0 / (27 * ci) ** 0.5), rnd(co, seed=3)
+        add, dy = rnd(N, co, D, H, W, seed=4), rnd(N, co, D, H, W, seed=5)
+        got = {}
+        for t16 in (1, 0):
+            tuning(M355_TILE16=t16)
+            got[t16] = (hip.conv3d_fwd(x, w, b, add, compute=X3), hip.conv3d_bwd_data(dy, w, x.shape, compute=X3),
+                        hip.conv3d_bwd_weight(x, dy, 3, compute=X3)[0])
+        close(got[1][0], oracle.conv3d_fwd(x, w, b, add), what=f"fwd {ci}->{co}")
+        close(got[1][1], oracle.conv3d_bwd_data(dy, w, x.shape), what=f"bwd_data {ci}->{co}")
+        close(got[1][2], oracle.conv3d_bwd_weight(x, dy, 3)[0], 3e-5, 3e-5 * (N * D * H * W) ** 0.5, what=f"bwd_weight {ci}->{co}")
+        for a, p_, name in zip(got[1], got[0], ("fwd", "bwd_data", "bwd_weight")):
+            close(a, p_, 3e-6, 3e-6, f"{name} vs the padded plan {ci}->{co}")
+
+
 def test_conv3d_f32x3_split_is_exact_on_hard_operands(hip):
     """The three-way split must reproduce values a bf16 rounding would destroy: operands with all 24 significant bits in
     use, mixed magnitudes (2^-20 .. 2^20 per channel), signed zeros; a non-finite operand makes exactly the outputs it
